@@ -1,0 +1,381 @@
+// gcr_api.hip -- C ABI of libgcr_hip.so (declared in include/gcr.h): scratch-buffer layout,
+// stage sequencing on the caller's HIP stream, error reporting, optional per-stage timing.
+// Stage order follows cr/rasterizer_impl.cu:178-283 (forward) and :287-338 (backward).
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "gcr_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+std::atomic<int> g_fast_exp{0};
+std::atomic<int> g_timing{0};
+
+enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PRE_BWD, ST_COUNT };
+thread_local float g_stage_ms[ST_COUNT];
+
+int fail(gcr_status code, const std::string& msg) {
+  g_err = msg;
+  return (int)code;
+}
+int fail_hip(hipError_t e, const char* where) {
+  g_err = std::string(where) + ": " + hipGetErrorString(e);
+  return (int)GCR_ERR_DEVICE;
+}
+#define HIP_TRY(expr, where)                      \
+  do {                                            \
+    hipError_t _e = (expr);                       \
+    if (_e != hipSuccess) return fail_hip(_e, where); \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// RAII stage timer: two hipEvents on the caller's stream, resolved at scope exit (sync).
+struct StageTimer {
+  hipStream_t s;
+  int stage;
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on;
+  StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_), on(g_timing.load() != 0) {
+    if (on) {
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, s);
+    }
+  }
+  ~StageTimer() {
+    if (on) {
+      (void)hipEventRecord(b, s);
+      (void)hipEventSynchronize(b);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, a, b);
+      g_stage_ms[stage] = ms;
+      (void)hipEventDestroy(a);
+      (void)hipEventDestroy(b);
+    }
+  }
+};
+
+int debug_sync(const gcr_camera* cam, hipStream_t s, const char* where) {
+  if (cam->debug) {  // cr/auxiliary.h:158-167
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail_hip(e, where);
+  }
+  return 0;
+}
+
+void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
+  const size_t p = (size_t)(P > 0 ? P : 0);
+  const size_t nblk = (p + 255) / 256;
+  size_t o = 0;
+  L->geom_rec = o;            o = align_up(o + p * sizeof(float4) * GCR_REC_QUADS);
+  L->geom_cov3D = o;          o = align_up(o + p * 6 * sizeof(float));
+  L->geom_clamped = o;        o = align_up(o + p);
+  L->geom_tiles_touched = o;  o = align_up(o + p * sizeof(uint32_t));
+  L->geom_block_sums = o;     o = align_up(o + (nblk + 1) * sizeof(uint32_t));
+  L->geom_num_rendered = o;   o = align_up(o + sizeof(uint64_t));
+  L->geom_total = o;
+
+  const size_t npix = (size_t)(W > 0 ? W : 0) * (size_t)(H > 0 ? H : 0);
+  const size_t gx = (size_t)(W + GCR_BLOCK_X - 1) / GCR_BLOCK_X, gy = (size_t)(H + GCR_BLOCK_Y - 1) / GCR_BLOCK_Y;
+  const size_t T = gx * gy;
+  o = 0;
+  L->img_final_T = o;    o = align_up(o + npix * sizeof(float));
+  L->img_n_contrib = o;  o = align_up(o + npix * sizeof(uint32_t));
+  L->img_ranges = o;     o = align_up(o + T * 2 * sizeof(uint32_t));
+  L->img_total = o;
+
+  const size_t r = (size_t)(R > 0 ? R : 0);
+  const int end_bit = 32 + (int)gcr_higher_msb((uint32_t)T);
+  o = 0;
+  L->bin_keys[0] = o;  o = align_up(o + r * sizeof(uint64_t));
+  L->bin_keys[1] = o;  o = align_up(o + r * sizeof(uint64_t));
+  L->bin_vals[0] = o;  o = align_up(o + r * sizeof(uint32_t));
+  L->bin_vals[1] = o;  o = align_up(o + r * sizeof(uint32_t));
+  L->bin_hist = o;     o = align_up(o + gcr_sort_hist_bytes((int64_t)r, end_bit));
+  L->bin_sorted = (size_t)(gcr_sort_passes(end_bit) & 1);
+  L->bin_total = o;
+}
+
+int check_inputs(const gcr_camera* cam, const gcr_gaussians* g, bool need_opacity = true) {
+  if (!cam || !g) return fail(GCR_ERR_INVALID_ARGUMENT, "null camera/gaussians record");
+  if (g->P < 0) return fail(GCR_ERR_INVALID_ARGUMENT, "P must be >= 0");
+  if (cam->img_w <= 0 || cam->img_h <= 0) return fail(GCR_ERR_INVALID_ARGUMENT, "image size must be positive");
+  if (cam->img_w > 16 * 65535 || cam->img_h > 16 * 65535)
+    return fail(GCR_ERR_INVALID_ARGUMENT, "image too large for 16-bit tile coordinates");
+  if (!cam->bg || !cam->view_matrix || !cam->proj_matrix || !cam->campos)
+    return fail(GCR_ERR_INVALID_ARGUMENT, "bg/view_matrix/proj_matrix/campos must be non-null");
+  if (g->P == 0) return 0;
+  if (!g->means3D) return fail(GCR_ERR_INVALID_ARGUMENT, "means3D must have dimensions (num_points, 3)");
+  if (need_opacity && !g->opacities) return fail(GCR_ERR_INVALID_ARGUMENT, "opacities must be non-null");
+  if ((g->shs == nullptr) == (g->colors_precomp == nullptr))
+    return fail(GCR_ERR_INVALID_ARGUMENT, "provide exactly one of SHs or precomputed colors");
+  const bool has_sr = g->scales != nullptr && g->rotations != nullptr;
+  if (has_sr == (g->cov3D_precomp != nullptr) || ((g->scales != nullptr) != (g->rotations != nullptr)))
+    return fail(GCR_ERR_INVALID_ARGUMENT,
+                "provide exactly one of scale/rotation pair or precomputed 3D covariance");
+  if (g->shs) {
+    if (cam->sh_degree < 0 || cam->sh_degree > 3) return fail(GCR_ERR_INVALID_ARGUMENT, "sh_degree must be 0..3");
+    if (g->M < (cam->sh_degree + 1) * (cam->sh_degree + 1))
+      return fail(GCR_ERR_INVALID_ARGUMENT, "sh has fewer coefficients than sh_degree needs");
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gcr_abi_version(void) { return GCR_ABI_VERSION; }
+const char* gcr_last_error(void) { return g_err.c_str(); }
+
+size_t gcr_geometry_bytes(int32_t P) {
+  gcr_layout L;
+  compute_layout(P, 16, 16, 0, &L);
+  return L.geom_total;
+}
+size_t gcr_image_bytes(int32_t W, int32_t H) {
+  gcr_layout L;
+  compute_layout(0, W, H, 0, &L);
+  return L.img_total;
+}
+size_t gcr_binning_bytes(int64_t R, int32_t W, int32_t H) {
+  gcr_layout L;
+  compute_layout(0, W, H, R, &L);
+  return L.bin_total;
+}
+int gcr_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* out) {
+  if (!out) return fail(GCR_ERR_INVALID_ARGUMENT, "null layout");
+  compute_layout(P, W, H, R, out);
+  return 0;
+}
+
+int gcr_set_option(const char* name, int value) {
+  if (!name) return -1;
+  if (!strcmp(name, "fast_exp")) return g_fast_exp.exchange(value);
+  if (!strcmp(name, "timing")) return g_timing.exchange(value);
+  return -1;
+}
+
+int gcr_get_stage_ms(float* ms_out, int capacity) {
+  int n = capacity < (int)ST_COUNT ? capacity : (int)ST_COUNT;
+  for (int i = 0; i < n; i++) ms_out[i] = g_stage_ms[i];
+  return n;
+}
+
+int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* geom,
+                           size_t geom_bytes, int32_t* radii, int64_t* num_rendered_host,
+                           void* hip_stream) {
+  if (int rc = check_inputs(cam, g)) return rc;
+  if (!num_rendered_host) return fail(GCR_ERR_INVALID_ARGUMENT, "num_rendered_host is null");
+  *num_rendered_host = 0;
+  if (g->P == 0) return 0;  // dgr/rasterize_points.cu:71
+  if (!geom || !radii) return fail(GCR_ERR_INVALID_ARGUMENT, "geom/radii must be non-null");
+  gcr_layout L;
+  compute_layout(g->P, cam->img_w, cam->img_h, 0, &L);
+  if (geom_bytes < L.geom_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "geometry buffer too small");
+  hipStream_t s = (hipStream_t)hip_stream;
+  char* gb = (char*)geom;
+
+  GcrPreprocessArgs a;
+  a.P = g->P; a.D = cam->sh_degree; a.M = g->M; a.W = cam->img_w; a.H = cam->img_h;
+  a.gx = (cam->img_w + GCR_BLOCK_X - 1) / GCR_BLOCK_X;
+  a.gy = (cam->img_h + GCR_BLOCK_Y - 1) / GCR_BLOCK_Y;
+  a.tanfovx = cam->tanfovx; a.tanfovy = cam->tanfovy;
+  a.focal_y = cam->img_h / (2.0f * cam->tanfovy);  // cr/rasterizer_impl.cu:189-190
+  a.focal_x = cam->img_w / (2.0f * cam->tanfovx);
+  a.scale_modifier = cam->scale_modifier;
+  a.means3D = g->means3D; a.scales = g->scales; a.rotations = g->rotations;
+  a.opacities = g->opacities; a.shs = g->shs; a.cov3D_precomp = g->cov3D_precomp;
+  a.colors_precomp = g->colors_precomp;
+  a.view = cam->view_matrix; a.proj = cam->proj_matrix; a.campos = cam->campos;
+  a.radii = radii;
+  a.rec = (float4*)(gb + L.geom_rec);
+  a.cov3D = (float*)(gb + L.geom_cov3D);
+  a.clamped = (uint8_t*)(gb + L.geom_clamped);
+  a.tiles_touched = (uint32_t*)(gb + L.geom_tiles_touched);
+  a.block_sums = (uint32_t*)(gb + L.geom_block_sums);
+  unsigned long long* total = (unsigned long long*)(gb + L.geom_num_rendered);
+  {
+    StageTimer t(s, ST_PRE);
+    HIP_TRY(gcr_launch_preprocess(a, s), "preprocess");
+  }
+  if (int rc = debug_sync(cam, s, "preprocess")) return rc;
+  {
+    StageTimer t(s, ST_SCAN);
+    HIP_TRY(gcr_launch_scan_block_sums(a.block_sums, (g->P + 255) / 256, total, s), "scan");
+  }
+  unsigned long long r = 0;
+  HIP_TRY(hipMemcpyAsync(&r, total, sizeof(r), hipMemcpyDeviceToHost, s), "num_rendered copy");
+  HIP_TRY(hipStreamSynchronize(s), "num_rendered sync");  // cr/rasterizer_impl.cu:236-238
+  if (r > 0x7fffffffull)
+    return fail(GCR_ERR_OVERFLOW, "num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)");
+  *num_rendered_host = (int64_t)r;
+  return 0;
+}
+
+int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes,
+                       void* binning, size_t binning_bytes, void* img, size_t img_bytes, int64_t R,
+                       float* out_color, void* hip_stream) {
+  if (int rc = check_inputs(cam, g)) return rc;
+  if (g->P == 0) return 0;
+  if (!geom || !img || !out_color) return fail(GCR_ERR_INVALID_ARGUMENT, "geom/img/out_color must be non-null");
+  if (R < 0 || R > 0x7fffffffll) return fail(GCR_ERR_INVALID_ARGUMENT, "R out of range");
+  if (R > 0 && !binning) return fail(GCR_ERR_INVALID_ARGUMENT, "binning buffer is null");
+  gcr_layout L;
+  compute_layout(g->P, cam->img_w, cam->img_h, R, &L);
+  if (geom_bytes < L.geom_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "geometry buffer too small");
+  if (img_bytes < L.img_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "image buffer too small");
+  if (R > 0 && binning_bytes < L.bin_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "binning buffer too small");
+  hipStream_t s = (hipStream_t)hip_stream;
+  char *gb = (char*)geom, *bb = (char*)binning, *ib = (char*)img;
+  const int gx = (cam->img_w + GCR_BLOCK_X - 1) / GCR_BLOCK_X;
+  const int gy = (cam->img_h + GCR_BLOCK_Y - 1) / GCR_BLOCK_Y;
+  const int T = gx * gy;
+  const float4* rec = (const float4*)(gb + L.geom_rec);
+  uint64_t* k0 = (uint64_t*)(bb + L.bin_keys[0]);
+  uint64_t* k1 = (uint64_t*)(bb + L.bin_keys[1]);
+  uint32_t* v0 = (uint32_t*)(bb + L.bin_vals[0]);
+  uint32_t* v1 = (uint32_t*)(bb + L.bin_vals[1]);
+  uint32_t* ranges = (uint32_t*)(ib + L.img_ranges);
+  int sorted_half = (int)L.bin_sorted;
+  if (R > 0) {
+    {
+      StageTimer t(s, ST_EMIT);
+      HIP_TRY(gcr_launch_emit(g->P, (const uint32_t*)(gb + L.geom_tiles_touched),
+                              (const uint32_t*)(gb + L.geom_block_sums), rec, gx, k0, v0, s),
+              "emit");
+    }
+    if (int rc = debug_sync(cam, s, "emit")) return rc;
+    {
+      StageTimer t(s, ST_SORT);
+      const int end_bit = 32 + (int)gcr_higher_msb((uint32_t)T);  // cr/rasterizer_impl.cu:252
+      HIP_TRY(gcr_launch_sort(k0, v0, k1, v1, R, end_bit, (uint32_t*)(bb + L.bin_hist), &sorted_half, s),
+              "sort");
+    }
+    if (int rc = debug_sync(cam, s, "sort")) return rc;
+  }
+  {
+    StageTimer t(s, ST_RANGES);
+    HIP_TRY(gcr_launch_tile_ranges(sorted_half ? k1 : k0, R, ranges, T, s), "tile ranges");
+  }
+  if (int rc = debug_sync(cam, s, "tile ranges")) return rc;
+  GcrBlendArgs b;
+  memset(&b, 0, sizeof(b));
+  b.ranges = ranges;
+  b.list = sorted_half ? v1 : v0;
+  b.rec = rec;
+  b.W = cam->img_w; b.H = cam->img_h; b.gx = gx; b.gy = gy;
+  b.bg = cam->bg;
+  b.final_T = (float*)(ib + L.img_final_T);
+  b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
+  b.out_color = out_color;
+  {
+    StageTimer t(s, ST_BLEND_FWD);
+    HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, s), "blend forward");
+  }
+  return debug_sync(cam, s, "blend forward");
+}
+
+int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* radii, const void* geom,
+                 size_t geom_bytes, const void* binning, size_t binning_bytes, const void* img,
+                 size_t img_bytes, int64_t R, const float* dL_dpix, const gcr_grads* gr,
+                 void* hip_stream) {
+  // opacities are not an input of the backward (cr/rasterizer.h:39-48): read from geom state
+  if (int rc = check_inputs(cam, g, false)) return rc;
+  if (g->P == 0) return 0;
+  if (!gr || !dL_dpix || !radii || !geom || !img)
+    return fail(GCR_ERR_INVALID_ARGUMENT, "grads/dL_dpix/radii/geom/img must be non-null");
+  if (!gr->dL_dmeans2D || !gr->dL_dconic || !gr->dL_dopacity || !gr->dL_dcolors || !gr->dL_dmeans3D ||
+      !gr->dL_dcov3D || (g->shs && !gr->dL_dsh) || (g->scales && (!gr->dL_dscales || !gr->dL_drotations)))
+    return fail(GCR_ERR_INVALID_ARGUMENT, "a required gradient output is null");
+  if (R < 0 || R > 0x7fffffffll) return fail(GCR_ERR_INVALID_ARGUMENT, "R out of range");
+  gcr_layout L;
+  compute_layout(g->P, cam->img_w, cam->img_h, R, &L);
+  if (geom_bytes < L.geom_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "geometry buffer too small");
+  if (img_bytes < L.img_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "image buffer too small");
+  if (R > 0 && (!binning || binning_bytes < L.bin_total))
+    return fail(GCR_ERR_BUFFER_TOO_SMALL, "binning buffer too small");
+  hipStream_t s = (hipStream_t)hip_stream;
+  const char *gb = (const char*)geom, *bb = (const char*)binning, *ib = (const char*)img;
+  const int gx = (cam->img_w + GCR_BLOCK_X - 1) / GCR_BLOCK_X;
+  const int gy = (cam->img_h + GCR_BLOCK_Y - 1) / GCR_BLOCK_Y;
+
+  if (R > 0) {
+    GcrBlendArgs b;
+    memset(&b, 0, sizeof(b));
+    b.ranges = (const uint32_t*)(ib + L.img_ranges);
+    b.list = (const uint32_t*)(bb + L.bin_vals[L.bin_sorted]);
+    b.rec = (const float4*)(gb + L.geom_rec);
+    b.W = cam->img_w; b.H = cam->img_h; b.gx = gx; b.gy = gy;
+    b.bg = cam->bg;
+    b.final_T = (float*)(ib + L.img_final_T);
+    b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
+    b.dL_dpix = dL_dpix;
+    b.dL_dmean2D = gr->dL_dmeans2D; b.dL_dconic = gr->dL_dconic;
+    b.dL_dopacity = gr->dL_dopacity; b.dL_dcolor = gr->dL_dcolors;
+    StageTimer t(s, ST_BLEND_BWD);
+    HIP_TRY(gcr_launch_blend_bwd(b, g_fast_exp.load() != 0, s), "blend backward");
+  }
+  if (int rc = debug_sync(cam, s, "blend backward")) return rc;
+
+  GcrPreprocessBwdArgs a;
+  a.P = g->P; a.D = cam->sh_degree; a.M = g->M; a.W = cam->img_w; a.H = cam->img_h;
+  a.tanfovx = cam->tanfovx; a.tanfovy = cam->tanfovy;
+  a.focal_y = cam->img_h / (2.0f * cam->tanfovy);
+  a.focal_x = cam->img_w / (2.0f * cam->tanfovx);
+  a.scale_modifier = cam->scale_modifier;
+  a.means3D = g->means3D; a.scales = g->scales; a.rotations = g->rotations; a.shs = g->shs;
+  a.cov3D = g->cov3D_precomp ? g->cov3D_precomp : (const float*)(gb + L.geom_cov3D);  // cr/rasterizer_impl.cu:329-330
+  a.view = cam->view_matrix; a.proj = cam->proj_matrix; a.campos = cam->campos;
+  a.radii = radii;
+  a.clamped = (const uint8_t*)(gb + L.geom_clamped);
+  a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dconic = gr->dL_dconic; a.dL_dcolor = gr->dL_dcolors;
+  a.dL_dmean3D = gr->dL_dmeans3D; a.dL_dcov3D = gr->dL_dcov3D; a.dL_dsh = gr->dL_dsh;
+  a.dL_dscale = gr->dL_dscales; a.dL_drot = gr->dL_drotations;
+  {
+    StageTimer t(s, ST_PRE_BWD);
+    HIP_TRY(gcr_launch_preprocess_bwd(a, s), "preprocess backward");
+  }
+  return debug_sync(cam, s, "preprocess backward");
+}
+
+int gcr_mark_visible(int32_t P, const float* means3D, const float* view_matrix,
+                     const float* proj_matrix, uint8_t* present, void* hip_stream) {
+  (void)proj_matrix;  // the reference's in_frustum only uses it for the commented-out side test
+  if (P < 0) return fail(GCR_ERR_INVALID_ARGUMENT, "P must be >= 0");
+  if (P == 0) return 0;
+  if (!means3D || !view_matrix || !present) return fail(GCR_ERR_INVALID_ARGUMENT, "null pointer");
+  HIP_TRY(gcr_launch_mark_visible(P, means3D, view_matrix, present, (hipStream_t)hip_stream), "mark_visible");
+  return 0;
+}
+
+int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void* geometry_user,
+                              gcr_resize_fn binning_buffer, void* binning_user,
+                              gcr_resize_fn image_buffer, void* image_user, const gcr_camera* cam,
+                              const gcr_gaussians* g, float* out_color, int32_t* radii,
+                              void* hip_stream) {
+  if (int rc = check_inputs(cam, g)) return rc;
+  if (!geometry_buffer || !binning_buffer || !image_buffer)
+    return fail(GCR_ERR_INVALID_ARGUMENT, "resize callbacks must be non-null");
+  if (g->P == 0) return 0;
+  const size_t gbytes = gcr_geometry_bytes(g->P);
+  void* geom = geometry_buffer(geometry_user, gbytes);
+  if (!geom) return fail(GCR_ERR_ALLOC, "geometry resize callback returned null");
+  const size_t ibytes = gcr_image_bytes(cam->img_w, cam->img_h);
+  void* img = image_buffer(image_user, ibytes);
+  if (!img) return fail(GCR_ERR_ALLOC, "image resize callback returned null");
+  int64_t R = 0;
+  if (int rc = gcr_forward_preprocess(cam, g, geom, gbytes, radii, &R, hip_stream)) return rc;
+  const size_t bbytes = gcr_binning_bytes(R, cam->img_w, cam->img_h);
+  void* bin = binning_buffer(binning_user, bbytes);
+  if (!bin && R > 0) return fail(GCR_ERR_ALLOC, "binning resize callback returned null");
+  if (int rc = gcr_forward_render(cam, g, geom, gbytes, bin, bbytes, img, ibytes, R, out_color, hip_stream))
+    return rc;
+  return R;
+}
+
+}  // extern "C"

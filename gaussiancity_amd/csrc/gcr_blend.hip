@@ -1,0 +1,285 @@
+// gcr_blend.hip -- K6 forward alpha compositing and K7 reverse-walk gradient for gfx950.
+//
+// One 256-thread workgroup (4 x wave64) per 16x16 tile; wave w owns pixel rows 4w..4w+3.
+// A tile's depth-sorted list is consumed in chunks of 256 entries: the 256 threads gather
+// one 48-byte Gaussian record each (3 x dwordx4 from <= 2 cache lines) and stage it in LDS
+// as SoA quads, so the blend loop reads wave-uniform (broadcast) ds_read_b128/b64 and never
+// touches global memory.  Differences from cr/forward.cu:238-346 that do not change results:
+//   * colour is staged in LDS too (the reference gathers it per contributing pixel, :328);
+//   * a per-Gaussian conservative bound pmin = -ln(255*opacity) - 1e-3 is staged; pixels with
+//     power < pmin are skipped before exp() -- exactly the pixels whose alpha < 1/255 test
+//     (:318) would skip them anyway (alpha = o*exp(power) < 1/255 with margin);
+//   * `contributor` is derived from the (wave-uniform) loop index instead of a per-lane counter;
+//   * the wave stops reading LDS as soon as its own 64 pixels are done (wave-level early
+//     out, on top of the block-level vote of :284-286).
+// Arithmetic: gcr-fp32-v1 (gcr_device.h) -> out_color / final_T / n_contrib are bit-identical
+// to the oracle.
+#include "gcr_device.h"
+#include "gcr_internal.h"
+
+namespace {
+
+constexpr int CHUNK = 256;
+
+// pmin such that power < pmin  =>  opacity*exp(power) < 1/255 with a 1e-3 safety margin.
+GCR_DEV float gcr_alpha_skip_bound(float opacity) {
+  if (!(opacity > 0.0f)) return __builtin_inff();  // alpha <= 0 < 1/255: always skipped
+  return -__builtin_logf(255.0f * opacity) - 1.0e-3f;
+}
+
+template <bool FAST_EXP>
+GCR_DEV float blend_exp(float x) {
+  return FAST_EXP ? gcr_expf_fast(x) : gcr_expf(x);
+}
+
+// ------------------------------------------------------------------------------------- K6
+template <bool FAST_EXP>
+__global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
+  __shared__ float4 sA[CHUNK];  // x, y, conic.x, conic.y
+  __shared__ float4 sB[CHUNK];  // conic.z, opacity, r, g
+  __shared__ float2 sC[CHUNK];  // b, pmin
+
+  const int tile = blockIdx.x;
+  const int tx = tile % a.gx, ty = tile / a.gx;
+  const int tid = threadIdx.x;
+  const int pxi = tx * GCR_TILE_X + (tid & 15), pyi = ty * GCR_TILE_Y + (tid >> 4);
+  const bool inside = pxi < a.W && pyi < a.H;
+  const float pixx = (float)pxi, pixy = (float)pyi;
+  const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
+  const int total = (int)(r1 - r0);
+
+  bool done = !inside;
+  float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+  uint32_t last_contributor = 0;
+
+  for (int base = 0; base < total; base += CHUNK) {
+    // block-wide vote (cr/forward.cu:284-286); also fences the previous chunk's LDS reads
+    if (__syncthreads_count(done) == 256) break;
+    const int n = min(CHUNK, total - base);
+    if (tid < n) {
+      const uint32_t id = a.list[r0 + base + tid];
+      const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
+      const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+      sA[tid] = q0;
+      sB[tid] = q1;
+      sC[tid] = make_float2(q2.x, gcr_alpha_skip_bound(q1.y));
+    }
+    __syncthreads();
+    for (int j = 0; !done && j < n; j++) {
+      const float4 qa = sA[j];
+      const float2 qc = sC[j];
+      const float dx = qa.x - pixx, dy = qa.y - pixy;
+      const float4 qb = sB[j];
+      const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
+      if (power > 0.0f) continue;
+      if (power < qc.y) continue;  // certain alpha < 1/255
+      const float alpha = gcr_min(0.99f, qb.y * blend_exp<FAST_EXP>(power));
+      if (alpha < 1.0f / 255.0f) continue;
+      const float test_T = T * (1 - alpha);
+      if (test_T < 0.0001f) {
+        done = true;
+        continue;
+      }
+      C0 = __builtin_fmaf(qb.z * alpha, T, C0);
+      C1 = __builtin_fmaf(qb.w * alpha, T, C1);
+      C2 = __builtin_fmaf(qc.x * alpha, T, C2);
+      T = test_T;
+      last_contributor = (uint32_t)(base + j + 1);
+    }
+  }
+  if (inside) {
+    const size_t pix_id = (size_t)a.W * pyi + pxi;
+    const size_t plane = (size_t)a.H * a.W;
+    a.final_T[pix_id] = T;
+    a.n_contrib[pix_id] = last_contributor;
+    a.out_color[pix_id] = C0 + T * a.bg[0];
+    a.out_color[plane + pix_id] = C1 + T * a.bg[1];
+    a.out_color[2 * plane + pix_id] = C2 + T * a.bg[2];
+  }
+}
+
+// ------------------------------------------------------------------------------------- K7
+// cr/backward.cu:428-581.  Per pixel the reverse walk is the reference's; what changes is how
+// the nine per-(pixel,Gaussian) gradient terms reach memory.  The reference issues nine global
+// float atomics per pixel per Gaussian; here
+//   1. each wave sums its 64 lanes with a DPP butterfly (no LDS traffic),
+//   2. lane 63 adds the wave sum into a per-chunk LDS accumulator (ds_add_f32),
+//   3. after the chunk, thread t flushes entry t with nine global_atomic_add_f32
+// so global atomics drop from 9 per (pixel,Gaussian) to 9 per (tile,Gaussian).
+// Only entries [0, max n_contrib of the tile) are visited: later entries are skipped by every
+// pixel in the reference too (contributor >= last_contributor, :511-512).
+template <bool FAST_EXP>
+__global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
+  __shared__ float4 sA[CHUNK];
+  __shared__ float4 sB[CHUNK];
+  __shared__ float2 sC[CHUNK];
+  __shared__ uint32_t sId[CHUNK];
+  __shared__ float sAcc[9][CHUNK];
+  __shared__ uint32_t sMax[4];
+
+  const int tile = blockIdx.x;
+  const int tx = tile % a.gx, ty = tile / a.gx;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int pxi = tx * GCR_TILE_X + (tid & 15), pyi = ty * GCR_TILE_Y + (tid >> 4);
+  const bool inside = pxi < a.W && pyi < a.H;
+  const float pixx = (float)pxi, pixy = (float)pyi;
+  const uint32_t r0 = a.ranges[2 * tile];
+  const size_t pix_id = (size_t)a.W * pyi + pxi;
+  const size_t plane = (size_t)a.H * a.W;
+
+  const float T_final = inside ? a.final_T[pix_id] : 0.0f;
+  const uint32_t last_contributor = inside ? a.n_contrib[pix_id] : 0u;
+  float dLp0 = 0.0f, dLp1 = 0.0f, dLp2 = 0.0f;
+  if (inside) {
+    dLp0 = a.dL_dpix[pix_id];
+    dLp1 = a.dL_dpix[plane + pix_id];
+    dLp2 = a.dL_dpix[2 * plane + pix_id];
+  }
+  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  float bg_dot_dpixel = 0;
+  bg_dot_dpixel += bg0 * dLp0;
+  bg_dot_dpixel += bg1 * dLp1;
+  bg_dot_dpixel += bg2 * dLp2;
+  const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
+
+  // entries any pixel of this tile consumed
+  {
+    const uint32_t m = gcr_wave_max_u32(last_contributor);
+    if (lane == 0) sMax[w] = m;
+  }
+  __syncthreads();
+  const int total = (int)max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
+  if (total == 0) return;
+
+  float T = T_final;
+  float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;  // accum_rec
+  float last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;
+
+  for (int base = 0; base < total; base += CHUNK) {
+    const int n = min(CHUNK, total - base);
+    __syncthreads();  // previous chunk fully flushed before its LDS is reused
+    if (tid < n) {
+      // back to front: chunk slot `tid` holds list entry e = total-1-(base+tid)
+      const uint32_t id = a.list[r0 + (uint32_t)(total - 1 - (base + tid))];
+      const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
+      const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+      sA[tid] = q0;
+      sB[tid] = q1;
+      sC[tid] = make_float2(q2.x, gcr_alpha_skip_bound(q1.y));
+      sId[tid] = id;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) sAcc[k][tid] = 0.0f;
+    __syncthreads();
+
+    for (int j = 0; j < n; j++) {
+      const uint32_t entry = (uint32_t)(total - 1 - (base + j));  // == `contributor` upstream
+      bool act = entry < last_contributor;
+      const float4 qa = sA[j];
+      const float2 qc = sC[j];
+      const float4 qb = sB[j];
+      const float dx = qa.x - pixx, dy = qa.y - pixy;
+      const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
+      act = act && !(power > 0.0f) && !(power < qc.y);
+      if (__ballot(act) == 0ull) continue;  // whole wave skips this Gaussian
+      float v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0;
+      if (act) {
+        const float G = blend_exp<FAST_EXP>(power);
+        const float alpha = gcr_min(0.99f, qb.y * G);
+        if (!(alpha < 1.0f / 255.0f)) {
+          T = T / (1.f - alpha);
+          const float dchannel_dcolor = alpha * T;
+          float dL_dalpha = 0.0f;
+          // channel 0
+          acc0 = __builtin_fmaf(last_alpha, lc0, (1.f - last_alpha) * acc0);
+          lc0 = qb.z;
+          dL_dalpha = __builtin_fmaf(qb.z - acc0, dLp0, dL_dalpha);
+          v0 = dchannel_dcolor * dLp0;
+          // channel 1
+          acc1 = __builtin_fmaf(last_alpha, lc1, (1.f - last_alpha) * acc1);
+          lc1 = qb.w;
+          dL_dalpha = __builtin_fmaf(qb.w - acc1, dLp1, dL_dalpha);
+          v1 = dchannel_dcolor * dLp1;
+          // channel 2
+          acc2 = __builtin_fmaf(last_alpha, lc2, (1.f - last_alpha) * acc2);
+          lc2 = qc.x;
+          dL_dalpha = __builtin_fmaf(qc.x - acc2, dLp2, dL_dalpha);
+          v2 = dchannel_dcolor * dLp2;
+
+          dL_dalpha *= T;
+          last_alpha = alpha;
+          dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+
+          const float dL_dG = qb.y * dL_dalpha;
+          const float gdx = G * dx, gdy = G * dy;
+          const float dG_ddelx = -gdx * qa.z - gdy * qa.w;
+          const float dG_ddely = -gdy * qb.x - gdx * qa.w;
+          v3 = dL_dG * dG_ddelx * ddelx_dx;
+          v4 = dL_dG * dG_ddely * ddely_dy;
+          v5 = -0.5f * gdx * dx * dL_dG;
+          v6 = -0.5f * gdx * dy * dL_dG;
+          v7 = -0.5f * gdy * dy * dL_dG;
+          v8 = G * dL_dalpha;
+        }
+      }
+      v0 = gcr_wave_sum_to_lane63(v0);
+      v1 = gcr_wave_sum_to_lane63(v1);
+      v2 = gcr_wave_sum_to_lane63(v2);
+      v3 = gcr_wave_sum_to_lane63(v3);
+      v4 = gcr_wave_sum_to_lane63(v4);
+      v5 = gcr_wave_sum_to_lane63(v5);
+      v6 = gcr_wave_sum_to_lane63(v6);
+      v7 = gcr_wave_sum_to_lane63(v7);
+      v8 = gcr_wave_sum_to_lane63(v8);
+      if (lane == 63) {
+        atomicAdd(&sAcc[0][j], v0);
+        atomicAdd(&sAcc[1][j], v1);
+        atomicAdd(&sAcc[2][j], v2);
+        atomicAdd(&sAcc[3][j], v3);
+        atomicAdd(&sAcc[4][j], v4);
+        atomicAdd(&sAcc[5][j], v5);
+        atomicAdd(&sAcc[6][j], v6);
+        atomicAdd(&sAcc[7][j], v7);
+        atomicAdd(&sAcc[8][j], v8);
+      }
+    }
+    __syncthreads();
+    if (tid < n) {
+      const uint32_t id = sId[tid];
+      float g[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) g[k] = sAcc[k][tid];
+      if (g[0] != 0.0f) atomicAdd(&a.dL_dcolor[3 * (size_t)id + 0], g[0]);
+      if (g[1] != 0.0f) atomicAdd(&a.dL_dcolor[3 * (size_t)id + 1], g[1]);
+      if (g[2] != 0.0f) atomicAdd(&a.dL_dcolor[3 * (size_t)id + 2], g[2]);
+      if (g[3] != 0.0f) atomicAdd(&a.dL_dmean2D[3 * (size_t)id + 0], g[3]);
+      if (g[4] != 0.0f) atomicAdd(&a.dL_dmean2D[3 * (size_t)id + 1], g[4]);
+      if (g[5] != 0.0f) atomicAdd(&a.dL_dconic[4 * (size_t)id + 0], g[5]);
+      if (g[6] != 0.0f) atomicAdd(&a.dL_dconic[4 * (size_t)id + 1], g[6]);
+      if (g[7] != 0.0f) atomicAdd(&a.dL_dconic[4 * (size_t)id + 3], g[7]);
+      if (g[8] != 0.0f) atomicAdd(&a.dL_dopacity[id], g[8]);
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool fast_exp, hipStream_t s) {
+  const int T = a.gx * a.gy;
+  if (T <= 0) return hipSuccess;
+  if (fast_exp)
+    k_blend_fwd<true><<<T, 256, 0, s>>>(a);
+  else
+    k_blend_fwd<false><<<T, 256, 0, s>>>(a);
+  return hipGetLastError();
+}
+
+hipError_t gcr_launch_blend_bwd(const GcrBlendArgs& a, bool fast_exp, hipStream_t s) {
+  const int T = a.gx * a.gy;
+  if (T <= 0) return hipSuccess;
+  if (fast_exp)
+    k_blend_bwd<true><<<T, 256, 0, s>>>(a);
+  else
+    k_blend_bwd<false><<<T, 256, 0, s>>>(a);
+  return hipGetLastError();
+}

@@ -1,0 +1,85 @@
+// gcr_internal.h -- host-side declarations shared by the translation units of libgcr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gcr.h"
+
+// One Gaussian's projected state, written by K1 and gathered by K3/K6/K7.  48 bytes, three
+// 16-byte quads so a staging thread issues three dwordx4 loads from (at most) two cache lines.
+//   q0 = (x, y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)
+//   q2 = (b, depth, rect_x, rect_y) with rect_* = min | max << 16 (tile units, as uint bits)
+#define GCR_REC_QUADS 3
+
+struct GcrPreprocessArgs {
+  int P, D, M, W, H, gx, gy;
+  float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+  const float *means3D, *scales, *rotations, *opacities, *shs, *cov3D_precomp, *colors_precomp;
+  const float *view, *proj, *campos;
+  int32_t* radii;
+  float4* rec;
+  float* cov3D;
+  uint8_t* clamped;
+  uint32_t* tiles_touched;
+  uint32_t* block_sums;
+};
+
+struct GcrPreprocessBwdArgs {
+  int P, D, M, W, H;
+  float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+  const float *means3D, *scales, *rotations, *shs, *cov3D;  // cov3D: precomp or geometry state
+  const float *view, *proj, *campos;
+  const int32_t* radii;
+  const uint8_t* clamped;
+  const float *dL_dmean2D, *dL_dconic, *dL_dcolor;
+  float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+};
+
+struct GcrBlendArgs {
+  const uint32_t* ranges;  // [T][2]
+  const uint32_t* list;    // sorted instance -> Gaussian
+  const float4* rec;
+  int W, H, gx, gy;
+  const float* bg;
+  float* final_T;
+  uint32_t* n_contrib;
+  float* out_color;         // fwd
+  const float* dL_dpix;     // bwd
+  float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor;  // bwd
+};
+
+// launchers (each enqueues on `s`, returns hipGetLastError())
+hipError_t gcr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present,
+                                   hipStream_t s);
+hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, hipStream_t s);
+hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long long* total,
+                                      hipStream_t s);
+hipError_t gcr_launch_emit(int P, const uint32_t* tiles_touched, const uint32_t* block_offsets,
+                           const float4* rec, int gx, uint64_t* keys, uint32_t* vals,
+                           hipStream_t s);
+// Stable LSD radix sort of R (u64 key, u32 value) pairs on bits [0, end_bit).  Ping-pongs
+// between (k0,v0) and (k1,v1); returns in *sorted_half which half holds the result.
+size_t gcr_sort_hist_bytes(int64_t R, int end_bit);
+hipError_t gcr_launch_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, int64_t R,
+                           int end_bit, uint32_t* hist, int* sorted_half, hipStream_t s);
+int gcr_sort_passes(int end_bit);
+hipError_t gcr_launch_tile_ranges(const uint64_t* keys, int64_t R, uint32_t* ranges, int T,
+                                  hipStream_t s);
+hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool fast_exp, hipStream_t s);
+hipError_t gcr_launch_blend_bwd(const GcrBlendArgs& a, bool fast_exp, hipStream_t s);
+hipError_t gcr_launch_preprocess_bwd(const GcrPreprocessBwdArgs& a, hipStream_t s);
+
+// cr/rasterizer_impl.cu:35-48
+static inline uint32_t gcr_higher_msb(uint32_t n) {
+  uint32_t msb = sizeof(n) * 4;
+  uint32_t step = msb;
+  while (step > 1) {
+    step /= 2;
+    if (n >> msb)
+      msb += step;
+    else
+      msb -= step;
+  }
+  if (n >> msb) msb++;
+  return msb;
+}

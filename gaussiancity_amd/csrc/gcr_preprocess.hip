@@ -1,0 +1,520 @@
+// gcr_preprocess.hip -- per-Gaussian streaming kernels for gfx950 (HBM-bound):
+//   K0 mark_visible, K1 forward preprocess (+ per-block tile counts), K2 scan of block
+//   counts, K8 fused backward preprocess (reference K8a computeCov2DCUDA + K8b preprocessCUDA).
+// One thread per Gaussian, 256-thread blocks (4 wave64).  Camera matrices are wave-uniform
+// and are fetched through the scalar cache (s_load), per-Gaussian attributes through
+// per-lane vector loads.  Arithmetic follows gcr-fp32-v1 (gcr_device.h) in the operation
+// order of cr/forward.cu / cr/backward.cu so that results are bit-identical to the oracle.
+#include "gcr_device.h"
+#include "gcr_internal.h"
+
+namespace {
+
+// cr/auxiliary.h:22-30
+__device__ const float SH_C0 = 0.28209479177387814f;
+__device__ const float SH_C1 = 0.4886025119029199f;
+__device__ const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                   -1.0925484305920792f, 0.5462742152960396f};
+__device__ const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                   0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                   -0.5900435899266435f};
+
+struct V3 {
+  float x, y, z;
+};
+
+// cr/auxiliary.h:48-56
+GCR_DEV V3 transform_point_4x3(const V3 p, const float* __restrict__ m) {
+  V3 o;
+  o.x = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
+  o.y = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
+  o.z = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14];
+  return o;
+}
+
+// Non-zero part of T = W*J (glm T[c][r], c in {0,1}) plus the clamped camera-space mean;
+// shared by the forward (cr/forward.cu:69-105) and backward (cr/backward.cu:160-187) paths.
+struct Cov2DCtx {
+  V3 t;
+  float txtz, tytz, limx, limy;
+  float T[2][3];
+};
+
+GCR_DEV void cov2d_setup(const V3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
+                         const float* __restrict__ vm, Cov2DCtx& c) {
+  c.t = transform_point_4x3(mean, vm);
+  c.limx = 1.3f * tan_fovx;
+  c.limy = 1.3f * tan_fovy;
+  c.txtz = c.t.x / c.t.z;
+  c.tytz = c.t.y / c.t.z;
+  c.t.x = gcr_min(c.limx, gcr_max(-c.limx, c.txtz)) * c.t.z;
+  c.t.y = gcr_min(c.limy, gcr_max(-c.limy, c.tytz)) * c.t.z;
+  const float tz = c.t.z;
+  const float J00 = fx / tz, J02 = -(fx * c.t.x) / (tz * tz);
+  const float J11 = fy / tz, J12 = -(fy * c.t.y) / (tz * tz);
+  c.T[0][0] = vm[0] * J00 + vm[2] * J02;
+  c.T[0][1] = vm[4] * J00 + vm[6] * J02;
+  c.T[0][2] = vm[8] * J00 + vm[10] * J02;
+  c.T[1][0] = vm[1] * J11 + vm[2] * J12;
+  c.T[1][1] = vm[5] * J11 + vm[6] * J12;
+  c.T[1][2] = vm[9] * J11 + vm[10] * J12;
+}
+
+// cov = transpose(T) * transpose(Vrk) * T ; returns (cov[0][0]+0.3, cov[0][1], cov[1][1]+0.3)
+GCR_DEV void cov2d_eval(const Cov2DCtx& c, const float (&cv)[6], float (&out)[3]) {
+  const float V[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
+  float A[3][2];
+#pragma unroll
+  for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+      A[cc][r] = c.T[r][0] * V[0][cc] + c.T[r][1] * V[1][cc] + c.T[r][2] * V[2][cc];
+  const float c00 = A[0][0] * c.T[0][0] + A[1][0] * c.T[0][1] + A[2][0] * c.T[0][2];
+  const float c01 = A[0][1] * c.T[0][0] + A[1][1] * c.T[0][1] + A[2][1] * c.T[0][2];
+  const float c11 = A[0][1] * c.T[1][0] + A[1][1] * c.T[1][1] + A[2][1] * c.T[1][2];
+  out[0] = c00 + 0.3f;
+  out[1] = c01;
+  out[2] = c11 + 0.3f;
+}
+
+// cr/forward.cu:110-144 (quaternion (r,x,y,z) deliberately not normalised)
+GCR_DEV void compute_cov3d(const V3 scale, float mod, const float4 rot, float (&cov3D)[6]) {
+  const float s[3] = {mod * scale.x, mod * scale.y, mod * scale.z};
+  const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
+  const float R[3][3] = {
+      {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+      {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+      {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+  float M[3][3];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) M[c][k] = s[k] * R[c][k];
+#define GCR_SIG(c, r) (M[r][0] * M[c][0] + M[r][1] * M[c][1] + M[r][2] * M[c][2])
+  cov3D[0] = GCR_SIG(0, 0);
+  cov3D[1] = GCR_SIG(0, 1);
+  cov3D[2] = GCR_SIG(0, 2);
+  cov3D[3] = GCR_SIG(1, 1);
+  cov3D[4] = GCR_SIG(1, 2);
+  cov3D[5] = GCR_SIG(2, 2);
+#undef GCR_SIG
+}
+
+// ------------------------------------------------------------------------------------- K0
+// cr/rasterizer_impl.cu:52-62 with in_frustum of cr/auxiliary.h:135-156 (near plane only).
+__global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
+                                                      const float* __restrict__ view,
+                                                      uint8_t* __restrict__ present) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  const V3 p = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+  const V3 pv = transform_point_4x3(p, view);
+  present[idx] = !(pv.z <= 0.2f);
+}
+
+// ------------------------------------------------------------------------------------- K1
+// cr/forward.cu:147-233.  Additionally reduces tiles_touched over the block so that K2 scans
+// P/256 block sums instead of P values, and packs the blend-time attributes of a Gaussian
+// into one 48-byte record (see gcr_internal.h).
+__global__ __launch_bounds__(256) void k_preprocess(const GcrPreprocessArgs a) {
+  __shared__ uint32_t wave_sums[4];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  uint32_t tiles = 0;
+
+  if (idx < a.P) {
+    int my_radius_i = 0;
+    const float* __restrict__ vm = a.view;
+    const float* __restrict__ pm = a.proj;
+    const V3 p_orig = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+    const V3 p_view = transform_point_4x3(p_orig, vm);
+    if (!(p_view.z <= 0.2f)) {  // in_frustum
+      const float hx = pm[0] * p_orig.x + pm[4] * p_orig.y + pm[8] * p_orig.z + pm[12];
+      const float hy = pm[1] * p_orig.x + pm[5] * p_orig.y + pm[9] * p_orig.z + pm[13];
+      const float hw = pm[3] * p_orig.x + pm[7] * p_orig.y + pm[11] * p_orig.z + pm[15];
+      const float p_w = 1.0f / (hw + 0.0000001f);
+      const float projx = hx * p_w, projy = hy * p_w;
+
+      float cov3D[6];
+      if (a.cov3D_precomp != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+      } else {
+        const V3 sc = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+        const float4 rot = reinterpret_cast<const float4*>(a.rotations)[idx];
+        compute_cov3d(sc, a.scale_modifier, rot, cov3D);
+      }
+      Cov2DCtx cc;
+      float cov[3];
+      cov2d_setup(p_orig, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy, vm, cc);
+      cov2d_eval(cc, cov3D, cov);
+
+      const float det = (cov[0] * cov[2] - cov[1] * cov[1]);
+      if (det != 0.0f) {
+        const float det_inv = 1.f / det;
+        const float conx = cov[2] * det_inv, cony = -cov[1] * det_inv, conz = cov[0] * det_inv;
+        const float mid = 0.5f * (cov[0] + cov[2]);
+        const float lambda1 = mid + __builtin_sqrtf(gcr_max(0.1f, mid * mid - det));
+        const float lambda2 = mid - __builtin_sqrtf(gcr_max(0.1f, mid * mid - det));
+        const float my_radius =
+            __builtin_ceilf(3.f * __builtin_sqrtf(gcr_max(lambda1, lambda2)));
+        const float px = gcr_ndc2pix(projx, a.W), py = gcr_ndc2pix(projy, a.H);
+        // getRect, cr/auxiliary.h:36-46
+        const int ri = gcr_f2i_sat(my_radius);
+        const float rf = (float)ri;
+        const int minx = min(a.gx, max(0, gcr_f2i_sat((px - rf) / 16.0f)));
+        const int miny = min(a.gy, max(0, gcr_f2i_sat((py - rf) / 16.0f)));
+        const int maxx = min(a.gx, max(0, gcr_f2i_sat((px + rf + 16.0f - 1.0f) / 16.0f)));
+        const int maxy = min(a.gy, max(0, gcr_f2i_sat((py + rf + 16.0f - 1.0f) / 16.0f)));
+        const uint32_t area = (uint32_t)(maxx - minx) * (uint32_t)(maxy - miny);
+        if (area != 0) {
+          float cr, cg, cb;
+          if (a.colors_precomp == nullptr) {
+            // computeColorFromSH, cr/forward.cu:20-66
+            const float* __restrict__ cp = a.campos;
+            float dx = p_orig.x - cp[0], dy = p_orig.y - cp[1], dz = p_orig.z - cp[2];
+            const float len = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+            const float x = dx / len, y = dy / len, z = dz / len;
+            const float* __restrict__ sh = a.shs + (size_t)idx * a.M * 3;
+            float res[3];
+            const int deg = a.D;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+#define GCR_S(i) sh[3 * (i) + ch]
+              float result = SH_C0 * GCR_S(0);
+              if (deg > 0) {
+                result = result - SH_C1 * y * GCR_S(1) + SH_C1 * z * GCR_S(2) - SH_C1 * x * GCR_S(3);
+                if (deg > 1) {
+                  const float xx = x * x, yy = y * y, zz = z * z;
+                  const float xy = x * y, yz = y * z, xz = x * z;
+                  result = result + SH_C2[0] * xy * GCR_S(4) + SH_C2[1] * yz * GCR_S(5) +
+                           SH_C2[2] * (2.0f * zz - xx - yy) * GCR_S(6) + SH_C2[3] * xz * GCR_S(7) +
+                           SH_C2[4] * (xx - yy) * GCR_S(8);
+                  if (deg > 2) {
+                    result = result + SH_C3[0] * y * (3.0f * xx - yy) * GCR_S(9) +
+                             SH_C3[1] * xy * z * GCR_S(10) +
+                             SH_C3[2] * y * (4.0f * zz - xx - yy) * GCR_S(11) +
+                             SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * GCR_S(12) +
+                             SH_C3[4] * x * (4.0f * zz - xx - yy) * GCR_S(13) +
+                             SH_C3[5] * z * (xx - yy) * GCR_S(14) +
+                             SH_C3[6] * x * (xx - 3.0f * yy) * GCR_S(15);
+                  }
+                }
+              }
+#undef GCR_S
+              res[ch] = result + 0.5f;
+            }
+            const uint8_t cl = (uint8_t)((res[0] < 0 ? 1 : 0) | (res[1] < 0 ? 2 : 0) | (res[2] < 0 ? 4 : 0));
+            a.clamped[idx] = cl;
+            cr = gcr_max(res[0], 0.0f);
+            cg = gcr_max(res[1], 0.0f);
+            cb = gcr_max(res[2], 0.0f);
+          } else {
+            cr = a.colors_precomp[3 * idx];
+            cg = a.colors_precomp[3 * idx + 1];
+            cb = a.colors_precomp[3 * idx + 2];
+          }
+          if (a.cov3D_precomp == nullptr) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov3D[i];
+          }
+          float4* __restrict__ rec = a.rec + (size_t)idx * GCR_REC_QUADS;
+          rec[0] = make_float4(px, py, conx, cony);
+          rec[1] = make_float4(conz, a.opacities[idx], cr, cg);
+          rec[2] = make_float4(cb, p_view.z, __uint_as_float((uint32_t)minx | ((uint32_t)maxx << 16)),
+                               __uint_as_float((uint32_t)miny | ((uint32_t)maxy << 16)));
+          my_radius_i = ri;
+          tiles = area;
+        }
+      }
+    }
+    a.radii[idx] = my_radius_i;
+    a.tiles_touched[idx] = tiles;
+  }
+  // block sum of tiles touched -> block_sums[blockIdx.x]
+  const uint32_t ws = gcr_wave_sum_u32(tiles);
+  if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) a.block_sums[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+}
+
+// ------------------------------------------------------------------------------------- K2
+// Exclusive scan (in place) of the n per-block tile counts; *total = num_rendered
+// (cr/rasterizer_impl.cu:228-238 scans all P counts; the per-Gaussian offsets are rebuilt
+// inside K3 from a block-local scan).  Single 1024-thread block: n = P/256 is small.
+__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, int n,
+                                                          unsigned long long* __restrict__ total) {
+  __shared__ unsigned long long part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int beg = min(n, tid * per), end = min(n, beg + per);
+  unsigned long long s = 0;
+  for (int i = beg; i < end; i++) s += sums[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    unsigned long long t = (tid >= o) ? part[tid - o] : 0ull;
+    __syncthreads();
+    part[tid] += t;
+    __syncthreads();
+  }
+  unsigned long long run = part[tid] - s;
+  for (int i = beg; i < end; i++) {
+    const uint32_t t = sums[i];
+    sums[i] = (uint32_t)run;
+    run += t;
+  }
+  if (tid == 1023) *total = part[1023];
+}
+
+// ------------------------------------------------------------------------------------- K8
+// Fused cr/backward.cu:143-293 (computeCov2DCUDA, "K8a") and :378-425 (preprocessCUDA, "K8b").
+// K8a assigns dL_dmean3D, K8b adds the projection and SH terms -- done here in registers in
+// the same order: cov2D part, + projection part, + SH part.
+__global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.P || !(a.radii[idx] > 0)) return;
+  const float* __restrict__ vm = a.view;
+  const float* __restrict__ proj = a.proj;
+  const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+  float cv[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) cv[i] = a.cov3D[6 * (size_t)idx + i];
+  const float dcx = a.dL_dconic[4 * idx], dcy = a.dL_dconic[4 * idx + 1], dcz = a.dL_dconic[4 * idx + 3];
+
+  // ---- K8a
+  Cov2DCtx c;
+  cov2d_setup(mean, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy, vm, c);
+  const float x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0.f : 1.f;
+  const float y_grad_mul = (c.tytz < -c.limy || c.tytz > c.limy) ? 0.f : 1.f;
+  float cov[3];
+  cov2d_eval(c, cv, cov);
+  const float ca = cov[0], cb = cov[1], cc = cov[2];
+  const float denom = ca * cc - cb * cb;
+  float dL_da = 0, dL_db = 0, dL_dc = 0;
+  const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+  float dcov[6];
+#define T(i, j) c.T[i][j]
+  if (denom2inv != 0) {
+    dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
+    dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
+    dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+    dcov[0] = (T(0, 0) * T(0, 0) * dL_da + T(0, 0) * T(1, 0) * dL_db + T(1, 0) * T(1, 0) * dL_dc);
+    dcov[3] = (T(0, 1) * T(0, 1) * dL_da + T(0, 1) * T(1, 1) * dL_db + T(1, 1) * T(1, 1) * dL_dc);
+    dcov[5] = (T(0, 2) * T(0, 2) * dL_da + T(0, 2) * T(1, 2) * dL_db + T(1, 2) * T(1, 2) * dL_dc);
+    dcov[1] = 2 * T(0, 0) * T(0, 1) * dL_da + (T(0, 0) * T(1, 1) + T(0, 1) * T(1, 0)) * dL_db +
+              2 * T(1, 0) * T(1, 1) * dL_dc;
+    dcov[2] = 2 * T(0, 0) * T(0, 2) * dL_da + (T(0, 0) * T(1, 2) + T(0, 2) * T(1, 0)) * dL_db +
+              2 * T(1, 0) * T(1, 2) * dL_dc;
+    dcov[4] = 2 * T(0, 2) * T(0, 1) * dL_da + (T(0, 1) * T(1, 2) + T(0, 2) * T(1, 1)) * dL_db +
+              2 * T(1, 1) * T(1, 2) * dL_dc;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; i++) dcov[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+
+  const float V[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
+#define ROWDOT(i, k) (T(i, 0) * V[k][0] + T(i, 1) * V[k][1] + T(i, 2) * V[k][2])
+  const float dL_dT00 = 2 * ROWDOT(0, 0) * dL_da + ROWDOT(1, 0) * dL_db;
+  const float dL_dT01 = 2 * ROWDOT(0, 1) * dL_da + ROWDOT(1, 1) * dL_db;
+  const float dL_dT02 = 2 * ROWDOT(0, 2) * dL_da + ROWDOT(1, 2) * dL_db;
+  const float dL_dT10 = 2 * ROWDOT(1, 0) * dL_dc + ROWDOT(0, 0) * dL_db;
+  const float dL_dT11 = 2 * ROWDOT(1, 1) * dL_dc + ROWDOT(0, 1) * dL_db;
+  const float dL_dT12 = 2 * ROWDOT(1, 2) * dL_dc + ROWDOT(0, 2) * dL_db;
+#undef ROWDOT
+#undef T
+  const float dL_dJ00 = vm[0] * dL_dT00 + vm[4] * dL_dT01 + vm[8] * dL_dT02;
+  const float dL_dJ02 = vm[2] * dL_dT00 + vm[6] * dL_dT01 + vm[10] * dL_dT02;
+  const float dL_dJ11 = vm[1] * dL_dT10 + vm[5] * dL_dT11 + vm[9] * dL_dT12;
+  const float dL_dJ12 = vm[2] * dL_dT10 + vm[6] * dL_dT11 + vm[10] * dL_dT12;
+  const float h_x = a.focal_x, h_y = a.focal_y;
+  const float tz = 1.f / c.t.z;
+  const float tz2 = tz * tz;
+  const float tz3 = tz2 * tz;
+  const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+  const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+  const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * c.t.x) * tz3 * dL_dJ02 +
+                       (2 * h_y * c.t.y) * tz3 * dL_dJ12;
+  float dmx = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
+  float dmy = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+  float dmz = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+
+  // ---- K8b: 2D mean -> 3D mean (cr/backward.cu:392-413)
+  {
+    const float mhw = proj[3] * mean.x + proj[7] * mean.y + proj[11] * mean.z + proj[15];
+    const float m_w = 1.0f / (mhw + 0.0000001f);
+    const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+    const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+    const float d2x = a.dL_dmean2D[3 * idx], d2y = a.dL_dmean2D[3 * idx + 1];
+    const float ax = (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
+    const float ay = (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
+    const float az = (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
+    dmx += ax;
+    dmy += ay;
+    dmz += az;
+  }
+
+  // ---- K8b: SH backward (cr/backward.cu:20-138)
+  if (a.shs != nullptr) {
+    const float* __restrict__ cp = a.campos;
+    const float ox = mean.x - cp[0], oy = mean.y - cp[1], oz = mean.z - cp[2];
+    const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
+    const float x = ox / len, y = oy / len, z = oz / len;
+    const float* __restrict__ sh = a.shs + (size_t)idx * a.M * 3;
+    float* __restrict__ dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+    const uint8_t cl = a.clamped[idx];
+    float dRGB[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) dRGB[ch] = a.dL_dcolor[3 * idx + ch] * (((cl >> ch) & 1) ? 0.f : 1.f);
+    float gdx[3] = {0, 0, 0}, gdy[3] = {0, 0, 0}, gdz[3] = {0, 0, 0};
+    const int deg = a.D;
+#define SHV(i) sh[3 * (i) + ch]
+#define DSH(i, w)                  \
+  _Pragma("unroll") for (int ch = 0; ch < 3; ch++) dsh[3 * (i) + ch] = (w) * dRGB[ch]
+    DSH(0, SH_C0);
+    if (deg > 0) {
+      const float d1 = -SH_C1 * y, d2 = SH_C1 * z, d3 = -SH_C1 * x;
+      DSH(1, d1);
+      DSH(2, d2);
+      DSH(3, d3);
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) {
+        gdx[ch] = -SH_C1 * SHV(3);
+        gdy[ch] = -SH_C1 * SHV(1);
+        gdz[ch] = SH_C1 * SHV(2);
+      }
+      if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float xy = x * y, yz = y * z, xz = x * z;
+        const float d4 = SH_C2[0] * xy, d5 = SH_C2[1] * yz, d6 = SH_C2[2] * (2.f * zz - xx - yy),
+                    d7 = SH_C2[3] * xz, d8 = SH_C2[4] * (xx - yy);
+        DSH(4, d4);
+        DSH(5, d5);
+        DSH(6, d6);
+        DSH(7, d7);
+        DSH(8, d8);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+          gdx[ch] += SH_C2[0] * y * SHV(4) + SH_C2[2] * 2.f * -x * SHV(6) + SH_C2[3] * z * SHV(7) +
+                     SH_C2[4] * 2.f * x * SHV(8);
+          gdy[ch] += SH_C2[0] * x * SHV(4) + SH_C2[1] * z * SHV(5) + SH_C2[2] * 2.f * -y * SHV(6) +
+                     SH_C2[4] * 2.f * -y * SHV(8);
+          gdz[ch] += SH_C2[1] * y * SHV(5) + SH_C2[2] * 2.f * 2.f * z * SHV(6) + SH_C2[3] * x * SHV(7);
+        }
+        if (deg > 2) {
+          const float d9 = SH_C3[0] * y * (3.f * xx - yy), d10 = SH_C3[1] * xy * z,
+                      d11 = SH_C3[2] * y * (4.f * zz - xx - yy),
+                      d12 = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy),
+                      d13 = SH_C3[4] * x * (4.f * zz - xx - yy), d14 = SH_C3[5] * z * (xx - yy),
+                      d15 = SH_C3[6] * x * (xx - 3.f * yy);
+          DSH(9, d9);
+          DSH(10, d10);
+          DSH(11, d11);
+          DSH(12, d12);
+          DSH(13, d13);
+          DSH(14, d14);
+          DSH(15, d15);
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) {
+            gdx[ch] += (SH_C3[0] * SHV(9) * 3.f * 2.f * xy + SH_C3[1] * SHV(10) * yz +
+                        SH_C3[2] * SHV(11) * -2.f * xy + SH_C3[3] * SHV(12) * -3.f * 2.f * xz +
+                        SH_C3[4] * SHV(13) * (-3.f * xx + 4.f * zz - yy) +
+                        SH_C3[5] * SHV(14) * 2.f * xz + SH_C3[6] * SHV(15) * 3.f * (xx - yy));
+            gdy[ch] += (SH_C3[0] * SHV(9) * 3.f * (xx - yy) + SH_C3[1] * SHV(10) * xz +
+                        SH_C3[2] * SHV(11) * (-3.f * yy + 4.f * zz - xx) +
+                        SH_C3[3] * SHV(12) * -3.f * 2.f * yz + SH_C3[4] * SHV(13) * -2.f * xy +
+                        SH_C3[5] * SHV(14) * -2.f * yz + SH_C3[6] * SHV(15) * -3.f * 2.f * xy);
+            gdz[ch] += (SH_C3[1] * SHV(10) * xy + SH_C3[2] * SHV(11) * 4.f * 2.f * yz +
+                        SH_C3[3] * SHV(12) * 3.f * (2.f * zz - xx - yy) +
+                        SH_C3[4] * SHV(13) * 4.f * 2.f * xz + SH_C3[5] * SHV(14) * (xx - yy));
+          }
+        }
+      }
+    }
+#undef SHV
+#undef DSH
+    const float ddx = gdx[0] * dRGB[0] + gdx[1] * dRGB[1] + gdx[2] * dRGB[2];
+    const float ddy = gdy[0] * dRGB[0] + gdy[1] * dRGB[1] + gdy[2] * dRGB[2];
+    const float ddz = gdz[0] * dRGB[0] + gdz[1] * dRGB[1] + gdz[2] * dRGB[2];
+    // dnormvdv(float3), cr/auxiliary.h:97-113
+    const float sum2 = ox * ox + oy * oy + oz * oz;
+    const float invsum32 = 1.0f / __builtin_sqrtf(sum2 * sum2 * sum2);
+    dmx += ((+sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+    dmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+    dmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+  }
+  a.dL_dmean3D[3 * idx] = dmx;
+  a.dL_dmean3D[3 * idx + 1] = dmy;
+  a.dL_dmean3D[3 * idx + 2] = dmz;
+
+  // ---- K8b: cov3D -> scale / rotation (cr/backward.cu:297-373)
+  if (a.scales != nullptr) {
+    const float4 rot = reinterpret_cast<const float4*>(a.rotations)[idx];
+    const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
+    const float Rm[3][3] = {
+        {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+        {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+        {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+    const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
+                        a.scale_modifier * a.scales[3 * idx + 2]};
+    float M2[3][3];
+#pragma unroll
+    for (int cidx = 0; cidx < 3; cidx++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) M2[cidx][k] = 2.0f * (s[k] * Rm[cidx][k]);
+    const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                            {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                            {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+    float Mt[3][3];  // dL_dMt[c][r] = dL_dM[r][c], dL_dM[c][r] = sum_k M2[k][r]*dS[c][k]
+#pragma unroll
+    for (int cidx = 0; cidx < 3; cidx++)
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++)
+        Mt[rr][cidx] = M2[0][rr] * dS[cidx][0] + M2[1][rr] * dS[cidx][1] + M2[2][rr] * dS[cidx][2];
+#pragma unroll
+    for (int cidx = 0; cidx < 3; cidx++)
+      a.dL_dscale[3 * idx + cidx] =
+          Rm[0][cidx] * Mt[cidx][0] + Rm[1][cidx] * Mt[cidx][1] + Rm[2][cidx] * Mt[cidx][2];
+#pragma unroll
+    for (int cidx = 0; cidx < 3; cidx++)
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++) Mt[cidx][rr] *= s[cidx];
+    float4 dq;
+    dq.x = 2 * z * (Mt[0][1] - Mt[1][0]) + 2 * y * (Mt[2][0] - Mt[0][2]) + 2 * x * (Mt[1][2] - Mt[2][1]);
+    dq.y = 2 * y * (Mt[1][0] + Mt[0][1]) + 2 * z * (Mt[2][0] + Mt[0][2]) + 2 * r * (Mt[1][2] - Mt[2][1]) -
+           4 * x * (Mt[2][2] + Mt[1][1]);
+    dq.z = 2 * x * (Mt[1][0] + Mt[0][1]) + 2 * r * (Mt[2][0] - Mt[0][2]) + 2 * z * (Mt[1][2] + Mt[2][1]) -
+           4 * y * (Mt[2][2] + Mt[0][0]);
+    dq.w = 2 * r * (Mt[0][1] - Mt[1][0]) + 2 * x * (Mt[2][0] + Mt[0][2]) + 2 * y * (Mt[1][2] + Mt[2][1]) -
+           4 * z * (Mt[1][1] + Mt[0][0]);
+    reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
+  }
+}
+
+}  // namespace
+
+hipError_t gcr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present,
+                                   hipStream_t s) {
+  if (P <= 0) return hipSuccess;
+  k_mark_visible<<<(P + 255) / 256, 256, 0, s>>>(P, means3D, view, present);
+  return hipGetLastError();
+}
+
+hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, hipStream_t s) {
+  if (a.P <= 0) return hipSuccess;
+  k_preprocess<<<(a.P + 255) / 256, 256, 0, s>>>(a);
+  return hipGetLastError();
+}
+
+hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long long* total,
+                                      hipStream_t s) {
+  k_scan_block_sums<<<1, 1024, 0, s>>>(block_sums, n, total);
+  return hipGetLastError();
+}
+
+hipError_t gcr_launch_preprocess_bwd(const GcrPreprocessBwdArgs& a, hipStream_t s) {
+  if (a.P <= 0) return hipSuccess;
+  k_preprocess_bwd<<<(a.P + 255) / 256, 256, 0, s>>>(a);
+  return hipGetLastError();
+}

@@ -1,0 +1,190 @@
+"""Native-module surface: the three functions of `diff_gaussian_rasterization_ext`.
+
+Mirrors the reference's pybind module (dgr/bindings.cpp:15-19) and its torch binding
+(dgr/rasterize_points.cu:37-173): same names, positional argument order, return tuples and
+tensor shapes -- but the work is done by libgcr_hip.so (hand-written gfx950 kernels) through
+the C ABI of include/gcr.h.  PyTorch only supplies device memory and the current HIP stream.
+
+Differences, all on the safe side:
+  * non-float32 / non-GPU inputs raise RuntimeError instead of being undefined behaviour;
+  * kernels run on torch's *current* stream, not the legacy default stream, so DDP's
+    side-stream bucket all-reduce orders correctly against them;
+  * scratch buffers live on means3D's device (the reference uses "current device").
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+NUM_CHANNELS = 3  # cr/config.h:15
+
+
+def _dev_f32(t, name, device):
+    """Return (tensor_or_None, data_ptr_or_None); numel()==0 is the reference's 'absent'."""
+    if t is None or t.numel() == 0:
+        return None, None
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
+    if t.device != device:
+        raise RuntimeError("%s must live on %s (got %s)" % (name, device, t.device))
+    t = t.contiguous()
+    return t, t.data_ptr()
+
+
+def _camera(device, bg, view, proj, campos, tan_fovx, tan_fovy, H, W, scale_modifier, degree,
+            prefiltered, debug):
+    keep = []
+    ptrs = []
+    for t, name, n in ((bg, "bg", 3), (view, "viewmatrix", 16), (proj, "projmatrix", 16),
+                       (campos, "campos", 3)):
+        tt, p = _dev_f32(t, name, device)
+        if tt is None or tt.numel() != n:
+            raise RuntimeError("%s must have %d elements" % (name, n))
+        keep.append(tt)
+        ptrs.append(p)
+    cam = N.Camera(int(H), int(W), float(tan_fovx), float(tan_fovy), float(scale_modifier),
+                   int(degree), int(bool(prefiltered)), int(bool(debug)), *ptrs)
+    return cam, keep
+
+
+def _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations, cov3D_precomp):
+    keep = []
+    ptr = {}
+    for t, name in ((means3D, "means3D"), (opacity, "opacity"), (sh, "sh"), (colors, "colors"),
+                    (scales, "scales"), (rotations, "rotations"),
+                    (cov3D_precomp, "cov3D_precomp")):
+        tt, p = _dev_f32(t, name, device)
+        keep.append(tt)
+        ptr[name] = p
+    M = 0
+    if sh is not None and sh.numel() != 0:  # dgr/rasterize_points.cu:72-75
+        if sh.dim() != 3 or sh.size(0) != P or sh.size(2) != 3:
+            raise RuntimeError("sh must have dimensions (num_points, M, 3)")
+        M = int(sh.size(1))
+    for t, name, last in ((opacity, "opacity", None), (colors, "colors", 3), (scales, "scales", 3),
+                          (rotations, "rotations", 4), (cov3D_precomp, "cov3D_precomp", 6)):
+        if t is not None and t.numel() != 0 and t.numel() != P * (last or 1):
+            raise RuntimeError("%s has %d elements, expected %d" % (name, t.numel(), P * (last or 1)))
+    g = N.Gaussians(int(P), M, ptr["means3D"], ptr["opacity"], ptr["sh"], ptr["colors"],
+                    ptr["scales"], ptr["rotations"], ptr["cov3D_precomp"])
+    return g, keep
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                        cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
+                        image_width, sh, degree, campos, prefiltered, debug):
+    """RasterizeGaussiansCUDA (dgr/rasterize_points.cu:37-93, dgr/rasterize_points.h:18-28).
+
+    Returns (num_rendered:int, out_color[3,H,W], radii[P] int32, geomBuffer, binningBuffer,
+    imgBuffer) -- the three buffers are opaque uint8 tensors to be handed back to
+    rasterize_gaussians_backward.
+    """
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor: this rasterizer has no CPU path")
+    L = N.lib()
+    device = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=device)
+    radii = torch.zeros((P,), dtype=torch.int32, device=device)
+    byte = dict(dtype=torch.uint8, device=device)
+    geom = torch.empty((0,), **byte)
+    binning = torch.empty((0,), **byte)
+    img = torch.empty((0,), **byte)
+    if P == 0:  # dgr/rasterize_points.cu:71
+        return 0, out_color, radii, geom, binning, img
+    with torch.cuda.device(device):
+        cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
+                              tan_fovy, H, W, scale_modifier, degree, prefiltered, debug)
+        g, keep_g = _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations,
+                               cov3D_precomp)
+        stream = _stream(device)
+        geom = torch.empty((L.gcr_geometry_bytes(P),), **byte)
+        img = torch.empty((L.gcr_image_bytes(W, H),), **byte)
+        R = C.c_int64(0)
+        N.check(L.gcr_forward_preprocess(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
+                                         radii.data_ptr(), C.byref(R), stream),
+                "gcr_forward_preprocess")
+        binning = torch.empty((L.gcr_binning_bytes(R.value, W, H),), **byte)
+        N.check(L.gcr_forward_render(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
+                                     binning.data_ptr(), binning.numel(), img.data_ptr(),
+                                     img.numel(), R.value, out_color.data_ptr(), stream),
+                "gcr_forward_render")
+        del keep_c, keep_g
+    return int(R.value), out_color, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations,
+                                 scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
+                                 tan_fovy, dL_dout_color, sh, degree, campos, geomBuffer, R,
+                                 binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA (dgr/rasterize_points.cu:97-155, .h:30-43).
+
+    Returns (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3],
+    dL_dcov3D[P,6], dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4]) in that order
+    (dgr/rasterize_points.cu:153-154).
+    """
+    L = N.lib()
+    device = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+    opts = dict(dtype=torch.float32, device=device)
+    dL_dmeans3D = torch.zeros((P, 3), **opts)
+    dL_dmeans2D = torch.zeros((P, 3), **opts)
+    dL_dcolors = torch.zeros((P, NUM_CHANNELS), **opts)
+    dL_dconic = torch.zeros((P, 2, 2), **opts)
+    dL_dopacity = torch.zeros((P, 1), **opts)
+    dL_dcov3D = torch.zeros((P, 6), **opts)
+    dL_dsh = torch.zeros((P, M, 3), **opts)
+    dL_dscales = torch.zeros((P, 3), **opts)
+    dL_drotations = torch.zeros((P, 4), **opts)
+    if P != 0:
+        with torch.cuda.device(device):
+            cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
+                                  tan_fovy, H, W, scale_modifier, degree, False, debug)
+            # opacity is not an input of the backward (it is read from the geometry state)
+            g, keep_g = _gaussians(device, P, means3D, None, sh, colors, scales, rotations,
+                                   cov3D_precomp)
+            dpix, dpix_ptr = _dev_f32(dL_dout_color, "dL_dout_color", device)
+            if radii.dtype != torch.int32:
+                raise RuntimeError("radii must be int32")
+            radii_c = radii.contiguous()
+            grads = N.Grads(dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
+                            dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+                            dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
+                            dL_drotations.data_ptr())
+            gb, bb, ib = geomBuffer.contiguous(), binningBuffer.contiguous(), imageBuffer.contiguous()
+            N.check(L.gcr_backward(C.byref(cam), C.byref(g), radii_c.data_ptr(), gb.data_ptr(),
+                                   gb.numel(), bb.data_ptr() if bb.numel() else None, bb.numel(),
+                                   ib.data_ptr(), ib.numel(), int(R), dpix_ptr, C.byref(grads),
+                                   _stream(device)),
+                    "gcr_backward")
+            del keep_c, keep_g, dpix
+    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
+            dL_drotations)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible (dgr/rasterize_points.cu:157-173): bool[P], True where view-space z > 0.2."""
+    L = N.lib()
+    device = means3D.device
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=device)
+    if P != 0:
+        if not means3D.is_cuda:
+            raise RuntimeError("means3D must be a GPU tensor: this rasterizer has no CPU path")
+        with torch.cuda.device(device):
+            m, mp = _dev_f32(means3D, "means3D", device)
+            v, vp = _dev_f32(viewmatrix, "viewmatrix", device)
+            p, pp = _dev_f32(projmatrix, "projmatrix", device)
+            N.check(L.gcr_mark_visible(P, mp, vp, pp, present.data_ptr(), _stream(device)),
+                    "gcr_mark_visible")
+            del m, v, p
+    return present

@@ -1,0 +1,246 @@
+"""Python API of the rasterizer -- import-compatible with GaussianCity's
+`extensions.diff_gaussian_rasterization` (reference dgr/__init__.py):
+
+    GaussianRasterizationSettings   dgr/__init__.py:203-215   (field names img_h/img_w/
+                                                               view_matrix/proj_matrix)
+    GaussianRasterizer              dgr/__init__.py:218-273
+    RasterizeGaussiansFunction      dgr/__init__.py:19-200
+    GaussianRasterizerWrapper       dgr/__init__.py:276-426
+
+so models/generator.py, core/train.py:144, core/test.py:55, scripts/inference.py:638 and
+utils/helpers.py:256 can call it unchanged.  The native side is gaussiancity_amd.ext
+(libgcr_hip.so, gfx950); this file is autograd glue and camera bookkeeping only.
+"""
+import math
+import typing
+
+import numpy as np
+import scipy.spatial.transform
+import torch
+
+from . import ext as _ext
+
+_EMPTY = None
+
+
+def _absent():
+    # The reference marks an absent optional input with an empty CPU tensor
+    # (dgr/__init__.py:250-259); numel()==0 is what the native side keys on.
+    return torch.Tensor([])
+
+
+class GaussianRasterizationSettings(typing.NamedTuple):
+    img_h: int
+    img_w: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    view_matrix: torch.Tensor
+    proj_matrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args):
+    """CPU deep copy of an argument tuple, taken before a debug-mode native call."""
+    return tuple(a.cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _call_native(fn, args, debug, dump_path, what):
+    """Debug mode keeps the reference's behaviour (dgr/__init__.py:65-83,155-175): snapshot
+    the inputs first, dump them if the native call raises, then re-raise."""
+    if not debug:
+        return fn(*args)
+    saved = _snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_path)
+        print("\nAn error occured in %s. Writing %s for debugging.\n" % (what, dump_path))
+        raise
+
+
+class RasterizeGaussiansFunction(torch.autograd.Function):
+    """autograd bridge; positional signature of dgr/__init__.py:29-41."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        # native argument order: dgr/rasterize_points.h:18-28
+        native_args = (
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
+            cov3Ds_precomp, rs.view_matrix, rs.proj_matrix, rs.tanfovx, rs.tanfovy, rs.img_h,
+            rs.img_w, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug,
+        )
+        num_rendered, color, radii, geom_buffer, binning_buffer, img_buffer = _call_native(
+            _ext.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii,
+                              sh, geom_buffer, binning_buffer, img_buffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buffer,
+         binning_buffer, img_buffer) = ctx.saved_tensors
+        # native argument order: dgr/rasterize_points.h:30-43
+        native_args = (
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier,
+            cov3Ds_precomp, rs.view_matrix, rs.proj_matrix, rs.tanfovx, rs.tanfovy,
+            grad_out_color, sh, rs.sh_degree, rs.campos, geom_buffer, ctx.num_rendered,
+            binning_buffer, img_buffer, rs.debug,
+        )
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
+         grad_sh, grad_scales, grad_rotations) = _call_native(
+            _ext.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump",
+            "backward")
+        # one gradient per forward() input, raster_settings last (dgr/__init__.py:188-198)
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities,
+                grad_scales, grad_rotations, grad_cov3Ds_precomp, None)
+
+
+class GaussianRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Frustum (near-plane) test; exported natively as mark_visible (dgr/bindings.cpp:18)."""
+        rs = self.raster_settings
+        with torch.no_grad():
+            return _ext.mark_visible(positions, rs.view_matrix, rs.proj_matrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        # exactly-one-of checks, bare Exception like dgr/__init__.py:236-248
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        has_any_sr = scales is not None or rotations is not None
+        has_both_sr = scales is not None and rotations is not None
+        if (not has_both_sr and cov3D_precomp is None) or (has_any_sr and cov3D_precomp is not None):
+            raise Exception(
+                "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        opt = [shs, colors_precomp, scales, rotations, cov3D_precomp]
+        shs, colors_precomp, scales, rotations, cov3D_precomp = [
+            _absent() if t is None else t for t in opt]
+        return RasterizeGaussiansFunction.apply(
+            means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+            self.raster_settings)
+
+
+class GaussianRasterizerWrapper(torch.nn.Module):
+    """GaussianCity's camera/point-tensor adapter (dgr/__init__.py:276-426).
+
+    K: 3x3 intrinsics, sensor_size: (W, H).  Points are [N,14] =
+    xyz(3) opacity(1) scale(3) rotation(4, r x y z) rgb(3).  Camera pose is a position
+    (tx,ty,tz) plus a quaternion (qx,qy,qz,qw) whose rotation columns are [Forward|Right|Up].
+    The projection has P[3,2] = -1 (clip w negative in front of the camera), which mirrors
+    the image in x and y; flip_lr=True (default) undoes the x mirror.
+    """
+
+    def __init__(self, K, sensor_size, flip_lr=True, flip_ud=False, z_near=0.01, z_far=50000.0,
+                 device=torch.device("cuda")):
+        super().__init__()
+        self.flip_lr = flip_lr
+        self.flip_ud = flip_ud
+        self.z_near = z_near
+        self.z_far = z_far
+        self.device = device
+        self.K = K
+        self.sensor_size = sensor_size
+        self.fov_x, self.fov_y = self._intrinsic_to_fov()
+        self.P = self._get_projection_matrix()
+
+    # ---- camera bookkeeping -----------------------------------------------------------
+    def _intrinsic_to_fov(self):
+        # dgr/__init__.py:326-331
+        w, h = self.sensor_size[0], self.sensor_size[1]
+        return (2 * np.arctan2(w, 2 * self.K[0, 0]), 2 * np.arctan2(h, 2 * self.K[1, 1]))
+
+    def _get_projection_matrix(self):
+        # dgr/__init__.py:333-347
+        w, h = self.sensor_size[0], self.sensor_size[1]
+        n, f = self.z_near, self.z_far
+        P = np.zeros((4, 4), dtype=np.float32)
+        P[0, 0] = 2.0 * self.K[0, 0] / w
+        P[1, 1] = 2.0 * self.K[1, 1] / h
+        P[0, 2] = (2.0 * self.K[0, 2] / w) - 1.0
+        P[1, 2] = (2.0 * self.K[1, 2] / h) - 1.0
+        P[2, 2] = -(f + n) / (f - n)
+        P[2, 3] = -2.0 * f * n / (f - n)
+        P[3, 2] = -1.0
+        return torch.from_numpy(P).to(self.device)
+
+    def _get_w2c_matrix(self, cam_position, cam_quaternion):
+        # dgr/__init__.py:349-368
+        if isinstance(cam_position, torch.Tensor):
+            cam_position = cam_position.cpu().numpy()
+        if isinstance(cam_quaternion, torch.Tensor):
+            cam_quaternion = cam_quaternion.cpu().numpy()
+        cam_position = np.asarray(cam_position)
+        rot = scipy.spatial.transform.Rotation.from_quat(cam_quaternion).as_matrix()
+        rot = rot[:, [1, 2, 0]]  # [F|R|U] -> [R|U|F]
+        w2c = np.zeros((4, 4), dtype=np.float32)
+        w2c[:3, :3] = rot.transpose()
+        w2c[:3, [3]] = -rot.transpose() @ cam_position[:, None]
+        w2c[3, 3] = 1.0
+        return torch.from_numpy(w2c).to(self.device)
+
+    def _get_gaussian_rasterization_settings(self, cam_position, cam_quaternion):
+        # dgr/__init__.py:382-402: row-vector (transposed) matrices, black background,
+        # sh_degree 0, unit scale modifier.
+        view = self._get_w2c_matrix(cam_position, cam_quaternion).transpose(0, 1)
+        proj_t = self.P.transpose(0, 1)
+        return GaussianRasterizationSettings(
+            img_h=self.sensor_size[1],
+            img_w=self.sensor_size[0],
+            tanfovx=math.tan(self.fov_x * 0.5),
+            tanfovy=math.tan(self.fov_y * 0.5),
+            bg=torch.tensor([0.0, 0.0, 0.0], dtype=torch.float32, device=self.device),
+            scale_modifier=1.0,
+            view_matrix=view,
+            proj_matrix=view @ proj_t,
+            sh_degree=0,
+            campos=view.inverse()[3, :3],
+            prefiltered=False,
+            debug=False,
+        )
+
+    def get_gaussian_rasterizer(self, cam_position, cam_quaternion):
+        return GaussianRasterizer(
+            raster_settings=self._get_gaussian_rasterization_settings(cam_position, cam_quaternion))
+
+    # ---- rendering ---------------------------------------------------------------------
+    def _get_gaussian_rasterization(self, points, rasterizer):
+        # dgr/__init__.py:404-426
+        xyz, opacity = points[:, 0:3], points[:, 3:4]
+        scales, quaternion, rgbs = points[:, 4:7], points[:, 7:11], points[:, 11:]
+        image, _radii = rasterizer(
+            means3D=xyz,
+            means2D=torch.zeros_like(xyz, dtype=torch.float32, device=self.device),
+            shs=None,
+            colors_precomp=rgbs,
+            opacities=opacity,
+            scales=scales,
+            rotations=quaternion,
+            cov3D_precomp=None,
+        )
+        if self.flip_lr:
+            image = torch.flip(image, dims=[2])
+        if self.flip_ud:
+            image = torch.flip(image, dims=[1])
+        return image
+
+    def forward(self, points, cam_position=None, cam_quaternion=None, gaussian_rasterizer=None):
+        _, n_channels = points.shape
+        assert n_channels == 14, "The input tensor should have 14 channels."
+        if gaussian_rasterizer is None:
+            gaussian_rasterizer = self.get_gaussian_rasterizer(cam_position, cam_quaternion)
+        return self._get_gaussian_rasterization(points, gaussian_rasterizer)

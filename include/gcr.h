@@ -1,0 +1,177 @@
+/*
+ * gcr.h -- C ABI of the MI355X-native differentiable Gaussian rasterizer (libgcr_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of hzxie/GaussianCity's
+ * extensions/diff_gaussian_rasterization ("dgr/", CUDA sources under "cr/").  Plain pointers
+ * and sizes only -- no torch types.  Every pointer is a DEVICE pointer (gfx950 HBM) unless
+ * the name ends in _host.  All memory is owned by the caller (the reference lets torch own
+ * it: dgr/rasterize_points.cu:57-68,118-126); nothing is retained across calls.
+ *
+ * Entry point                      replaces (reference interface)
+ * -------------------------------  ---------------------------------------------------------
+ * gcr_rasterize_forward            CudaRasterizer::Rasterizer::forward   cr/rasterizer.h:25-37
+ *                                  (== cr/rasterizer_impl.cu:178-283, std::function resize
+ *                                  callbacks become C callbacks)
+ * gcr_forward_preprocess +         the same forward split at its one host sync
+ *   gcr_forward_render             (cr/rasterizer_impl.cu:236-238) so the caller allocates
+ *                                  the binning buffer itself (dgr/rasterize_points.cu:27-33)
+ * gcr_backward                     CudaRasterizer::Rasterizer::backward  cr/rasterizer.h:39-48
+ *                                  (== cr/rasterizer_impl.cu:287-338)
+ * gcr_mark_visible                 CudaRasterizer::Rasterizer::markVisible cr/rasterizer.h:22-23
+ * gcr_geometry_bytes/_image_bytes/ required<GeometryState|ImageState|BinningState>(n)
+ *   _binning_bytes                 cr/rasterizer_impl.h:65-69
+ * gcr_last_error                   the std::runtime_error text (cr/auxiliary.h:158-167)
+ *
+ * Conventions shared with the reference: matrices are 16 floats in the row-vector layout the
+ * kernels index as m[0],m[4],m[8],m[12] (cr/auxiliary.h:48-56); quaternions are (r,x,y,z) and
+ * are NOT normalised; absent optional inputs are NULL (the reference passes empty tensors,
+ * dgr/__init__.py:250-259); all arithmetic fp32, radii int32.
+ *
+ * Return codes: 0 (or a non-negative count) on success, negative gcr_status on failure with
+ * a message retrievable through gcr_last_error() (thread-local).
+ */
+#ifndef GCR_H_INCLUDED
+#define GCR_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCR_ABI_VERSION 1
+#define GCR_BLOCK_X 16 /* cr/config.h:16 */
+#define GCR_BLOCK_Y 16 /* cr/config.h:17 */
+#define GCR_NUM_CHANNELS 3 /* cr/config.h:15 */
+
+typedef enum gcr_status {
+  GCR_OK = 0,
+  GCR_ERR_INVALID_ARGUMENT = -1, /* bad shape / null pointer / exactly-one-of violated */
+  GCR_ERR_BUFFER_TOO_SMALL = -2, /* a scratch buffer is smaller than gcr_*_bytes() */
+  GCR_ERR_OVERFLOW = -3,         /* num_rendered does not fit the 32-bit instance index */
+  GCR_ERR_DEVICE = -4,           /* HIP runtime error (text in gcr_last_error) */
+  GCR_ERR_ALLOC = -5             /* a resize callback returned NULL */
+} gcr_status;
+
+/* GaussianRasterizationSettings (dgr/__init__.py:203-215) */
+typedef struct gcr_camera {
+  int32_t img_h, img_w;
+  float tanfovx, tanfovy;
+  float scale_modifier;
+  int32_t sh_degree;   /* active degree D, 0..3 */
+  int32_t prefiltered; /* accepted for API parity; culled points are simply skipped */
+  int32_t debug;       /* !=0: synchronise + check after every stage (cr/auxiliary.h:158) */
+  const float *bg;          /* [3] */
+  const float *view_matrix; /* [16] */
+  const float *proj_matrix; /* [16] */
+  const float *campos;      /* [3] */
+} gcr_camera;
+
+/* Per-Gaussian inputs (argument list of cr/rasterizer.h:25-37) */
+typedef struct gcr_gaussians {
+  int32_t P;                   /* number of Gaussians */
+  int32_t M;                   /* SH coefficients per Gaussian (sh.size(1)); 0 without SH */
+  const float *means3D;        /* [P,3] */
+  const float *opacities;      /* [P] */
+  const float *shs;            /* [P,M,3] or NULL */
+  const float *colors_precomp; /* [P,3]   or NULL  (exactly one of shs/colors_precomp) */
+  const float *scales;         /* [P,3]   or NULL */
+  const float *rotations;      /* [P,4]   or NULL */
+  const float *cov3D_precomp;  /* [P,6]   or NULL  (exactly one of scales+rotations/cov3D) */
+} gcr_gaussians;
+
+/* Gradient outputs (cr/rasterizer.h:39-48); every array must be ZERO-FILLED by the caller,
+ * as dgr/rasterize_points.cu:118-126 does with torch::zeros. */
+typedef struct gcr_grads {
+  float *dL_dmeans2D;   /* [P,3] (x,y used) */
+  float *dL_dconic;     /* [P,4] scratch, (x,y,w used) -- dgr/rasterize_points.cu:121 */
+  float *dL_dopacity;   /* [P] */
+  float *dL_dcolors;    /* [P,3] */
+  float *dL_dmeans3D;   /* [P,3] */
+  float *dL_dcov3D;     /* [P,6] */
+  float *dL_dsh;        /* [P,M,3] (unused when shs==NULL) */
+  float *dL_dscales;    /* [P,3] (unused when scales==NULL) */
+  float *dL_drotations; /* [P,4] (unused when scales==NULL) */
+} gcr_grads;
+
+/* Byte offsets of the sub-arrays carved from the three opaque scratch buffers.  Exposed so
+ * that tests can compare intermediate state with the oracle; not needed by normal callers. */
+typedef struct gcr_layout {
+  /* geometry buffer (per Gaussian) */
+  size_t geom_rec;           /* float[12] per Gaussian: x,y,conic.x,conic.y | conic.z,opacity,
+                                r,g | b,depth,rect_x(min|max<<16),rect_y(min|max<<16) */
+  size_t geom_cov3D;         /* float[6] per Gaussian */
+  size_t geom_clamped;       /* uint8 bitmask per Gaussian (bit ch set = channel clamped) */
+  size_t geom_tiles_touched; /* uint32 per Gaussian */
+  size_t geom_block_sums;    /* uint32 per 256-Gaussian block; exclusive-scanned in place */
+  size_t geom_num_rendered;  /* uint64 total */
+  size_t geom_total;
+  /* image buffer */
+  size_t img_final_T;   /* float per pixel   (ImageState::accum_alpha) */
+  size_t img_n_contrib; /* uint32 per pixel */
+  size_t img_ranges;    /* uint32[2] per tile */
+  size_t img_total;
+  /* binning buffer (per instance) */
+  size_t bin_keys[2]; /* uint64 per instance, ping/pong */
+  size_t bin_vals[2]; /* uint32 per instance, ping/pong */
+  size_t bin_hist;    /* radix-sort histogram table */
+  size_t bin_sorted;  /* 0 or 1: which ping/pong half holds the sorted list */
+  size_t bin_total;
+} gcr_layout;
+
+int gcr_abi_version(void);
+const char *gcr_last_error(void);
+
+size_t gcr_geometry_bytes(int32_t P);
+size_t gcr_image_bytes(int32_t W, int32_t H);
+size_t gcr_binning_bytes(int64_t R, int32_t W, int32_t H);
+int gcr_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout *out);
+
+/* K1 (project, cov2D, SH colour, tile rect) + K2 (scan of tiles touched).  Writes radii[P],
+ * fills geom, and returns num_rendered through *num_rendered_host after ONE 8-byte D2H copy
+ * (the sync the reference has at cr/rasterizer_impl.cu:236-238). */
+int gcr_forward_preprocess(const gcr_camera *cam, const gcr_gaussians *g, void *geom,
+                           size_t geom_bytes, int32_t *radii, int64_t *num_rendered_host,
+                           void *hip_stream);
+
+/* K3 (key emit) + K4 (stable radix sort by tile|depth) + K5 (tile ranges) + K6 (blend).
+ * out_color is [3,H,W].  R must be the value gcr_forward_preprocess returned. */
+int gcr_forward_render(const gcr_camera *cam, const gcr_gaussians *g, void *geom,
+                       size_t geom_bytes, void *binning, size_t binning_bytes, void *img,
+                       size_t img_bytes, int64_t R, float *out_color, void *hip_stream);
+
+/* K7 (reverse-walk blend gradient) + K8 (preprocess gradient). dL_dpix is [3,H,W]. */
+int gcr_backward(const gcr_camera *cam, const gcr_gaussians *g, const int32_t *radii,
+                 const void *geom, size_t geom_bytes, const void *binning,
+                 size_t binning_bytes, const void *img, size_t img_bytes, int64_t R,
+                 const float *dL_dpix, const gcr_grads *grads, void *hip_stream);
+
+/* K0: present[i] = (view-space z > 0.2).  present is uint8[P]. */
+int gcr_mark_visible(int32_t P, const float *means3D, const float *view_matrix,
+                     const float *proj_matrix, uint8_t *present, void *hip_stream);
+
+/* One-call forward with the reference's resize-callback contract
+ * (cr/rasterizer.h:25-27: std::function<char*(size_t)>).  Each callback must return a device
+ * buffer of at least `bytes` bytes.  Returns num_rendered (>= 0) or a negative gcr_status. */
+typedef void *(*gcr_resize_fn)(void *user, size_t bytes);
+int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user,
+                              gcr_resize_fn binning_buffer, void *binning_user,
+                              gcr_resize_fn image_buffer, void *image_user,
+                              const gcr_camera *cam, const gcr_gaussians *g, float *out_color,
+                              int32_t *radii, void *hip_stream);
+
+/* Blend-kernel variant knobs (process-wide; for A/B measurement, defaults are the parity
+ * configuration).  name in {"fast_exp"}; returns previous value or <0 if unknown. */
+int gcr_set_option(const char *name, int value);
+
+/* Per-stage device timings of the most recent forward/backward on this thread, in ms,
+ * measured with hipEvents on the caller's stream when enabled via gcr_set_option("timing",1).
+ * stage ids: 0 preprocess, 1 scan, 2 emit, 3 sort, 4 ranges, 5 blend_fwd, 6 blend_bwd,
+ * 7 preprocess_bwd.  Returns the number of stages written. */
+int gcr_get_stage_ms(float *ms_out, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCR_H_INCLUDED */
