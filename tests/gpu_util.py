@@ -1,0 +1,69 @@
+"""Helpers for the -m gpu parity tests: run the HIP path through the native-module surface and
+decode its opaque scratch buffers (layout from gcr_get_layout) for stage-wise comparison."""
+import numpy as np
+import torch
+
+from gaussiancity_amd import _native as N
+from gaussiancity_amd import ext
+
+
+def to_dev(a, device):
+    if a is None:
+        return torch.Tensor([])
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def run_forward(rs, sc, device, *, use_sh=True, use_cov3d=False, cov3D=None):
+    """Calls ext.rasterize_gaussians with the reference's positional signature."""
+    colors = torch.Tensor([]) if use_sh else to_dev(sc["colors_precomp"], device)
+    sh = to_dev(sc["shs"], device) if use_sh else torch.Tensor([])
+    scales = torch.Tensor([]) if use_cov3d else to_dev(sc["scales"], device)
+    rots = torch.Tensor([]) if use_cov3d else to_dev(sc["rotations"], device)
+    cov = to_dev(cov3D, device) if use_cov3d else torch.Tensor([])
+    args = (rs.bg.to(device), to_dev(sc["means3D"], device), colors, to_dev(sc["opacities"], device),
+            scales, rots, rs.scale_modifier, cov, rs.view_matrix.to(device), rs.proj_matrix.to(device),
+            rs.tanfovx, rs.tanfovy, rs.img_h, rs.img_w, sh, rs.sh_degree, rs.campos.to(device),
+            rs.prefiltered, rs.debug)
+    out = ext.rasterize_gaussians(*args)
+    torch.cuda.synchronize()
+    return args, out
+
+
+def run_backward(args, out, dL_dpix, device):
+    (bg, means3D, colors, opacity, scales, rots, scale_modifier, cov, view, proj, tfx, tfy, H, W,
+     sh, degree, campos, prefiltered, debug) = args
+    R, color, radii, geom, binning, img = out
+    g = ext.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, scale_modifier,
+                                         cov, view, proj, tfx, tfy, to_dev(dL_dpix, device), sh,
+                                         degree, campos, geom, R, binning, img, debug)
+    torch.cuda.synchronize()
+    names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh",
+             "dL_dscale", "dL_drot")
+    return {n: t.cpu().numpy() for n, t in zip(names, g)}
+
+
+def decode(P, W, H, out):
+    """Opaque buffers -> dict of numpy arrays named like the oracle's Frame attributes."""
+    R, color, radii, geom, binning, img = out
+    L = N.get_layout(P, W, H, R)
+    gb, bb, ib = geom.cpu().numpy(), binning.cpu().numpy(), img.cpu().numpy()
+    rec = gb[L.geom_rec:L.geom_rec + P * 48].view(np.float32).reshape(P, 12)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    d = dict(
+        R=R, out_color=color.cpu().numpy(), radii=radii.cpu().numpy(),
+        means2D=rec[:, 0:2], conic_opacity=np.concatenate([rec[:, 2:5], rec[:, 5:6]], 1),
+        rgb=rec[:, 6:9], depths=rec[:, 9],
+        rect=rec[:, 10:12].copy().view(np.uint32),
+        cov3D=gb[L.geom_cov3D:L.geom_cov3D + P * 24].view(np.float32).reshape(P, 6),
+        clamped=gb[L.geom_clamped:L.geom_clamped + P],
+        tiles_touched=gb[L.geom_tiles_touched:L.geom_tiles_touched + 4 * P].view(np.uint32),
+        final_T=ib[L.img_final_T:L.img_final_T + 4 * W * H].view(np.float32),
+        n_contrib=ib[L.img_n_contrib:L.img_n_contrib + 4 * W * H].view(np.uint32),
+        ranges=ib[L.img_ranges:L.img_ranges + 8 * T].view(np.uint32).reshape(T, 2),
+    )
+    if R > 0:
+        s = L.bin_sorted
+        d["keys"] = bb[L.bin_keys[s]:L.bin_keys[s] + 8 * R].view(np.uint64)
+        d["point_list"] = bb[L.bin_vals[s]:L.bin_vals[s] + 4 * R].view(np.uint32)
+        d["keys_unsorted"] = bb[L.bin_keys[0]:L.bin_keys[0] + 8 * R].view(np.uint64) if s == 1 else None
+    return d

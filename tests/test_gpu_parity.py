@@ -1,0 +1,181 @@
+"""-m gpu: HIP path (through the native-module surface -> C ABI -> gfx950 kernels) vs the CPU
+oracle on identical seeded inputs.  Bars:
+  forward:  radii, num_rendered, sorted list, tile ranges, n_contrib EXACT; per-Gaussian
+            state, final_T and the image BIT-EXACT (numerics contract gcr-fp32-v1);
+  backward: every gradient tensor max|d| <= 1e-4 * max(1, max|ref|)  (fp32 atomics reorder
+            the sums, so bit-exactness is not defined there).
+"""
+import numpy as np
+import pytest
+import torch
+
+import gpu_util as G
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+GRAD_TOL = 1e-4
+
+
+def _frame(O, rs, sc, use_sh=True, cov3D=None):
+    kw = scenes.settings_kwargs(rs)
+    extra = dict(shs=sc["shs"]) if use_sh else dict(colors_precomp=sc["colors_precomp"])
+    if cov3D is not None:
+        extra["cov3D_precomp"] = cov3D
+    else:
+        extra.update(scales=sc["scales"], rotations=sc["rotations"])
+    return O.Frame(**kw, means3D=sc["means3D"], opacities=sc["opacities"], **extra)
+
+
+def _check_forward(fr, d, P, use_sh, has_cov3d_state=True):
+    vis = fr.radii > 0
+    assert d["R"] == fr.R
+    np.testing.assert_array_equal(d["radii"], fr.radii)
+    np.testing.assert_array_equal(d["tiles_touched"], fr.tiles_touched[:P])
+    for name in ("means2D", "conic_opacity", "depths"):
+        a, b = d[name][vis], getattr(fr, name)[:P][vis]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name + " not bit-exact"
+    if use_sh:
+        assert np.array_equal(d["rgb"][vis].view(np.uint32), fr.rgb[:P][vis].view(np.uint32))
+        cl = fr.clamped[:P]
+        mask = (cl[:, 0] | (cl[:, 1] << 1) | (cl[:, 2] << 2)).astype(np.uint8)
+        np.testing.assert_array_equal(d["clamped"][vis], mask[vis])
+    if has_cov3d_state:
+        assert np.array_equal(d["cov3D"][vis].view(np.uint32), fr.cov3D[:P][vis].view(np.uint32))
+    if fr.R > 0:
+        np.testing.assert_array_equal(d["keys"], fr.keys[:fr.R])
+        np.testing.assert_array_equal(d["point_list"], fr.point_list[:fr.R])
+    np.testing.assert_array_equal(d["ranges"], fr.ranges)
+    np.testing.assert_array_equal(d["n_contrib"], fr.n_contrib)
+    assert np.array_equal(d["final_T"].view(np.uint32), fr.final_T.view(np.uint32)), "final_T not bit-exact"
+    assert np.array_equal(d["out_color"].view(np.uint32), fr.out_color.view(np.uint32)), (
+        "image not bit-exact, max diff %g" % np.abs(d["out_color"] - fr.out_color).max())
+
+
+def _check_grads(gref, ggpu, names):
+    for n in names:
+        ref, got = gref[n], ggpu[n]
+        assert ref.shape == got.shape, n
+        tol = GRAD_TOL * max(1.0, float(np.abs(ref).max()))
+        err = float(np.abs(ref - got).max())
+        assert err <= tol, "%s: max|d| %.3e > %.3e" % (n, err, tol)
+
+
+CASES = [
+    # name, P, W, H, sh_degree(None = precomputed colour), bg, seed
+    ("sh3_ragged", 3000, 200, 150, 3, (0.0, 0.0, 0.0), 11),
+    ("sh0_bg", 2000, 128, 128, 0, (0.3, 0.1, 0.7), 12),
+    ("sh1", 1500, 96, 80, 1, (0.0, 0.0, 0.0), 13),
+    ("sh2", 1500, 96, 80, 2, (1.0, 1.0, 1.0), 14),
+    ("precomp_colour", 4000, 256, 144, None, (0.0, 0.0, 0.0), 15),
+    ("tiny_image", 300, 17, 9, 3, (0.5, 0.5, 0.5), 16),
+    ("dense_overdraw", 6000, 64, 64, 3, (0.0, 0.0, 0.0), 17),
+]
+
+
+@pytest.mark.parametrize("name,P,W,H,deg,bg,seed", CASES, ids=[c[0] for c in CASES])
+def test_forward_backward_parity(oracle_mod, cuda_device, name, P, W, H, deg, bg, seed):
+    use_sh = deg is not None
+    rs = scenes.camera(W, H, pose_index=seed % 24)._replace(
+        sh_degree=deg if use_sh else 0, bg=torch.tensor(bg, dtype=torch.float32))
+    sc = scenes.blob_scene(P, seed, deg if use_sh else 0,
+                           smax=12.0 if name == "dense_overdraw" else 6.0)
+    fr = _frame(oracle_mod, rs, sc, use_sh)
+    args, out = G.run_forward(rs, sc, cuda_device, use_sh=use_sh)
+    d = G.decode(P, W, H, out)
+    _check_forward(fr, d, P, use_sh)
+    dpix = np.random.default_rng(seed).normal(size=(3, H, W)).astype(np.float32)
+    gref = fr.backward(dpix)
+    ggpu = G.run_backward(args, out, dpix, cuda_device)
+    names = ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot"]
+    if use_sh:
+        names.append("dL_dsh")
+    _check_grads(gref, ggpu, names)
+
+
+def test_precomputed_cov3d(oracle_mod, cuda_device):
+    P, W, H = 2500, 160, 96
+    rs = scenes.camera(W, H)._replace(sh_degree=2)
+    sc = scenes.blob_scene(P, 21, 2)
+    # take the covariance the oracle derives from scale/rotation and feed it back precomputed
+    cov = _frame(oracle_mod, rs, sc).cov3D[:P].copy()
+    fr = _frame(oracle_mod, rs, sc, cov3D=cov)
+    args, out = G.run_forward(rs, sc, cuda_device, use_cov3d=True, cov3D=cov)
+    d = G.decode(P, W, H, out)
+    _check_forward(fr, d, P, True, has_cov3d_state=False)
+    dpix = np.random.default_rng(3).normal(size=(3, H, W)).astype(np.float32)
+    _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device),
+                 ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh"])
+
+
+def test_all_culled_and_empty(oracle_mod, cuda_device):
+    """Everything behind the camera -> R == 0, image == background; and P == 0."""
+    W, H = 64, 48
+    rs = scenes.camera(W, H)._replace(bg=torch.tensor([0.25, 0.5, 0.75]))
+    sc = scenes.blob_scene(200, 5, 0)
+    sc["means3D"][:, 2] += 10000.0  # far above the camera, behind the near plane
+    fr = _frame(oracle_mod, rs, sc, use_sh=False)
+    assert fr.R == 0
+    args, out = G.run_forward(rs, sc, cuda_device, use_sh=False)
+    assert out[0] == 0
+    img = out[1].cpu().numpy()
+    assert np.array_equal(img, fr.out_color)
+    assert np.all(out[2].cpu().numpy() == 0)
+    g = G.run_backward(args, out, np.ones((3, H, W), np.float32), cuda_device)
+    assert all(np.all(v == 0) for v in g.values())
+    # P == 0 short-circuit (dgr/rasterize_points.cu:71)
+    sc0 = {k: (v[:0] if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
+    _, out0 = G.run_forward(rs, sc0, cuda_device, use_sh=False)
+    assert out0[0] == 0 and out0[1].shape == (3, H, W) and float(out0[1].abs().max()) == 0.0
+
+
+def test_mark_visible(oracle_mod, cuda_device):
+    from gaussiancity_amd import ext
+    rs = scenes.camera(64, 64)
+    sc = scenes.blob_scene(5000, 9, 0, spread=400.0)
+    ref = oracle_mod.mark_visible(sc["means3D"], rs.view_matrix.numpy(), rs.proj_matrix.numpy())
+    got = ext.mark_visible(G.to_dev(sc["means3D"], cuda_device), rs.view_matrix.to(cuda_device),
+                           rs.proj_matrix.to(cuda_device)).cpu().numpy()
+    assert got.dtype == np.bool_ and 0 < ref.sum() < len(ref)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_sort_is_stable_on_depth_ties(oracle_mod, cuda_device):
+    """Many Gaussians at IDENTICAL depth in the same tiles: the blend order must be ascending
+    Gaussian index (stable radix sort, cr/rasterizer_impl.cu:255-260)."""
+    P, W, H = 1200, 80, 64
+    rs = scenes.camera(W, H)
+    sc = scenes.blob_scene(P, 31, 0)
+    sc["means3D"][:] = sc["means3D"][0]          # same point -> same depth, same tiles
+    sc["means3D"][::3, 0] += 3.0                  # a second and third depth class, interleaved
+    sc["means3D"][1::3, 0] -= 3.0
+    fr = _frame(oracle_mod, rs, sc, use_sh=False)
+    args, out = G.run_forward(rs, sc, cuda_device, use_sh=False)
+    d = G.decode(P, W, H, out)
+    assert fr.R > 1000
+    np.testing.assert_array_equal(d["point_list"], fr.point_list[:fr.R])
+    assert np.array_equal(d["out_color"].view(np.uint32), fr.out_color.view(np.uint32))
+
+
+def test_autograd_api_matches_oracle(oracle_mod, cuda_device):
+    """Same check through GaussianRasterizer / autograd (what generator code calls)."""
+    from gaussiancity_amd import GaussianRasterizer
+    P, W, H = 2000, 112, 80
+    rs_cpu = scenes.camera(W, H)._replace(sh_degree=3)
+    sc = scenes.blob_scene(P, 41, 3)
+    fr = _frame(oracle_mod, rs_cpu, sc)
+    rs = rs_cpu._replace(bg=rs_cpu.bg.to(cuda_device), view_matrix=rs_cpu.view_matrix.to(cuda_device),
+                         proj_matrix=rs_cpu.proj_matrix.to(cuda_device), campos=rs_cpu.campos.to(cuda_device))
+    t = {k: G.to_dev(sc[k], cuda_device).requires_grad_(True)
+         for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    means2D = torch.zeros((P, 3), device=cuda_device, requires_grad=True)
+    img, radii = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"],
+                                        shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    assert np.array_equal(img.detach().cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
+    np.testing.assert_array_equal(radii.cpu().numpy(), fr.radii)
+    dpix = np.random.default_rng(1).normal(size=(3, H, W)).astype(np.float32)
+    (img * G.to_dev(dpix, cuda_device)).sum().backward()
+    gref = fr.backward(dpix)
+    got = dict(dL_dmean3D=t["means3D"].grad, dL_dmean2D=means2D.grad, dL_dopacity=t["opacities"].grad,
+               dL_dsh=t["shs"].grad, dL_dscale=t["scales"].grad, dL_drot=t["rotations"].grad)
+    _check_grads(gref, {k: v.cpu().numpy() for k, v in got.items()}, list(got))
