@@ -1,0 +1,264 @@
+#!/usr/bin/env python
+"""bench.py -- hot-path benchmark of the MI355X-native Gaussian rasterizer.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one frame: one forward pass of the rasterizer over the resident synthetic scene for
+the next pose of the 24-pose inference orbit (reference scripts/inference.py:655-667 renders
+one frame per loop iteration).  Default workload = BASELINE.json's headline config C3
+(5M-Gaussian S-city scene, 1920x1080, SH degree 3, forward only).  Frames are independent, so
+with N GPUs rank r renders poses r, r+N, ... (no collective on the data path; weak scaling:
+every rank renders K frames).  Scene tensors and camera matrices are resident in HBM before
+the timed region starts.
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
+  "roofline":     dominant kernel's ALGORITHMIC bytes (SURVEY.md 8d / DESIGN.md 6) / its mean
+                  duration, measured with HIP events on the launch stream inside the timed region;
+  "cpu_baseline": the CPU oracle (oracle/, a restatement -- the reference has no CPU path)
+                  timed on a bounded sample on this host's cores;
+  "stages_ms":    every stage's mean device time and achieved algorithmic GB/s;
+  "secondary":    C2 (500k Gaussians, 640x448, SH3) forward+backward ms/frame, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured copy)
+
+
+def higher_msb(n):
+    """cr/rasterizer_impl.cu:35-48 (getHigherMsb): bits needed for the tile id."""
+    msb, step = 16, 16
+    while step > 1:
+        step //= 2
+        msb = msb + step if (n >> msb) else msb - step
+    return msb + 1 if (n >> msb) else msb
+
+
+def algorithmic_bytes(P, P_v, R, R_p, W, H, M, sh):
+    """Per-frame algorithmic HBM bytes of every stage."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    c3 = 12 * M if sh else 0
+    w1 = 75 if sh else 60
+    P_c = P - P_v
+    return {
+        "preprocess": P_v * (44 + c3 + w1) + 20 * P_c,
+        "scan": 8 * P,
+        "emit": 4 * P + 16 * P_v + 12 * R,
+        "sort": 24 * R,  # lower bound: one read + one write of 12-byte pairs
+        "ranges": 8 * R + 8 * T,
+        "blend_fwd": 40 * R_p + 20 * W * H + 8 * T,
+        "blend_bwd": 112 * R_p + 20 * W * H + 8 * T,
+        "preprocess_bwd": P_v * (96 + (15 + c3 if sh else 0)) + P_v * (64 + c3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--points", type=int, default=None, help="override P (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--fast-exp", action="store_true", help="non-parity v_exp_f32 variant (A/B only)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gaussiancity_amd import _native as N
+    from gaussiancity_amd import ext, synth
+    from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    N.lib()
+    N.set_option("fast_exp", 1 if args.fast_exp else 0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def load_scene(cfg_name, points=None):
+        cfg, sc = synth.make_scene(cfg_name, points)
+        W, H = cfg["W"], cfg["H"]
+        wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), device=dev)
+        cams = []
+        for pos, quat in synth.orbit_poses():
+            rs = wr._get_gaussian_rasterization_settings(pos, quat)
+            cams.append(rs._replace(sh_degree=cfg["sh_degree"]))
+        use_sh = not cfg.get("precomp_color", False)
+        t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items() if isinstance(v, np.ndarray)}
+        empty = torch.Tensor([])
+
+        def fwd(pose):
+            rs = cams[pose % len(cams)]
+            a = (rs.bg, t["means3D"], empty if use_sh else t["colors_precomp"], t["opacities"],
+                 t["scales"], t["rotations"], rs.scale_modifier, empty, rs.view_matrix, rs.proj_matrix,
+                 rs.tanfovx, rs.tanfovy, rs.img_h, rs.img_w, t["shs"] if use_sh else empty,
+                 rs.sh_degree, rs.campos, False, False)
+            return a, ext.rasterize_gaussians(*a)
+
+        return cfg, sc, cams, use_sh, fwd
+
+    cfg, sc, cams, use_sh, fwd = load_scene(args.config, args.points)
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    M = sc["shs"].shape[1] if use_sh else 0
+    poses = [rank + i * world for i in range(args.warmup + args.steps)]
+
+    # ---- warm-up, then the timed region (stage timers are non-blocking HIP events) ----------
+    for i in range(args.warmup):
+        fwd(poses[i])
+    N.set_option("timing", 1)
+    N.stage_ms()  # reset accumulators
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        fwd(poses[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stage = N.stage_ms()
+    N.set_option("timing", 0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_frames = args.steps * world
+    fps = total_frames / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- per-frame workload statistics over the same poses (untimed) --------------------
+        stats = []
+        for i in range(args.warmup, args.warmup + args.steps):
+            _, o = fwd(poses[i])
+            R, _, radii, _, _, img = o
+            L = N.get_layout(P, W, H, R)
+            nc = img[L.img_n_contrib:L.img_n_contrib + 4 * W * H].view(torch.int32).view(H, W)
+            Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+            pad = torch.zeros((Hp, Wp), dtype=torch.int32, device=dev)
+            pad[:H, :W] = nc
+            R_p = int(pad.view(Hp // 16, 16, Wp // 16, 16).amax(dim=(1, 3)).sum().item())
+            stats.append((R, R_p, int((radii > 0).sum().item())))
+        R_mean = float(np.mean([s[0] for s in stats]))
+        Rp_mean = float(np.mean([s[1] for s in stats]))
+        Pv_mean = float(np.mean([s[2] for s in stats]))
+        ab = algorithmic_bytes(P, Pv_mean, R_mean, Rp_mean, W, H, M, use_sh)
+        fwd_stages = ("preprocess", "scan", "emit", "sort", "ranges", "blend_fwd")
+        stages = {}
+        for k in fwd_stages:
+            ms = stage.get(k, 0.0)
+            stages[k] = {"ms": round(ms, 4), "alg_MB": round(ab[k] / 1e6, 3),
+                         "alg_GBps": round(ab[k] / 1e9 / (ms / 1e3), 1) if ms > 0 else None}
+        dom = max(fwd_stages, key=lambda k: stage.get(k, 0.0))
+        dom_ms = stage[dom]
+        achieved = ab[dom] / 1e9 / (dom_ms / 1e3) if dom_ms > 0 else 0.0
+        blend_ms = stage["blend_fwd"]
+        blend_ach = ab["blend_fwd"] / 1e9 / (blend_ms / 1e3) if blend_ms > 0 else 0.0
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launch_ms": round(dom_ms, 4), "alg_bytes_per_launch": int(ab[dom]),
+                    "alpha_blend": {"kernel": "blend_fwd", "achieved": round(blend_ach, 1),
+                                    "frac": round(blend_ach / HBM_PEAK_GBS, 4),
+                                    "launch_ms": round(blend_ms, 4)}}
+        T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        sort_passes = (32 + higher_msb(T_tiles) + 7) // 8
+        if dom == "sort":
+            roofline["note"] = ("sort = %d radix passes x (histogram, scan, scatter); `achieved` uses the "
+                                "24*R one-pass lower bound of SURVEY.md 8d" % sort_passes)
+
+        out = {
+            "metric": "rendered frames/sec (fwd) @ %d Gaussians, %dx%d" % (P, W, H),
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (gcity-synth-v1 %s, seed %d)" % (cfg["scene"], cfg["seed"]),
+            "config": {"workload": "%s: %s %d Gaussians, %dx%d, SH degree %d, forward, 24-pose orbit"
+                                   % (args.config, cfg["scene"], P, W, H, cfg["sh_degree"]),
+                       "parallelism": "frames sharded round-robin, one frame per GPU, no data-path collective",
+                       "exp": "v_exp_f32 (non-parity)" if args.fast_exp else "gcr-fp32-v1 (bit-exact vs oracle)"},
+            "frame_stats": {"num_rendered": R_mean, "consumed_entries_Rp": Rp_mean, "visible": Pv_mean,
+                            "tiles": T_tiles, "sort_passes": sort_passes},
+            "stages_ms": stages,
+            "roofline": roofline,
+        }
+
+        # ---- CPU baseline: the oracle on a bounded sample of the same workload --------------
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            rs = cams[0]
+            kw = dict(img_h=rs.img_h, img_w=rs.img_w, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy,
+                      bg=rs.bg.cpu().numpy(), scale_modifier=rs.scale_modifier,
+                      view_matrix=rs.view_matrix.cpu().numpy(), proj_matrix=rs.proj_matrix.cpu().numpy(),
+                      sh_degree=rs.sh_degree, campos=rs.campos.cpu().numpy(), means3D=sc["means3D"],
+                      opacities=sc["opacities"], scales=sc["scales"], rotations=sc["rotations"])
+            kw.update(dict(shs=sc["shs"]) if use_sh else dict(colors_precomp=sc["colors_precomp"]))
+            O.lib()
+            tc = time.perf_counter()
+            fr = O.Frame(**kw)
+            cpu_s = time.perf_counter() - tc
+            _, o = fwd(0)
+            same = bool(np.array_equal(o[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32)))
+            out["cpu_baseline"] = {"value": round(1.0 / cpu_s, 4), "unit": "frames/s", "cores": O.num_threads(),
+                                   "kind": "port", "sample": "1 frame (pose 0) of the same workload, %.1f s" % cpu_s,
+                                   "host_cpus": os.cpu_count(), "gpu_image_bit_exact_vs_cpu": same}
+
+        # ---- secondary metric: C2 forward+backward ms/frame ----------------------------------
+        if world == 1 and not args.no_secondary and args.config != "C2":
+            del fwd
+            torch.cuda.empty_cache()
+            cfg2, sc2, cams2, use_sh2, fwd2 = load_scene("C2", None if args.points is None else min(args.points, 500000))
+            W2, H2 = cfg2["W"], cfg2["H"]
+            dpix = torch.from_numpy(synth.grad_image(W2, H2, cfg2["seed"])).to(dev)
+
+            def fb(pose):
+                a, o = fwd2(pose)
+                (bg, m3, col, opa, scl, rot, smod, cov, view, proj, tfx, tfy, h, w, sh, deg, campos, _, _) = a
+                R, color, radii, geom, binning, img = o
+                ext.rasterize_gaussians_backward(bg, m3, radii, col, scl, rot, smod, cov, view, proj, tfx, tfy,
+                                                 dpix, sh, deg, campos, geom, R, binning, img, False)
+            for i in range(3):
+                fb(i)
+            N.set_option("timing", 1)
+            N.stage_ms()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n2 = 12
+            for i in range(n2):
+                fb(3 + i)
+            torch.cuda.synchronize()
+            ms2 = 1e3 * (time.perf_counter() - t1) / n2
+            st2 = N.stage_ms()
+            N.set_option("timing", 0)
+            out["secondary"] = {"metric": "fwd+bwd ms/frame @ %d Gaussians, %dx%d, SH3" % (cfg2["P"], W2, H2),
+                                "value": round(ms2, 4), "unit": "ms/frame", "higher_is_better": False,
+                                "stages_ms": {k: round(v, 4) for k, v in st2.items()}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,6 @@ std::atomic<int> g_fast_exp{0};
 std::atomic<int> g_timing{0};
 
 enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PRE_BWD, ST_COUNT };
-thread_local float g_stage_ms[ST_COUNT];
 
 int fail(gcr_status code, const std::string& msg) {
   g_err = msg;
@@ -33,29 +32,46 @@ int fail_hip(hipError_t e, const char* where) {
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
-// RAII stage timer: two hipEvents on the caller's stream, resolved at scope exit (sync).
+// Stage timer: a pair of hipEvents per stage recorded on the caller's stream.  Non-blocking:
+// the previous recording of a stage is resolved when the stage is recorded again (by then it
+// has completed: same stream, and every forward has a host sync in the middle), so timing can
+// stay enabled inside a benchmark's timed region.  gcr_get_stage_ms() resolves what is
+// pending and reports the average per stage since the last call.
+struct StageSlot {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool pending = false;
+  double sum_ms = 0.0;
+  long count = 0;
+};
+thread_local StageSlot g_slots[ST_COUNT];
+
+void stage_resolve(StageSlot& sl) {
+  if (!sl.pending) return;
+  float ms = 0;
+  if (hipEventSynchronize(sl.b) == hipSuccess && hipEventElapsedTime(&ms, sl.a, sl.b) == hipSuccess) {
+    sl.sum_ms += ms;
+    sl.count += 1;
+  }
+  sl.pending = false;
+}
+
 struct StageTimer {
   hipStream_t s;
-  int stage;
-  hipEvent_t a = nullptr, b = nullptr;
-  bool on;
-  StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_), on(g_timing.load() != 0) {
-    if (on) {
-      (void)hipEventCreate(&a);
-      (void)hipEventCreate(&b);
-      (void)hipEventRecord(a, s);
+  StageSlot* sl = nullptr;
+  StageTimer(hipStream_t s_, int stage) : s(s_) {
+    if (g_timing.load() == 0) return;
+    sl = &g_slots[stage];
+    if (!sl->a) {
+      (void)hipEventCreate(&sl->a);
+      (void)hipEventCreate(&sl->b);
     }
+    stage_resolve(*sl);
+    (void)hipEventRecord(sl->a, s);
   }
   ~StageTimer() {
-    if (on) {
-      (void)hipEventRecord(b, s);
-      (void)hipEventSynchronize(b);
-      float ms = 0;
-      (void)hipEventElapsedTime(&ms, a, b);
-      g_stage_ms[stage] = ms;
-      (void)hipEventDestroy(a);
-      (void)hipEventDestroy(b);
-    }
+    if (!sl) return;
+    (void)hipEventRecord(sl->b, s);
+    sl->pending = true;
   }
 };
 
@@ -162,7 +178,13 @@ int gcr_set_option(const char* name, int value) {
 
 int gcr_get_stage_ms(float* ms_out, int capacity) {
   int n = capacity < (int)ST_COUNT ? capacity : (int)ST_COUNT;
-  for (int i = 0; i < n; i++) ms_out[i] = g_stage_ms[i];
+  for (int i = 0; i < n; i++) {
+    StageSlot& sl = g_slots[i];
+    stage_resolve(sl);
+    ms_out[i] = sl.count ? (float)(sl.sum_ms / (double)sl.count) : 0.0f;
+    sl.sum_ms = 0.0;
+    sl.count = 0;
+  }
   return n;
 }
 

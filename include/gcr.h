@@ -165,8 +165,8 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  * configuration).  name in {"fast_exp"}; returns previous value or <0 if unknown. */
 int gcr_set_option(const char *name, int value);
 
-/* Per-stage device timings of the most recent forward/backward on this thread, in ms,
- * measured with hipEvents on the caller's stream when enabled via gcr_set_option("timing",1).
+/* Average per-stage device time (ms) on this thread since the previous call,
+ * measured with hipEvents on the caller's stream (non-blocking) when gcr_set_option("timing",1).
  * stage ids: 0 preprocess, 1 scan, 2 emit, 3 sort, 4 ranges, 5 blend_fwd, 6 blend_bwd,
  * 7 preprocess_bwd.  Returns the number of stages written. */
 int gcr_get_stage_ms(float *ms_out, int capacity);
