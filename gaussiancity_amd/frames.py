@@ -1,0 +1,119 @@
+"""Frame loops around the rasterizer, one process per GPU.
+
+The hot path shards by FRAME: a frame is one camera over a replicated Gaussian set, with no
+cross-frame state (reference utils/helpers.py:255-260, scripts/inference.py:655-667).  So
+
+  * inference: rank r renders frames r, r+world, ... -- no collective on the data path; frames
+    are only gathered at the end (all_gather of [3,H,W] images) if the caller wants the video
+    on one rank;
+  * training: the reference is plain DDP (core/train.py:78-87): one frame per rank per step,
+    then an all-reduce(avg) of the generator gradients (69.8M fp32 = 279 MB for the BG config,
+    SURVEY.md 2.2).  `allreduce_gradients` is that collective, bucketed flat buffers over
+    torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+    The rasterizer's own backward needs no collective.
+
+Nothing here touches CUDA/HIP directly; it works on whatever device the tensors live on, which
+is what lets the world_size-2 gloo tests cover the N>1 logic on CPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_frames(n_frames, rank, world):
+    """Round-robin frame ownership: frame f belongs to rank f % world."""
+    return list(range(rank, n_frames, world))
+
+
+def render_sharded(render_fn, n_frames, rank=None, world=None, gather=True, group=None):
+    """Each rank renders its own frames with `render_fn(frame_index) -> Tensor[3,H,W]`.
+
+    Returns {frame_index: image}.  With gather=True every rank ends up with all frames
+    (one all_gather of equally sized stacks; the last round is padded), which is the only
+    collective and is off the per-frame critical path.
+    """
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = shard_frames(n_frames, rank, world)
+    local = {f: render_fn(f) for f in mine}
+    if not gather or world == 1:
+        return local
+    per_rank = (n_frames + world - 1) // world
+    sample = next(iter(local.values())) if local else None
+    shape = torch.tensor(list(sample.shape) if sample is not None else [0, 0, 0], dtype=torch.int64)
+    if sample is not None and sample.is_cuda:
+        shape = shape.to(sample.device)
+    dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=group)
+    c, h, w = [int(v) for v in shape.tolist()]
+    ref = sample if sample is not None else torch.zeros(1, device=shape.device)
+    stack = torch.zeros((per_rank, c, h, w), dtype=torch.float32, device=ref.device)
+    for slot, f in enumerate(mine):
+        stack[slot] = local[f]
+    gathered = [torch.empty_like(stack) for _ in range(world)]
+    dist.all_gather(gathered, stack, group=group)
+    out = {}
+    for r in range(world):
+        for slot, f in enumerate(shard_frames(n_frames, r, world)):
+            out[f] = gathered[r][slot]
+    return out
+
+
+def allreduce_gradients(tensors, group=None, bucket_bytes=64 << 20, average=True):
+    """DDP-style gradient exchange: pack `tensors` (in order) into flat fp32 buckets of about
+    `bucket_bytes`, all-reduce each bucket, scale by 1/world, and scatter back in place.
+    Returns the number of buckets used.  Bucket size is a knob because a ring all-reduce over
+    xGMI is per-link bound (7 links x ~153 GB/s per GPU): fewer, larger messages amortise the
+    launch + protocol latency; 64 MB keeps a 279 MB gradient set at five messages."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    world = dist.get_world_size(group)
+    buckets, cur, cur_bytes = [], [], 0
+    for t in tensors:
+        nbytes = t.numel() * t.element_size()
+        if cur and cur_bytes + nbytes > bucket_bytes:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(t)
+        cur_bytes += nbytes
+    if cur:
+        buckets.append(cur)
+    for b in buckets:
+        flat = torch.cat([t.reshape(-1) for t in b])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat.div_(world)
+        off = 0
+        for t in b:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+    return len(buckets)
+
+
+class TrainStepHarness:
+    """Shape of the reference's G-step (core/train.py:263-295) around the rasterizer only:
+    points -> rasterize (wrapper API) -> crop -> stand-in loss -> backward -> gradient
+    all-reduce of a stand-in parameter set.  The generator/discriminator/VGG are out of scope
+    (plain torch modules); `n_param` fp32 values stand in for their gradients so the RCCL
+    message sizes match the real training step (BG generator: 69,809,101 parameters)."""
+
+    def __init__(self, rasterizer_wrapper, n_param=69_809_101, crop=None, device=None, group=None):
+        self.rw = rasterizer_wrapper
+        self.crop = crop
+        self.group = group
+        self.device = device if device is not None else rasterizer_wrapper.device
+        self.param_grad = torch.zeros(n_param, dtype=torch.float32, device=self.device)
+
+    def step(self, points, cam_pos, cam_quat, target=None):
+        """points: [N,14] leaf tensor requiring grad.  Returns (loss, image)."""
+        img = self.rw(points, cam_pos, cam_quat)
+        if self.crop is not None:
+            x, y, w, h = self.crop
+            img = img[:, y:y + h, x:x + w]
+        loss = (img - target).abs().mean() if target is not None else img.abs().mean()
+        loss.backward()
+        # stand-in for "the generator's gradients depend on d(loss)/d(points)"
+        self.param_grad.fill_(points.grad.abs().mean())
+        n_buckets = allreduce_gradients([self.param_grad], group=self.group)
+        return loss.detach(), img.detach(), n_buckets

@@ -1,0 +1,91 @@
+"""C-ABI library (not gpu): it loads without a GPU, exports every symbol include/gcr.h declares,
+its host-only entry points work, and argument errors are reported through the status/last-error
+convention -- no compute call is made here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from gaussiancity_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "gcr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gcr_[a-z_]+)\s*\(", src)) - {"gcr_resize_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    lib = N.lib()
+    declared = _header_functions()
+    assert set(declared) == set(N.EXPORTED_SYMBOLS), (declared, N.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", N.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (gcr_[a-z_]+)", out))
+    assert set(declared) <= exported
+    assert lib.gcr_abi_version() == 1
+
+
+def test_library_contains_gfx950_code_object():
+    blob = open(N.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_blend_fwd" in blob and b"k_radix_scatter" in blob
+
+
+def test_scratch_sizes_and_layout():
+    lib = N.lib()
+    assert lib.gcr_geometry_bytes(0) >= 0
+    g1, g2 = lib.gcr_geometry_bytes(1000), lib.gcr_geometry_bytes(2000)
+    assert 1000 * (48 + 24 + 1 + 4) <= g1 < g2
+    assert lib.gcr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 8
+    b0, b1 = lib.gcr_binning_bytes(0, 640, 448), lib.gcr_binning_bytes(1_000_000, 640, 448)
+    assert b1 >= 1_000_000 * 24 and b0 < b1
+    L = N.get_layout(5000, 640, 448, 123456)
+    offs = [L.geom_rec, L.geom_cov3D, L.geom_clamped, L.geom_tiles_touched, L.geom_block_sums,
+            L.geom_num_rendered, L.geom_total]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    assert L.geom_total == lib.gcr_geometry_bytes(5000)
+    assert L.img_total == lib.gcr_image_bytes(640, 448)
+    assert L.bin_total == lib.gcr_binning_bytes(123456, 640, 448)
+    # 1120 tiles -> 11 tile bits -> 43 key bits -> 6 radix passes -> result in half 0
+    assert L.bin_sorted == 0
+    assert N.get_layout(10, 16, 16, 10).bin_sorted == 1  # 1 tile -> 33 bits -> 5 passes
+
+
+def test_argument_errors_are_reported_without_touching_the_gpu():
+    lib = N.lib()
+    R = C.c_int64(-1)
+    cam = N.Camera(16, 16, 0.3, 0.3, 1.0, 0, 0, 0, None, None, None, None)
+    g = N.Gaussians(4, 0, None, None, None, None, None, None, None)
+    rc = lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), None, 0, None, C.byref(R), None)
+    assert rc == -1 and b"non-null" in lib.gcr_last_error()
+    with pytest.raises(RuntimeError, match="gcr_status -1"):
+        N.check(rc, "gcr_forward_preprocess")
+    buf = (C.c_float * 64)()
+    p = C.addressof(buf)
+    cam = N.Camera(16, 16, 0.3, 0.3, 1.0, 0, 0, 0, p, p, p, p)
+    # exactly one of SH / precomputed colour
+    g = N.Gaussians(4, 0, p, p, None, None, p, p, None)
+    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), None, 0, None, C.byref(R), None) == -1
+    assert b"exactly one of SHs" in lib.gcr_last_error()
+    # scale without rotation
+    g = N.Gaussians(4, 0, p, p, None, p, p, None, None)
+    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), None, 0, None, C.byref(R), None) == -1
+    assert b"scale/rotation" in lib.gcr_last_error()
+    # SH table too small for the requested degree
+    cam3 = N.Camera(16, 16, 0.3, 0.3, 1.0, 3, 0, 0, p, p, p, p)
+    g = N.Gaussians(4, 4, p, p, p, None, p, p, None)
+    assert lib.gcr_forward_preprocess(C.byref(cam3), C.byref(g), None, 0, None, C.byref(R), None) == -1
+    # geometry buffer too small -> -2, before any launch
+    g = N.Gaussians(4, 0, p, p, None, p, p, p, None)
+    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), p, 8, p, C.byref(R), None) == -2
+    # P == 0 short-circuits successfully (dgr/rasterize_points.cu:71)
+    g0 = N.Gaussians(0, 0, None, None, None, None, None, None, None)
+    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g0), None, 0, None, C.byref(R), None) == 0
+    assert R.value == 0
+    assert lib.gcr_mark_visible(-1, None, None, None, None, None) == -1
+    assert lib.gcr_set_option(b"no_such_option", 1) < 0

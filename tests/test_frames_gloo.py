@@ -1,0 +1,72 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise frame sharding, the final gather and
+the bucketed gradient all-reduce of gaussiancity_amd.frames (same code the RCCL runs use)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gaussiancity_amd import frames
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_frame(f):
+    return torch.full((3, 4, 5), float(f)) + torch.arange(60, dtype=torch.float32).reshape(3, 4, 5) / 100
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rendered = []
+
+        def render(f):
+            rendered.append(f)
+            return _fake_frame(f)
+
+        out = frames.render_sharded(render, 7)          # 7 frames on 2 ranks: ragged last round
+        ok_gather = sorted(out) == list(range(7)) and all(torch.equal(out[f], _fake_frame(f)) for f in out)
+        local_only = frames.render_sharded(_fake_frame, 7, gather=False)
+        # gradient exchange: three tensors, tiny buckets so that several messages are used
+        g = [torch.full((1000,), float(rank + 1)), torch.full((17, 3), float(10 * (rank + 1))),
+             torch.full((5,), float(-rank))]
+        nb = frames.allreduce_gradients(g, bucket_bytes=4096)
+        q.put((rank, rendered, ok_gather, sorted(local_only), nb, [float(t.reshape(-1)[0]) for t in g]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_sharding_and_gradient_allreduce_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5]        # round-robin ownership
+    assert res[0][2] and res[1][2]                                      # every rank has all frames
+    assert res[0][3] == [0, 2, 4, 6] and res[1][3] == [1, 3, 5]
+    assert res[0][4] == res[1][4] >= 2                                  # several buckets
+    want = [1.5, 15.0, -0.5]                                            # averages over the 2 ranks
+    assert np.allclose(res[0][5], want) and np.allclose(res[1][5], want)
+
+
+def test_single_process_paths():
+    assert frames.shard_frames(24, 3, 8) == [3, 11, 19]
+    assert frames.shard_frames(5, 7, 8) == []
+    out = frames.render_sharded(_fake_frame, 3, rank=0, world=1)
+    assert sorted(out) == [0, 1, 2]
+    assert frames.allreduce_gradients([torch.ones(3)]) == 0

@@ -1,0 +1,156 @@
+"""The oracle itself (not gpu): pinned against the independent float64 autograd formulation
+(oracle/dense_f64.py), against committed regression vectors, and on edge cases."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from oracle import dense_f64 as DF
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+D = torch.float64
+
+
+def _frame(O, rs, sc, mode="sh", cov3D=None):
+    kw = scenes.settings_kwargs(rs)
+    extra = dict(shs=sc["shs"]) if mode == "sh" else dict(colors_precomp=sc["colors_precomp"])
+    if cov3D is not None:
+        extra["cov3D_precomp"] = cov3D
+    else:
+        extra.update(scales=sc["scales"], rotations=sc["rotations"])
+    return O.Frame(**kw, means3D=sc["means3D"], opacities=sc["opacities"], **extra)
+
+
+def _dense(rs, sc, mode, dpix, cov3D=None):
+    t = lambda a, req=True: torch.tensor(np.asarray(a), dtype=D, requires_grad=req)  # noqa: E731
+    kw = scenes.settings_kwargs(rs)
+    P = sc["means3D"].shape[0]
+    leaves = dict(means3D=t(sc["means3D"]), means2D=t(np.zeros((P, 3))), opacities=t(sc["opacities"][:, 0]))
+    if mode == "sh":
+        leaves["shs"] = t(sc["shs"])
+    else:
+        leaves["colors_precomp"] = t(sc["colors_precomp"])
+    if cov3D is not None:
+        leaves["cov3D_precomp"] = t(cov3D)
+    else:
+        leaves["scales"], leaves["rotations"] = t(sc["scales"]), t(sc["rotations"])
+    img, radii = DF.render(img_h=rs.img_h, img_w=rs.img_w, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy,
+                           bg=t(kw["bg"], False), scale_modifier=rs.scale_modifier,
+                           view_matrix=t(kw["view_matrix"], False), proj_matrix=t(kw["proj_matrix"], False),
+                           sh_degree=rs.sh_degree, campos=t(kw["campos"], False), **leaves)
+    (img * torch.tensor(dpix, dtype=D)).sum().backward()
+    return img.detach().numpy(), radii.numpy(), {k: v.grad.numpy() for k, v in leaves.items()}
+
+
+CASES = [("sh3", 3, "sh", (0.2, 0.5, 0.1), 7), ("sh0", 0, "sh", (0.0, 0.0, 0.0), 8),
+         ("sh2", 2, "sh", (1.0, 1.0, 1.0), 9), ("colour", 0, "colour", (0.0, 0.3, 0.0), 10)]
+
+
+@pytest.mark.parametrize("name,deg,mode,bg,seed", CASES, ids=[c[0] for c in CASES])
+def test_oracle_matches_dense_float64(oracle_mod, name, deg, mode, bg, seed):
+    W, H, P = 44, 36, 120
+    rs = scenes.camera(W, H, pose_index=seed)._replace(sh_degree=deg, bg=torch.tensor(bg))
+    sc = scenes.blob_scene(P, seed, deg)
+    fr = _frame(oracle_mod, rs, sc, mode)
+    dpix = np.random.default_rng(seed).normal(size=(3, H, W)).astype(np.float32)
+    g = fr.backward(dpix)
+    img, radii, gd = _dense(rs, sc, mode, dpix)
+    assert (fr.n_contrib > 0).mean() > 0.5, "scene must actually cover the image"
+    np.testing.assert_array_equal(radii, fr.radii)
+    assert np.abs(img - fr.out_color).max() < 1e-4
+    pairs = [("means3D", "dL_dmean3D"), ("means2D", "dL_dmean2D"), ("opacities", "dL_dopacity"),
+             ("scales", "dL_dscale"), ("rotations", "dL_drot")]
+    pairs.append(("shs", "dL_dsh") if mode == "sh" else ("colors_precomp", "dL_dcolor"))
+    for kd, ko in pairs:
+        ref, got = gd[kd], g[ko].reshape(gd[kd].shape)
+        assert np.abs(ref - got).max() <= 2e-4 * max(1.0, np.abs(ref).max()), kd
+
+
+def test_oracle_precomputed_cov3d_matches_dense(oracle_mod):
+    W, H, P = 40, 40, 90
+    rs = scenes.camera(W, H)._replace(sh_degree=1)
+    sc = scenes.blob_scene(P, 3, 1)
+    cov = _frame(oracle_mod, rs, sc).cov3D[:P].copy()
+    fr = _frame(oracle_mod, rs, sc, cov3D=cov)
+    dpix = np.random.default_rng(0).normal(size=(3, H, W)).astype(np.float32)
+    g = fr.backward(dpix)
+    img, radii, gd = _dense(rs, sc, "sh", dpix, cov3D=cov)
+    assert np.abs(img - fr.out_color).max() < 1e-4
+    # the reference's dL_dcov3D counts each off-diagonal entry once per symmetric pair (x2)
+    ref = gd["cov3D_precomp"]
+    assert np.abs(ref - g["dL_dcov3D"]).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_oracle_regression_vectors(oracle_mod):
+    """Committed inputs + outputs of the oracle (self-generated pins: they detect drift of the
+    restatement, they are not reference outputs -- the reference cannot run here)."""
+    g = np.load(os.path.join(GOLD, "oracle_regression.npz"))
+    rs = scenes.camera(int(g["W"]), int(g["H"]), pose_index=int(g["pose"]))._replace(
+        sh_degree=3, bg=torch.from_numpy(g["bg"]))
+    sc = {k: g["sc_" + k] for k in ("means3D", "scales", "rotations", "opacities", "shs", "colors_precomp")}
+    fr = _frame(oracle_mod, rs, sc)
+    assert fr.R == int(g["R"])
+    np.testing.assert_array_equal(fr.radii, g["radii"])
+    np.testing.assert_array_equal(fr.point_list[:fr.R], g["point_list"])
+    np.testing.assert_array_equal(fr.n_contrib, g["n_contrib"])
+    assert np.array_equal(fr.out_color.view(np.uint32), g["out_color"].view(np.uint32))
+    gr = fr.backward(g["dpix"])
+    for k in ("dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot", "dL_dopacity", "dL_dmean2D"):
+        assert np.array_equal(gr[k].view(np.uint32), g["g_" + k].view(np.uint32)), k
+
+
+def test_expf_accuracy_and_exact_points(oracle_mod):
+    assert oracle_mod.expf(0.0) == 1.0
+    assert oracle_mod.expf(-100.0) == 0.0
+    xs = -np.random.default_rng(0).uniform(0, 20, 20000)
+    err = 0.0
+    for x in xs[:4000]:
+        x32 = np.float32(x)
+        ref = np.exp(np.float64(x32))
+        err = max(err, abs(oracle_mod.expf(float(x32)) - ref) / np.spacing(np.float32(ref)))
+    assert err < 1.01, "gcr_expf must stay within 1 ulp (got %.3f)" % err
+
+
+def test_higher_msb(oracle_mod):
+    for n, want in ((1, 1), (2, 2), (255, 8), (256, 9), (1120, 11), (2040, 11), (8160, 13), (32400, 15)):
+        assert oracle_mod.lib().orc_higher_msb(n) == want
+
+
+def test_edge_cases(oracle_mod):
+    W, H = 33, 17
+    rs = scenes.camera(W, H)._replace(bg=torch.tensor([0.1, 0.2, 0.3]))
+    sc = scenes.blob_scene(50, 1, 0)
+    # empty input
+    sc0 = {k: (v[:0] if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
+    fr0 = _frame(oracle_mod, rs, sc0, "colour")
+    assert fr0.R == 0 and np.allclose(fr0.out_color, np.array([0.1, 0.2, 0.3])[:, None, None])
+    # everything behind the near plane
+    sc1 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
+    sc1["means3D"][:, 2] += 1e4
+    fr1 = _frame(oracle_mod, rs, sc1, "colour")
+    assert fr1.R == 0 and np.all(fr1.radii == 0) and np.all(fr1.n_contrib == 0) and np.all(fr1.final_T == 1)
+    assert not oracle_mod.mark_visible(sc1["means3D"], rs.view_matrix.numpy(), rs.proj_matrix.numpy()).any()
+    g = fr1.backward(np.ones((3, H, W), np.float32))
+    assert all(np.all(v == 0) for v in g.values())
+    # single opaque Gaussian: saturation at alpha = 0.99 and T bookkeeping
+    sc2 = {k: (v[:1].copy() if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
+    sc2["opacities"][:] = 1.0
+    sc2["scales"][:] = 8.0
+    fr2 = _frame(oracle_mod, rs, sc2, "colour")
+    assert fr2.R > 0 and fr2.n_contrib.max() == 1
+    assert np.isclose(fr2.final_T.min(), 0.01, atol=1e-6)
+
+
+def test_sort_is_stable_for_equal_depth(oracle_mod):
+    W, H, P = 48, 32, 300
+    rs = scenes.camera(W, H)
+    sc = scenes.blob_scene(P, 2, 0)
+    sc["means3D"][:] = sc["means3D"][0]
+    fr = _frame(oracle_mod, rs, sc, "colour")
+    assert fr.R >= P
+    for t in range(fr.ranges.shape[0]):
+        a, b = fr.ranges[t]
+        seg = fr.point_list[a:b]
+        assert np.all(np.diff(seg.astype(np.int64)) > 0), "ties must keep ascending Gaussian index"
