@@ -54,14 +54,20 @@ class Layout(C.Structure):
     _fields_ = [
         ("geom_rec", C.c_size_t), ("geom_cov3D", C.c_size_t), ("geom_clamped", C.c_size_t),
         ("geom_tiles_touched", C.c_size_t), ("geom_block_sums", C.c_size_t),
+        ("geom_vis_list", C.c_size_t), ("geom_vis_count", C.c_size_t),
         ("geom_num_rendered", C.c_size_t), ("geom_total", C.c_size_t),
         ("img_final_T", C.c_size_t), ("img_n_contrib", C.c_size_t), ("img_ranges", C.c_size_t),
-        ("img_total", C.c_size_t),
+        ("img_tile_cursor", C.c_size_t), ("img_tile_table", C.c_size_t), ("img_total", C.c_size_t),
         ("bin_keys", C.c_size_t * 2), ("bin_vals", C.c_size_t * 2), ("bin_hist", C.c_size_t),
         ("bin_sorted", C.c_size_t), ("bin_total", C.c_size_t),
     ]
 
 
+class FrameInfo(C.Structure):
+    _fields_ = [("num_rendered", C.c_int64), ("max_tile_instances", C.c_int64)]
+
+
+ABI_VERSION = 2
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 _lib = None
@@ -98,12 +104,12 @@ def lib():
     L.gcr_get_layout.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(Layout)]
     L.gcr_forward_preprocess.restype = C.c_int
     L.gcr_forward_preprocess.argtypes = [C.POINTER(Camera), C.POINTER(Gaussians), C.c_void_p,
-                                         C.c_size_t, C.c_void_p, C.POINTER(C.c_int64),
-                                         C.c_void_p]
+                                         C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                         C.POINTER(FrameInfo), C.c_void_p]
     L.gcr_forward_render.restype = C.c_int
     L.gcr_forward_render.argtypes = [C.POINTER(Camera), C.POINTER(Gaussians), C.c_void_p,
                                      C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
-                                     C.c_int64, C.c_void_p, C.c_void_p]
+                                     C.POINTER(FrameInfo), C.c_void_p, C.c_void_p]
     L.gcr_backward.restype = C.c_int
     L.gcr_backward.argtypes = [C.POINTER(Camera), C.POINTER(Gaussians), C.c_void_p, C.c_void_p,
                                C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
@@ -119,7 +125,7 @@ def lib():
     L.gcr_set_option.argtypes = [C.c_char_p, C.c_int]
     L.gcr_get_stage_ms.restype = C.c_int
     L.gcr_get_stage_ms.argtypes = [C.POINTER(C.c_float), C.c_int]
-    if L.gcr_abi_version() != 1:
+    if L.gcr_abi_version() != ABI_VERSION:
         raise RuntimeError("libgcr_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -13,6 +13,8 @@ namespace {
 thread_local std::string g_err;
 std::atomic<int> g_fast_exp{0};
 std::atomic<int> g_timing{0};
+std::atomic<int> g_force_radix{0};
+std::atomic<int> g_force_global_cursor{0};
 
 enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PRE_BWD, ST_COUNT };
 
@@ -92,7 +94,9 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   L->geom_clamped = o;        o = align_up(o + p);
   L->geom_tiles_touched = o;  o = align_up(o + p * sizeof(uint32_t));
   L->geom_block_sums = o;     o = align_up(o + (nblk + 1) * sizeof(uint32_t));
-  L->geom_num_rendered = o;   o = align_up(o + sizeof(uint64_t));
+  L->geom_vis_list = o;       o = align_up(o + p * sizeof(uint32_t));
+  L->geom_vis_count = o;      o = align_up(o + (nblk + 1) * sizeof(uint32_t));
+  L->geom_num_rendered = o;   o = align_up(o + 2 * sizeof(uint64_t));  // {R, longest tile list}
   L->geom_total = o;
 
   const size_t npix = (size_t)(W > 0 ? W : 0) * (size_t)(H > 0 ? H : 0);
@@ -101,7 +105,13 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   o = 0;
   L->img_final_T = o;    o = align_up(o + npix * sizeof(float));
   L->img_n_contrib = o;  o = align_up(o + npix * sizeof(uint32_t));
-  L->img_ranges = o;     o = align_up(o + T * 2 * sizeof(uint32_t));
+  L->img_ranges = o;       o = align_up(o + T * 2 * sizeof(uint32_t));
+  L->img_tile_cursor = o;  o = align_up(o + T * GCR_CURSOR_STRIDE * sizeof(uint32_t));
+  {
+    int G = 1;
+    const int ng = gcr_tile_table_groups((int)T, 2048, &G);  // 2048 = max K1 blocks -> max groups
+    L->img_tile_table = o;   o = align_up(o + (size_t)ng * T * sizeof(uint32_t));
+  }
   L->img_total = o;
 
   const size_t r = (size_t)(R > 0 ? R : 0);
@@ -173,6 +183,8 @@ int gcr_set_option(const char* name, int value) {
   if (!name) return -1;
   if (!strcmp(name, "fast_exp")) return g_fast_exp.exchange(value);
   if (!strcmp(name, "timing")) return g_timing.exchange(value);
+  if (!strcmp(name, "force_radix")) return g_force_radix.exchange(value);
+  if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.exchange(value);
   return -1;
 }
 
@@ -189,23 +201,26 @@ int gcr_get_stage_ms(float* ms_out, int capacity) {
 }
 
 int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* geom,
-                           size_t geom_bytes, int32_t* radii, int64_t* num_rendered_host,
-                           void* hip_stream) {
+                           size_t geom_bytes, void* img, size_t img_bytes, int32_t* radii,
+                           gcr_frame_info* info_host, void* hip_stream) {
   if (int rc = check_inputs(cam, g)) return rc;
-  if (!num_rendered_host) return fail(GCR_ERR_INVALID_ARGUMENT, "num_rendered_host is null");
-  *num_rendered_host = 0;
+  if (!info_host) return fail(GCR_ERR_INVALID_ARGUMENT, "info_host is null");
+  info_host->num_rendered = 0;
+  info_host->max_tile_instances = 0;
   if (g->P == 0) return 0;  // dgr/rasterize_points.cu:71
-  if (!geom || !radii) return fail(GCR_ERR_INVALID_ARGUMENT, "geom/radii must be non-null");
+  if (!geom || !radii || !img) return fail(GCR_ERR_INVALID_ARGUMENT, "geom/img/radii must be non-null");
   gcr_layout L;
   compute_layout(g->P, cam->img_w, cam->img_h, 0, &L);
   if (geom_bytes < L.geom_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "geometry buffer too small");
+  if (img_bytes < L.img_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "image buffer too small");
   hipStream_t s = (hipStream_t)hip_stream;
-  char* gb = (char*)geom;
+  char *gb = (char*)geom, *ib = (char*)img;
 
   GcrPreprocessArgs a;
   a.P = g->P; a.D = cam->sh_degree; a.M = g->M; a.W = cam->img_w; a.H = cam->img_h;
   a.gx = (cam->img_w + GCR_BLOCK_X - 1) / GCR_BLOCK_X;
   a.gy = (cam->img_h + GCR_BLOCK_Y - 1) / GCR_BLOCK_Y;
+  const int T = a.gx * a.gy;
   a.tanfovx = cam->tanfovx; a.tanfovy = cam->tanfovy;
   a.focal_y = cam->img_h / (2.0f * cam->tanfovy);  // cr/rasterizer_impl.cu:189-190
   a.focal_x = cam->img_w / (2.0f * cam->tanfovx);
@@ -218,33 +233,56 @@ int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* 
   a.rec = (float4*)(gb + L.geom_rec);
   a.cov3D = (float*)(gb + L.geom_cov3D);
   a.clamped = (uint8_t*)(gb + L.geom_clamped);
-  a.tiles_touched = (uint32_t*)(gb + L.geom_tiles_touched);
-  a.block_sums = (uint32_t*)(gb + L.geom_block_sums);
-  unsigned long long* total = (unsigned long long*)(gb + L.geom_num_rendered);
-  {
-    StageTimer t(s, ST_PRE);
-    HIP_TRY(gcr_launch_preprocess(a, s), "preprocess");
-  }
-  if (int rc = debug_sync(cam, s, "preprocess")) return rc;
-  {
+  a.tile_count = (uint32_t*)(ib + L.img_tile_cursor);
+  a.vis_list = (uint32_t*)(gb + L.geom_vis_list);
+  a.vis_count = (uint32_t*)(gb + L.geom_vis_count);
+  gcr_preprocess_grid(g->P, &a.nblocks, &a.chunk);
+  unsigned long long* total_and_max = (unsigned long long*)(gb + L.geom_num_rendered);
+  int G = 1;
+  const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, a.nblocks, &G);
+  uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
+  uint32_t* ranges = (uint32_t*)(ib + L.img_ranges);
+  if (NG > 0) {
+    // default: per-tile counts are built in LDS tables after K1 (no global atomics)
+    a.tile_count = nullptr;
+    {
+      StageTimer t(s, ST_PRE);
+      HIP_TRY(gcr_launch_preprocess(a, s), "preprocess");
+    }
+    if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
-    HIP_TRY(gcr_launch_scan_block_sums(a.block_sums, (g->P + 255) / 256, total, s), "scan");
+    HIP_TRY(gcr_launch_tile_count(T, a.gx, NG, G, a.nblocks, a.chunk, a.vis_list, a.vis_count, a.rec,
+                                  (uint32_t*)(ib + L.img_tile_table), cursor, s),
+            "tile count");
+    HIP_TRY(gcr_launch_scan_tiles(cursor, 1, ranges, T, total_and_max, s), "tile scan");
+  } else {
+    {
+      StageTimer t(s, ST_PRE);
+      HIP_TRY(hipMemsetAsync(a.tile_count, 0, sizeof(uint32_t) * GCR_CURSOR_STRIDE * (size_t)T, s), "tile count memset");
+      HIP_TRY(gcr_launch_preprocess(a, s), "preprocess");
+    }
+    if (int rc = debug_sync(cam, s, "preprocess")) return rc;
+    StageTimer t(s, ST_SCAN);
+    HIP_TRY(gcr_launch_scan_tiles(cursor, GCR_CURSOR_STRIDE, ranges, T, total_and_max, s), "tile scan");
   }
-  unsigned long long r = 0;
-  HIP_TRY(hipMemcpyAsync(&r, total, sizeof(r), hipMemcpyDeviceToHost, s), "num_rendered copy");
+  unsigned long long r[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(r, total_and_max, sizeof(r), hipMemcpyDeviceToHost, s), "num_rendered copy");
   HIP_TRY(hipStreamSynchronize(s), "num_rendered sync");  // cr/rasterizer_impl.cu:236-238
-  if (r > 0x7fffffffull)
+  if (r[0] > 0x7fffffffull)
     return fail(GCR_ERR_OVERFLOW, "num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)");
-  *num_rendered_host = (int64_t)r;
+  info_host->num_rendered = (int64_t)r[0];
+  info_host->max_tile_instances = (int64_t)r[1];
   return 0;
 }
 
 int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes,
-                       void* binning, size_t binning_bytes, void* img, size_t img_bytes, int64_t R,
-                       float* out_color, void* hip_stream) {
+                       void* binning, size_t binning_bytes, void* img, size_t img_bytes,
+                       const gcr_frame_info* info, float* out_color, void* hip_stream) {
   if (int rc = check_inputs(cam, g)) return rc;
   if (g->P == 0) return 0;
-  if (!geom || !img || !out_color) return fail(GCR_ERR_INVALID_ARGUMENT, "geom/img/out_color must be non-null");
+  if (!geom || !img || !out_color || !info)
+    return fail(GCR_ERR_INVALID_ARGUMENT, "geom/img/out_color/info must be non-null");
+  const int64_t R = info->num_rendered;
   if (R < 0 || R > 0x7fffffffll) return fail(GCR_ERR_INVALID_ARGUMENT, "R out of range");
   if (R > 0 && !binning) return fail(GCR_ERR_INVALID_ARGUMENT, "binning buffer is null");
   gcr_layout L;
@@ -258,37 +296,72 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   const int gy = (cam->img_h + GCR_BLOCK_Y - 1) / GCR_BLOCK_Y;
   const int T = gx * gy;
   const float4* rec = (const float4*)(gb + L.geom_rec);
+  uint32_t* tiles_touched = (uint32_t*)(gb + L.geom_tiles_touched);
+  const uint32_t* vis_list = (const uint32_t*)(gb + L.geom_vis_list);
+  const uint32_t* vis_count = (const uint32_t*)(gb + L.geom_vis_count);
+  int nblocks, chunk;
+  gcr_preprocess_grid(g->P, &nblocks, &chunk);
   uint64_t* k0 = (uint64_t*)(bb + L.bin_keys[0]);
   uint64_t* k1 = (uint64_t*)(bb + L.bin_keys[1]);
   uint32_t* v0 = (uint32_t*)(bb + L.bin_vals[0]);
   uint32_t* v1 = (uint32_t*)(bb + L.bin_vals[1]);
-  uint32_t* ranges = (uint32_t*)(ib + L.img_ranges);
-  int sorted_half = (int)L.bin_sorted;
+  uint32_t* ranges = (uint32_t*)(ib + L.img_ranges);  // already valid: written by k_scan_tiles
+  const int sorted_half = (int)L.bin_sorted;
+  uint32_t* list = sorted_half ? v1 : v0;
   if (R > 0) {
-    {
-      StageTimer t(s, ST_EMIT);
-      HIP_TRY(gcr_launch_emit(g->P, (const uint32_t*)(gb + L.geom_tiles_touched),
-                              (const uint32_t*)(gb + L.geom_block_sums), rec, gx, k0, v0, s),
-              "emit");
+    const bool lds_sort = !g_force_radix.load() && info->max_tile_instances <= gcr_tile_sort_capacity();
+    if (lds_sort) {
+      // counting-sort binning: scatter into tile segments, then sort every segment in LDS
+      {
+        StageTimer t(s, ST_EMIT);
+        int G = 1;
+        const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, nblocks, &G);
+        if (NG > 0)
+          HIP_TRY(gcr_launch_tile_scatter(T, gx, NG, G, nblocks, chunk, vis_list, vis_count, rec,
+                                          (uint32_t*)(ib + L.img_tile_table), ranges, k0, s),
+                  "tile scatter");
+        else
+          HIP_TRY(gcr_launch_scatter_instances(nblocks, chunk, vis_list, vis_count, rec, gx,
+                                               (uint32_t*)(ib + L.img_tile_cursor), k0, s),
+                  "scatter instances");
+      }
+      if (int rc = debug_sync(cam, s, "scatter instances")) return rc;
+      {
+        StageTimer t(s, ST_SORT);
+        HIP_TRY(gcr_launch_tile_sort(ranges, T, k0, list, info->max_tile_instances, s), "tile sort");
+      }
+      if (int rc = debug_sync(cam, s, "tile sort")) return rc;
+    } else {
+      // fallback (a tile list longer than the LDS capacity): the reference's own scheme --
+      // emit tile|depth keys in index order, stable global radix sort, boundary scan.
+      int half = sorted_half;
+      {
+        StageTimer t(s, ST_EMIT);
+        uint32_t* block_sums = (uint32_t*)(gb + L.geom_block_sums);
+        unsigned long long* scratch_total = (unsigned long long*)(bb + L.bin_hist);
+        HIP_TRY(gcr_launch_tiles_touched(g->P, nblocks, chunk, vis_list, vis_count, rec, tiles_touched, block_sums, s),
+                "tiles touched");
+        HIP_TRY(gcr_launch_scan_block_sums(block_sums, (g->P + 255) / 256, scratch_total, s), "scan");
+        HIP_TRY(gcr_launch_emit(g->P, tiles_touched, block_sums, rec, gx, k0, v0, s), "emit");
+      }
+      if (int rc = debug_sync(cam, s, "emit")) return rc;
+      {
+        StageTimer t(s, ST_SORT);
+        const int end_bit = 32 + (int)gcr_higher_msb((uint32_t)T);  // cr/rasterizer_impl.cu:252
+        HIP_TRY(gcr_launch_sort(k0, v0, k1, v1, R, end_bit, (uint32_t*)(bb + L.bin_hist), &half, s), "sort");
+      }
+      if (int rc = debug_sync(cam, s, "sort")) return rc;
+      {
+        StageTimer t(s, ST_RANGES);
+        HIP_TRY(gcr_launch_tile_ranges(half ? k1 : k0, R, ranges, T, s), "tile ranges");
+      }
+      if (int rc = debug_sync(cam, s, "tile ranges")) return rc;
     }
-    if (int rc = debug_sync(cam, s, "emit")) return rc;
-    {
-      StageTimer t(s, ST_SORT);
-      const int end_bit = 32 + (int)gcr_higher_msb((uint32_t)T);  // cr/rasterizer_impl.cu:252
-      HIP_TRY(gcr_launch_sort(k0, v0, k1, v1, R, end_bit, (uint32_t*)(bb + L.bin_hist), &sorted_half, s),
-              "sort");
-    }
-    if (int rc = debug_sync(cam, s, "sort")) return rc;
   }
-  {
-    StageTimer t(s, ST_RANGES);
-    HIP_TRY(gcr_launch_tile_ranges(sorted_half ? k1 : k0, R, ranges, T, s), "tile ranges");
-  }
-  if (int rc = debug_sync(cam, s, "tile ranges")) return rc;
   GcrBlendArgs b;
   memset(&b, 0, sizeof(b));
   b.ranges = ranges;
-  b.list = sorted_half ? v1 : v0;
+  b.list = list;
   b.rec = rec;
   b.W = cam->img_w; b.H = cam->img_h; b.gx = gx; b.gy = gy;
   b.bg = cam->bg;
@@ -355,6 +428,9 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   a.view = cam->view_matrix; a.proj = cam->proj_matrix; a.campos = cam->campos;
   a.radii = radii;
   a.clamped = (const uint8_t*)(gb + L.geom_clamped);
+  a.vis_list = (const uint32_t*)(gb + L.geom_vis_list);
+  a.vis_count = (const uint32_t*)(gb + L.geom_vis_count);
+  gcr_preprocess_grid(g->P, &a.nblocks, &a.chunk);
   a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dconic = gr->dL_dconic; a.dL_dcolor = gr->dL_dcolors;
   a.dL_dmean3D = gr->dL_dmeans3D; a.dL_dcov3D = gr->dL_dcov3D; a.dL_dsh = gr->dL_dsh;
   a.dL_dscale = gr->dL_dscales; a.dL_drot = gr->dL_drotations;
@@ -390,14 +466,14 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void* geometry_user
   const size_t ibytes = gcr_image_bytes(cam->img_w, cam->img_h);
   void* img = image_buffer(image_user, ibytes);
   if (!img) return fail(GCR_ERR_ALLOC, "image resize callback returned null");
-  int64_t R = 0;
-  if (int rc = gcr_forward_preprocess(cam, g, geom, gbytes, radii, &R, hip_stream)) return rc;
-  const size_t bbytes = gcr_binning_bytes(R, cam->img_w, cam->img_h);
+  gcr_frame_info info;
+  if (int rc = gcr_forward_preprocess(cam, g, geom, gbytes, img, ibytes, radii, &info, hip_stream)) return rc;
+  const size_t bbytes = gcr_binning_bytes(info.num_rendered, cam->img_w, cam->img_h);
   void* bin = binning_buffer(binning_user, bbytes);
-  if (!bin && R > 0) return fail(GCR_ERR_ALLOC, "binning resize callback returned null");
-  if (int rc = gcr_forward_render(cam, g, geom, gbytes, bin, bbytes, img, ibytes, R, out_color, hip_stream))
+  if (!bin && info.num_rendered > 0) return fail(GCR_ERR_ALLOC, "binning resize callback returned null");
+  if (int rc = gcr_forward_render(cam, g, geom, gbytes, bin, bbytes, img, ibytes, &info, out_color, hip_stream))
     return rc;
-  return R;
+  return info.num_rendered;
 }
 
 }  // extern "C"

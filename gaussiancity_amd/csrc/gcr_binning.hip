@@ -41,7 +41,194 @@ __global__ __launch_bounds__(256) void k_emit(int P, const uint32_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------- K3'/K4' (fast path)
+// Counting-sort binning without global atomics.  Device-scope atomics on MI355X resolve at the
+// memory side (the eight XCD L2s are not coherent): fire-and-forget adds are cheap, but RETURNING
+// adds -- what a scatter needs to claim a slot -- measured ~13 G/s, which made a global-cursor
+// scatter as slow as the radix sort it was meant to replace.  So slots are claimed in LDS:
+//   A'  k_tile_table<false>: K1's per-block survivor lists are grouped into NG <= 512 groups;
+//       workgroup g counts its instances per tile in an LDS table (ds_add) and stores the row
+//       to table[g][0..T).
+//   B'  k_table_colscan: exclusive prefix down every tile column (base[g][t] = instances of
+//       tile t owned by groups < g) and the tile totals; k_scan_tiles (gcr_preprocess.hip)
+//       turns the totals into tile ranges, num_rendered and the longest list.
+//   C'  k_tile_table<true>: workgroup g loads range[t].start + base[g][t] into LDS cursors and
+//       claims slots with LDS returning atomics; the (depth<<32|index) key goes straight to its
+//       final tile segment.
+//   D'  k_tile_sort: bitonic sort of every tile segment in LDS.
+// The slot order inside a tile is arbitrary but the key is unique, so the sorted list is
+// deterministic: positive-float depth bits ascending, ties in ascending Gaussian index -- the
+// order the reference gets from its stable radix sort on tile<<32|depth over instances emitted
+// in index order (cr/rasterizer_impl.cu:66-99,255-260).
+constexpr int TT_THREADS = 512;
+constexpr int TT_MAX_GROUP = 64;  // K1 blocks per group (host guarantees G <= this)
+
+template <bool SCATTER>
+__global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G, int nblocks_k1, int chunk,
+                                                           const uint32_t* __restrict__ vis_list,
+                                                           const uint32_t* __restrict__ vis_count,
+                                                           const float4* __restrict__ rec,
+                                                           uint32_t* __restrict__ table,
+                                                           const uint32_t* __restrict__ ranges,
+                                                           uint64_t* __restrict__ pairs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(gcr_smem);  // [T]
+  __shared__ uint32_t pre[TT_MAX_GROUP + 1];              // prefix of the group's list lengths
+  const int tid = threadIdx.x;
+  uint32_t* __restrict__ row = table + (size_t)blockIdx.x * T;
+  for (int t = tid; t < T; t += TT_THREADS) cnt[t] = SCATTER ? ranges[2 * t] + row[t] : 0u;
+  const int kb0 = blockIdx.x * G;
+  const int kbn = min(G, nblocks_k1 - kb0);
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int k = 0; k < kbn; k++) {
+      pre[k] = run;
+      run += vis_count[kb0 + k];
+    }
+    pre[kbn] = run;
+  }
+  __syncthreads();
+  const uint32_t total = pre[kbn];
+  for (uint32_t f = tid; f < total; f += TT_THREADS) {
+    int k = 0;
+    while (k + 1 < kbn && pre[k + 1] <= f) k++;
+    const uint32_t idx = vis_list[(size_t)(kb0 + k) * chunk + (f - pre[k])];
+    const float4 q2 = rec[(size_t)idx * GCR_REC_QUADS + 2];
+    const uint32_t rx = __float_as_uint(q2.z), ry = __float_as_uint(q2.w);
+    const uint32_t minx = rx & 0xffffu, maxx = rx >> 16, miny = ry & 0xffffu, maxy = ry >> 16;
+    const uint64_t key = ((uint64_t)__float_as_uint(q2.y) << 32) | idx;
+    for (uint32_t y = miny; y < maxy; y++)
+      for (uint32_t x = minx; x < maxx; x++) {
+        const uint32_t t = y * (uint32_t)gx + x;
+        if (SCATTER) {
+          const uint32_t pos = atomicAdd(&cnt[t], 1u);  // ds_add_rtn_u32
+          pairs[pos] = key;
+        } else {
+          atomicAdd(&cnt[t], 1u);  // ds_add_u32
+        }
+      }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (int t = tid; t < T; t += TT_THREADS) row[t] = cnt[t];
+  }
+}
+
+// table[g][t] (g < NG <= 512) -> exclusive prefix over g in place; totals[t] = column sum.
+// Workgroup = 64 tiles x 16 row groups; every thread keeps its <= 32 rows in registers, so the
+// column is read exactly once with all loads in flight.
+__global__ __launch_bounds__(1024) void k_table_colscan(uint32_t* __restrict__ table, int NG, int T,
+                                                        uint32_t* __restrict__ totals) {
+  __shared__ uint32_t part[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  const int rpg = (NG + 15) / 16;  // rows per row-group, <= 32
+  const int r0 = grp * rpg;
+  uint32_t v[32];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int r = 0; r < 32; r++) {
+    const int g = r0 + r;
+    v[r] = (r < rpg && g < NG && t < T) ? table[(size_t)g * T + t] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < 32; r++) sum += v[r];
+  part[grp][lane] = sum;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const uint32_t p = part[k][lane];
+    if (k < grp) before += p;
+    all += p;
+  }
+  if (t < T) {
+    uint32_t run = before;
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+      const int g = r0 + r;
+      if (r < rpg && g < NG) {
+        table[(size_t)g * T + t] = run;
+        run += v[r];
+      }
+    }
+    if (grp == 0) totals[t] = all;
+  }
+}
+
+// Global-cursor variant of the scatter, used only when the tile table does not fit in LDS
+// (T * 4 B > 160 KiB, i.e. images beyond ~8K x 5K): one returning device-scope atomic per instance.
+__global__ __launch_bounds__(256) void k_scatter_instances(int chunk, const uint32_t* __restrict__ vis_list,
+                                                           const uint32_t* __restrict__ vis_count,
+                                                           const float4* __restrict__ rec, int gx,
+                                                           uint32_t* __restrict__ cursor,
+                                                           uint64_t* __restrict__ pairs) {
+  const uint32_t nvis = vis_count[blockIdx.x];
+  const uint32_t* __restrict__ my_list = vis_list + (size_t)blockIdx.x * chunk;
+  for (uint32_t it = threadIdx.x; it < nvis; it += 256) {
+    const int idx = (int)my_list[it];
+    const float4 q2 = rec[(size_t)idx * GCR_REC_QUADS + 2];
+    const uint64_t key = ((uint64_t)__float_as_uint(q2.y) << 32) | (uint32_t)idx;
+    const uint32_t rx = __float_as_uint(q2.z), ry = __float_as_uint(q2.w);
+    const uint32_t minx = rx & 0xffffu, maxx = rx >> 16, miny = ry & 0xffffu, maxy = ry >> 16;
+    const uint32_t w = maxx - minx, n = w * (maxy - miny);
+    for (uint32_t k0 = 0; k0 < n; k0 += 8) {
+      uint32_t pos[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++) {
+        const uint32_t k = k0 + u;
+        if (k < n) {
+          const uint32_t t = (miny + k / w) * (uint32_t)gx + minx + k % w;
+          pos[u] = atomicAdd(&cursor[(size_t)t * GCR_CURSOR_STRIDE], 1u);
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++)
+        if (k0 + u < n) pairs[pos[u]] = key;
+    }
+  }
+}
+
+// One workgroup per tile: bitonic sort of the tile's n <= capacity keys in LDS (padded to a
+// power of two with ~0), then the Gaussian indices (low 32 bits) go to the sorted list.
+__global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ ranges,
+                                                   const uint64_t* __restrict__ pairs,
+                                                   uint32_t* __restrict__ list) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
+  uint64_t* s = reinterpret_cast<uint64_t*>(gcr_smem);
+  const int tid = threadIdx.x;
+  const uint32_t r0 = ranges[2 * blockIdx.x], r1 = ranges[2 * blockIdx.x + 1];
+  const int n = (int)(r1 - r0);
+  if (n <= 0) return;
+  if (n == 1) {
+    if (tid == 0) list[r0] = (uint32_t)pairs[r0];
+    return;
+  }
+  int N2 = 2;
+  while (N2 < n) N2 <<= 1;
+  for (int i = tid; i < N2; i += 256) s[i] = i < n ? pairs[r0 + i] : ~0ull;
+  __syncthreads();
+  const int half = N2 >> 1;
+  for (int k = 2; k <= N2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < half; i += 256) {
+        const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int b = a | j;
+        const uint64_t x = s[a], y = s[b];
+        const bool ascending = (a & k) == 0;
+        if ((x > y) == ascending) {
+          s[a] = y;
+          s[b] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n; i += 256) list[r0 + i] = (uint32_t)s[i];
+}
+
 // ------------------------------------------------------------------------------------- K4
+// (fallback path, used when a tile list exceeds the LDS sort capacity or "force_radix" is set)
 // Stable least-significant-digit radix sort, 8-bit digits (replaces
 // cub::DeviceRadixSort::SortPairs at cr/rasterizer_impl.cu:255-260; stability is what makes
 // equal-depth ties resolve in ascending Gaussian index, which the blend order depends on).
@@ -176,6 +363,108 @@ hipError_t gcr_launch_emit(int P, const uint32_t* tiles_touched, const uint32_t*
                            hipStream_t s) {
   if (P <= 0) return hipSuccess;
   k_emit<<<(P + 255) / 256, 256, 0, s>>>(P, tiles_touched, block_offsets, rec, gx, keys, vals);
+  return hipGetLastError();
+}
+
+// Geometry of the tile-table path: NG groups of G consecutive K1 blocks; 0 if the table does
+// not fit in LDS.
+int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out) {
+  const size_t lds = (size_t)T * sizeof(uint32_t);
+  if (lds > 150 * 1024) return 0;
+  const int per_cu = lds > 64 * 1024 ? 1 : 2;
+  int ng = 256 * per_cu;
+  if (ng > nblocks_k1) ng = nblocks_k1;
+  if (ng < 1) ng = 1;
+  int G = (nblocks_k1 + ng - 1) / ng;
+  if (G > TT_MAX_GROUP) return 0;
+  *G_out = G;
+  return (nblocks_k1 + G - 1) / G;
+}
+
+static hipError_t tile_table_attr() {
+  static hipError_t done = [] {
+    hipError_t e = hipFuncSetAttribute((const void*)k_tile_table<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_tile_table<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+  }();
+  return done;
+}
+
+hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
+                                 const uint32_t* vis_count, const float4* rec, uint32_t* table,
+                                 uint32_t* totals, hipStream_t s) {
+  hipError_t e = tile_table_attr();
+  if (e != hipSuccess) return e;
+  k_tile_table<false><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(T, gx, G, nblocks_k1, chunk, vis_list,
+                                                                         vis_count, rec, table, nullptr, nullptr);
+  k_table_colscan<<<(T + 63) / 64, 1024, 0, s>>>(table, NG, T, totals);
+  return hipGetLastError();
+}
+
+hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
+                                   const uint32_t* vis_count, const float4* rec, uint32_t* table,
+                                   const uint32_t* ranges, uint64_t* pairs, hipStream_t s) {
+  hipError_t e = tile_table_attr();
+  if (e != hipSuccess) return e;
+  k_tile_table<true><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(T, gx, G, nblocks_k1, chunk, vis_list,
+                                                                        vis_count, rec, table, ranges, pairs);
+  return hipGetLastError();
+}
+
+hipError_t gcr_launch_scatter_instances(int nblocks, int chunk, const uint32_t* vis_list,
+                                        const uint32_t* vis_count, const float4* rec, int gx,
+                                        uint32_t* tile_cursor, uint64_t* pairs, hipStream_t s) {
+  if (nblocks <= 0) return hipSuccess;
+  k_scatter_instances<<<nblocks, 256, 0, s>>>(chunk, vis_list, vis_count, rec, gx, tile_cursor, pairs);
+  return hipGetLastError();
+}
+
+// fallback only: tiles touched per Gaussian (0 if culled; array zeroed first) from K1's visible
+// lists, then per-256 block sums in index order for k_emit.
+__global__ __launch_bounds__(256) void k_fill_tiles_touched(int chunk, const uint32_t* __restrict__ vis_list,
+                                                            const uint32_t* __restrict__ vis_count,
+                                                            const float4* __restrict__ rec,
+                                                            uint32_t* __restrict__ tiles_touched) {
+  const uint32_t nvis = vis_count[blockIdx.x];
+  const uint32_t* __restrict__ my_list = vis_list + (size_t)blockIdx.x * chunk;
+  for (uint32_t it = threadIdx.x; it < nvis; it += 256) {
+    const uint32_t idx = my_list[it];
+    const float4 q2 = rec[(size_t)idx * GCR_REC_QUADS + 2];
+    const uint32_t rx = __float_as_uint(q2.z), ry = __float_as_uint(q2.w);
+    tiles_touched[idx] = ((rx >> 16) - (rx & 0xffffu)) * ((ry >> 16) - (ry & 0xffffu));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_block_sums(int P, const uint32_t* __restrict__ tiles_touched,
+                                                    uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t wsum[4];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t t = idx < P ? tiles_touched[idx] : 0u;
+  const uint32_t ws = gcr_wave_sum_u32(t);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+hipError_t gcr_launch_tiles_touched(int P, int nblocks, int chunk, const uint32_t* vis_list,
+                                    const uint32_t* vis_count, const float4* rec, uint32_t* tiles_touched,
+                                    uint32_t* block_sums, hipStream_t s) {
+  if (P <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(tiles_touched, 0, sizeof(uint32_t) * (size_t)P, s);
+  if (e != hipSuccess) return e;
+  k_fill_tiles_touched<<<nblocks, 256, 0, s>>>(chunk, vis_list, vis_count, rec, tiles_touched);
+  k_block_sums<<<(P + 255) / 256, 256, 0, s>>>(P, tiles_touched, block_sums);
+  return hipGetLastError();
+}
+
+int gcr_tile_sort_capacity(void) { return 4096; }  // 32 KiB of LDS per workgroup at most
+
+hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, const uint64_t* pairs, uint32_t* list,
+                                int64_t max_tile_instances, hipStream_t s) {
+  if (T <= 0) return hipSuccess;
+  size_t n2 = 2;
+  while ((int64_t)n2 < max_tile_instances) n2 <<= 1;
+  k_tile_sort<<<T, 256, n2 * sizeof(uint64_t), s>>>(ranges, pairs, list);
   return hipGetLastError();
 }
 

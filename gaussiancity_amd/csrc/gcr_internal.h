@@ -11,6 +11,10 @@
 //   q2 = (b, depth, rect_x, rect_y) with rect_* = min | max << 16 (tile units, as uint bits)
 #define GCR_REC_QUADS 3
 
+// Per-tile atomic counters are padded to one per 128-byte line: device-scope atomics to the
+// same line serialise (measured: C2's 1120 unpadded counters made K1 4.6x slower).
+#define GCR_CURSOR_STRIDE 32
+
 struct GcrPreprocessArgs {
   int P, D, M, W, H, gx, gy;
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
@@ -20,9 +24,25 @@ struct GcrPreprocessArgs {
   float4* rec;
   float* cov3D;
   uint8_t* clamped;
-  uint32_t* tiles_touched;
-  uint32_t* block_sums;
+  uint32_t* tile_count;  // [T * GCR_CURSOR_STRIDE] per-tile instance counts (zeroed before K1)
+  uint32_t* vis_list;    // [P] block b's survivors at [b*chunk, b*chunk + vis_count[b])
+  uint32_t* vis_count;   // [nblocks]
+  int nblocks, chunk;    // persistent grid: block b owns Gaussians [b*chunk, (b+1)*chunk)
 };
+
+// Persistent-grid geometry of K1 (also used by the kernels that walk its visible lists).
+static inline void gcr_preprocess_grid(int P, int* nblocks, int* chunk) {
+  const int max_blocks = 2048;  // 8 workgroups per CU x 256 CUs
+  int nb = (P + 255) / 256;
+  if (nb > max_blocks) nb = max_blocks;
+  if (nb < 1) nb = 1;
+  long long c = ((long long)P + nb - 1) / nb;
+  c = (c + 255) / 256 * 256;
+  if (c < 256) c = 256;
+  *chunk = (int)c;
+  *nblocks = (int)(((long long)P + c - 1) / c);
+  if (*nblocks < 1) *nblocks = 1;
+}
 
 struct GcrPreprocessBwdArgs {
   int P, D, M, W, H;
@@ -31,6 +51,8 @@ struct GcrPreprocessBwdArgs {
   const float *view, *proj, *campos;
   const int32_t* radii;
   const uint8_t* clamped;
+  const uint32_t *vis_list, *vis_count;  // K1's per-block survivor lists
+  int nblocks, chunk;
   const float *dL_dmean2D, *dL_dconic, *dL_dcolor;
   float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 };
@@ -54,9 +76,29 @@ hipError_t gcr_launch_mark_visible(int P, const float* means3D, const float* vie
 hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, hipStream_t s);
 hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long long* total,
                                       hipStream_t s);
+// fallback binning: per-Gaussian tile counts from radii + record rect, then emit in index order
+hipError_t gcr_launch_tiles_touched(int P, int nblocks, int chunk, const uint32_t* vis_list,
+                                    const uint32_t* vis_count, const float4* rec, uint32_t* tiles_touched,
+                                    uint32_t* block_sums, hipStream_t s);
 hipError_t gcr_launch_emit(int P, const uint32_t* tiles_touched, const uint32_t* block_offsets,
                            const float4* rec, int gx, uint64_t* keys, uint32_t* vals,
                            hipStream_t s);
+// Fast binning path: tile counts -> ranges/cursors (+ total, max), scatter, per-tile LDS sort.
+hipError_t gcr_launch_scan_tiles(uint32_t* tile_cursor, int stride, uint32_t* ranges, int T,
+                                 unsigned long long* total_and_max, hipStream_t s);
+int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out);
+hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
+                                 const uint32_t* vis_count, const float4* rec, uint32_t* table,
+                                 uint32_t* totals, hipStream_t s);
+hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
+                                   const uint32_t* vis_count, const float4* rec, uint32_t* table,
+                                   const uint32_t* ranges, uint64_t* pairs, hipStream_t s);
+hipError_t gcr_launch_scatter_instances(int nblocks, int chunk, const uint32_t* vis_list,
+                                        const uint32_t* vis_count, const float4* rec, int gx,
+                                        uint32_t* tile_cursor, uint64_t* pairs, hipStream_t s);
+int gcr_tile_sort_capacity(void);  // longest per-tile list the LDS sort accepts
+hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, const uint64_t* pairs, uint32_t* list,
+                                int64_t max_tile_instances, hipStream_t s);
 // Stable LSD radix sort of R (u64 key, u32 value) pairs on bits [0, end_bit).  Ping-pongs
 // between (k0,v0) and (k1,v1); returns in *sorted_half which half holds the result.
 size_t gcr_sort_hist_bytes(int64_t R, int end_bit);

@@ -113,128 +113,188 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------- K1
-// cr/forward.cu:147-233.  Additionally reduces tiles_touched over the block so that K2 scans
-// P/256 block sums instead of P values, and packs the blend-time attributes of a Gaussian
-// into one 48-byte record (see gcr_internal.h).
-__global__ __launch_bounds__(256) void k_preprocess(const GcrPreprocessArgs a) {
-  __shared__ uint32_t wave_sums[4];
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  uint32_t tiles = 0;
+// cr/forward.cu:147-233, restructured for wave64 lane efficiency.  In city-scale frames only a
+// few percent of the Gaussians survive culling, so doing the visible-only work (SH colour from
+// 192 B of coefficients, record write, tile counting) in the thread that found the survivor
+// would run it at a few percent lane utilisation in almost every wave.  Instead:
+//   * persistent grid: block b owns the contiguous chunk [b*chunk, (b+1)*chunk) of Gaussians
+//     and walks it 256 at a time;
+//   * phase A (all lanes): project, covariance, conic, radius, tile rect -> radii[] and, for
+//     survivors, a 9-word item pushed into a ring queue in LDS (wave ballot + one LDS atomic
+//     per wave);
+//   * phase B (whenever >= 256 items are queued, and once at the end): one item per thread --
+//     SH -> RGB, 48-byte record, clamp mask, per-tile instance counts (atomics on 128-byte
+//     padded counters), and the Gaussian's index appended to the block's visible list, which
+//     the scatter kernel and the backward preprocess iterate densely.
+// Per-Gaussian arithmetic is unchanged (gcr-fp32-v1, bit-identical to the oracle).
+constexpr int Q_CAP = 512;   // ring capacity (items); < 256 queued before a push round
+constexpr int Q_WORDS = 9;   // idx, px, py, conic.xyz, depth, rect_x, rect_y
 
-  if (idx < a.P) {
-    int my_radius_i = 0;
-    const float* __restrict__ vm = a.view;
-    const float* __restrict__ pm = a.proj;
-    const V3 p_orig = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-    const V3 p_view = transform_point_4x3(p_orig, vm);
-    if (!(p_view.z <= 0.2f)) {  // in_frustum
-      const float hx = pm[0] * p_orig.x + pm[4] * p_orig.y + pm[8] * p_orig.z + pm[12];
-      const float hy = pm[1] * p_orig.x + pm[5] * p_orig.y + pm[9] * p_orig.z + pm[13];
-      const float hw = pm[3] * p_orig.x + pm[7] * p_orig.y + pm[11] * p_orig.z + pm[15];
-      const float p_w = 1.0f / (hw + 0.0000001f);
-      const float projx = hx * p_w, projy = hy * p_w;
-
-      float cov3D[6];
-      if (a.cov3D_precomp != nullptr) {
+GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, const uint32_t (*q)[Q_CAP], uint32_t slot,
+                                uint32_t list_pos, uint32_t* __restrict__ vis_list) {
+  const int idx = (int)q[0][slot];
+  const float px = __uint_as_float(q[1][slot]), py = __uint_as_float(q[2][slot]);
+  const float conx = __uint_as_float(q[3][slot]), cony = __uint_as_float(q[4][slot]);
+  const float conz = __uint_as_float(q[5][slot]), depth = __uint_as_float(q[6][slot]);
+  const uint32_t rx = q[7][slot], ry = q[8][slot];
+  float cr, cg, cb;
+  if (a.colors_precomp == nullptr) {
+    // computeColorFromSH, cr/forward.cu:20-66
+    const float* __restrict__ cp = a.campos;
+    const float ox = a.means3D[3 * idx] - cp[0], oy = a.means3D[3 * idx + 1] - cp[1],
+                oz = a.means3D[3 * idx + 2] - cp[2];
+    const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
+    const float x = ox / len, y = oy / len, z = oz / len;
+    const float* __restrict__ sh = a.shs + (size_t)idx * a.M * 3;
+    float res[3];
+    const int deg = a.D;
 #pragma unroll
-        for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D_precomp[6 * (size_t)idx + i];
-      } else {
-        const V3 sc = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
-        const float4 rot = reinterpret_cast<const float4*>(a.rotations)[idx];
-        compute_cov3d(sc, a.scale_modifier, rot, cov3D);
-      }
-      Cov2DCtx cc;
-      float cov[3];
-      cov2d_setup(p_orig, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy, vm, cc);
-      cov2d_eval(cc, cov3D, cov);
-
-      const float det = (cov[0] * cov[2] - cov[1] * cov[1]);
-      if (det != 0.0f) {
-        const float det_inv = 1.f / det;
-        const float conx = cov[2] * det_inv, cony = -cov[1] * det_inv, conz = cov[0] * det_inv;
-        const float mid = 0.5f * (cov[0] + cov[2]);
-        const float lambda1 = mid + __builtin_sqrtf(gcr_max(0.1f, mid * mid - det));
-        const float lambda2 = mid - __builtin_sqrtf(gcr_max(0.1f, mid * mid - det));
-        const float my_radius =
-            __builtin_ceilf(3.f * __builtin_sqrtf(gcr_max(lambda1, lambda2)));
-        const float px = gcr_ndc2pix(projx, a.W), py = gcr_ndc2pix(projy, a.H);
-        // getRect, cr/auxiliary.h:36-46
-        const int ri = gcr_f2i_sat(my_radius);
-        const float rf = (float)ri;
-        const int minx = min(a.gx, max(0, gcr_f2i_sat((px - rf) / 16.0f)));
-        const int miny = min(a.gy, max(0, gcr_f2i_sat((py - rf) / 16.0f)));
-        const int maxx = min(a.gx, max(0, gcr_f2i_sat((px + rf + 16.0f - 1.0f) / 16.0f)));
-        const int maxy = min(a.gy, max(0, gcr_f2i_sat((py + rf + 16.0f - 1.0f) / 16.0f)));
-        const uint32_t area = (uint32_t)(maxx - minx) * (uint32_t)(maxy - miny);
-        if (area != 0) {
-          float cr, cg, cb;
-          if (a.colors_precomp == nullptr) {
-            // computeColorFromSH, cr/forward.cu:20-66
-            const float* __restrict__ cp = a.campos;
-            float dx = p_orig.x - cp[0], dy = p_orig.y - cp[1], dz = p_orig.z - cp[2];
-            const float len = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
-            const float x = dx / len, y = dy / len, z = dz / len;
-            const float* __restrict__ sh = a.shs + (size_t)idx * a.M * 3;
-            float res[3];
-            const int deg = a.D;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
+    for (int ch = 0; ch < 3; ch++) {
 #define GCR_S(i) sh[3 * (i) + ch]
-              float result = SH_C0 * GCR_S(0);
-              if (deg > 0) {
-                result = result - SH_C1 * y * GCR_S(1) + SH_C1 * z * GCR_S(2) - SH_C1 * x * GCR_S(3);
-                if (deg > 1) {
-                  const float xx = x * x, yy = y * y, zz = z * z;
-                  const float xy = x * y, yz = y * z, xz = x * z;
-                  result = result + SH_C2[0] * xy * GCR_S(4) + SH_C2[1] * yz * GCR_S(5) +
-                           SH_C2[2] * (2.0f * zz - xx - yy) * GCR_S(6) + SH_C2[3] * xz * GCR_S(7) +
-                           SH_C2[4] * (xx - yy) * GCR_S(8);
-                  if (deg > 2) {
-                    result = result + SH_C3[0] * y * (3.0f * xx - yy) * GCR_S(9) +
-                             SH_C3[1] * xy * z * GCR_S(10) +
-                             SH_C3[2] * y * (4.0f * zz - xx - yy) * GCR_S(11) +
-                             SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * GCR_S(12) +
-                             SH_C3[4] * x * (4.0f * zz - xx - yy) * GCR_S(13) +
-                             SH_C3[5] * z * (xx - yy) * GCR_S(14) +
-                             SH_C3[6] * x * (xx - 3.0f * yy) * GCR_S(15);
-                  }
-                }
-              }
-#undef GCR_S
-              res[ch] = result + 0.5f;
-            }
-            const uint8_t cl = (uint8_t)((res[0] < 0 ? 1 : 0) | (res[1] < 0 ? 2 : 0) | (res[2] < 0 ? 4 : 0));
-            a.clamped[idx] = cl;
-            cr = gcr_max(res[0], 0.0f);
-            cg = gcr_max(res[1], 0.0f);
-            cb = gcr_max(res[2], 0.0f);
-          } else {
-            cr = a.colors_precomp[3 * idx];
-            cg = a.colors_precomp[3 * idx + 1];
-            cb = a.colors_precomp[3 * idx + 2];
+      float result = SH_C0 * GCR_S(0);
+      if (deg > 0) {
+        result = result - SH_C1 * y * GCR_S(1) + SH_C1 * z * GCR_S(2) - SH_C1 * x * GCR_S(3);
+        if (deg > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z;
+          const float xy = x * y, yz = y * z, xz = x * z;
+          result = result + SH_C2[0] * xy * GCR_S(4) + SH_C2[1] * yz * GCR_S(5) +
+                   SH_C2[2] * (2.0f * zz - xx - yy) * GCR_S(6) + SH_C2[3] * xz * GCR_S(7) +
+                   SH_C2[4] * (xx - yy) * GCR_S(8);
+          if (deg > 2) {
+            result = result + SH_C3[0] * y * (3.0f * xx - yy) * GCR_S(9) + SH_C3[1] * xy * z * GCR_S(10) +
+                     SH_C3[2] * y * (4.0f * zz - xx - yy) * GCR_S(11) +
+                     SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * GCR_S(12) +
+                     SH_C3[4] * x * (4.0f * zz - xx - yy) * GCR_S(13) + SH_C3[5] * z * (xx - yy) * GCR_S(14) +
+                     SH_C3[6] * x * (xx - 3.0f * yy) * GCR_S(15);
           }
-          if (a.cov3D_precomp == nullptr) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov3D[i];
-          }
-          float4* __restrict__ rec = a.rec + (size_t)idx * GCR_REC_QUADS;
-          rec[0] = make_float4(px, py, conx, cony);
-          rec[1] = make_float4(conz, a.opacities[idx], cr, cg);
-          rec[2] = make_float4(cb, p_view.z, __uint_as_float((uint32_t)minx | ((uint32_t)maxx << 16)),
-                               __uint_as_float((uint32_t)miny | ((uint32_t)maxy << 16)));
-          my_radius_i = ri;
-          tiles = area;
         }
       }
+#undef GCR_S
+      res[ch] = result + 0.5f;
     }
-    a.radii[idx] = my_radius_i;
-    a.tiles_touched[idx] = tiles;
+    a.clamped[idx] = (uint8_t)((res[0] < 0 ? 1 : 0) | (res[1] < 0 ? 2 : 0) | (res[2] < 0 ? 4 : 0));
+    cr = gcr_max(res[0], 0.0f);
+    cg = gcr_max(res[1], 0.0f);
+    cb = gcr_max(res[2], 0.0f);
+  } else {
+    cr = a.colors_precomp[3 * idx];
+    cg = a.colors_precomp[3 * idx + 1];
+    cb = a.colors_precomp[3 * idx + 2];
   }
-  // block sum of tiles touched -> block_sums[blockIdx.x]
-  const uint32_t ws = gcr_wave_sum_u32(tiles);
-  if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = ws;
+  float4* __restrict__ rec = a.rec + (size_t)idx * GCR_REC_QUADS;
+  rec[0] = make_float4(px, py, conx, cony);
+  rec[1] = make_float4(conz, a.opacities[idx], cr, cg);
+  rec[2] = make_float4(cb, depth, __uint_as_float(rx), __uint_as_float(ry));
+  vis_list[list_pos] = (uint32_t)idx;
+  // per-tile instance counts, global-cursor variant only (gcr_binning.hip explains why the
+  // default path counts in LDS instead)
+  const int minx = (int)(rx & 0xffffu), maxx = (int)(rx >> 16), miny = (int)(ry & 0xffffu), maxy = (int)(ry >> 16);
+  if (a.tile_count != nullptr)  // only in the global-cursor variant (tile table too big for LDS)
+    for (int ty = miny; ty < maxy; ty++)
+      for (int tx = minx; tx < maxx; tx++)
+        atomicAdd(&a.tile_count[(size_t)(ty * a.gx + tx) * GCR_CURSOR_STRIDE], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_preprocess(const GcrPreprocessArgs a) {
+  __shared__ uint32_t q[Q_WORDS][Q_CAP];
+  __shared__ uint32_t q_tail;  // items ever pushed by this block
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) q_tail = 0;
   __syncthreads();
-  if (threadIdx.x == 0) a.block_sums[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+  const float* __restrict__ vm = a.view;
+  const float* __restrict__ pm = a.proj;
+  const long long chunk_begin = (long long)blockIdx.x * a.chunk;
+  const long long chunk_end = chunk_begin + a.chunk < a.P ? chunk_begin + a.chunk : a.P;
+  uint32_t* __restrict__ my_list = a.vis_list + chunk_begin;
+  uint32_t head = 0;  // items already consumed (uniform across the block)
+
+  for (long long base = chunk_begin; base < chunk_end; base += 256) {
+    const long long idx64 = base + tid;
+    bool keep = false;
+    uint32_t item[Q_WORDS];
+    if (idx64 < chunk_end) {
+      const int idx = (int)idx64;
+      int my_radius_i = 0;
+      const V3 p_orig = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+      const V3 p_view = transform_point_4x3(p_orig, vm);
+      if (!(p_view.z <= 0.2f)) {  // in_frustum
+        const float hx = pm[0] * p_orig.x + pm[4] * p_orig.y + pm[8] * p_orig.z + pm[12];
+        const float hy = pm[1] * p_orig.x + pm[5] * p_orig.y + pm[9] * p_orig.z + pm[13];
+        const float hw = pm[3] * p_orig.x + pm[7] * p_orig.y + pm[11] * p_orig.z + pm[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float projx = hx * p_w, projy = hy * p_w;
+        float cov3D[6];
+        if (a.cov3D_precomp != nullptr) {
+#pragma unroll
+          for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+        } else {
+          const V3 sc = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+          const float4 rot = reinterpret_cast<const float4*>(a.rotations)[idx];
+          compute_cov3d(sc, a.scale_modifier, rot, cov3D);
+        }
+        Cov2DCtx cc;
+        float cov[3];
+        cov2d_setup(p_orig, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy, vm, cc);
+        cov2d_eval(cc, cov3D, cov);
+        const float det = (cov[0] * cov[2] - cov[1] * cov[1]);
+        if (det != 0.0f) {
+          const float det_inv = 1.f / det;
+          const float conx = cov[2] * det_inv, cony = -cov[1] * det_inv, conz = cov[0] * det_inv;
+          const float mid = 0.5f * (cov[0] + cov[2]);
+          const float lambda1 = mid + __builtin_sqrtf(gcr_max(0.1f, mid * mid - det));
+          const float lambda2 = mid - __builtin_sqrtf(gcr_max(0.1f, mid * mid - det));
+          const float my_radius = __builtin_ceilf(3.f * __builtin_sqrtf(gcr_max(lambda1, lambda2)));
+          const float px = gcr_ndc2pix(projx, a.W), py = gcr_ndc2pix(projy, a.H);
+          // getRect, cr/auxiliary.h:36-46
+          const int ri = gcr_f2i_sat(my_radius);
+          const float rf = (float)ri;
+          const int minx = min(a.gx, max(0, gcr_f2i_sat((px - rf) / 16.0f)));
+          const int miny = min(a.gy, max(0, gcr_f2i_sat((py - rf) / 16.0f)));
+          const int maxx = min(a.gx, max(0, gcr_f2i_sat((px + rf + 16.0f - 1.0f) / 16.0f)));
+          const int maxy = min(a.gy, max(0, gcr_f2i_sat((py + rf + 16.0f - 1.0f) / 16.0f)));
+          if ((uint32_t)(maxx - minx) * (uint32_t)(maxy - miny) != 0) {
+            keep = true;
+            my_radius_i = ri;
+            item[0] = (uint32_t)idx;
+            item[1] = __float_as_uint(px);
+            item[2] = __float_as_uint(py);
+            item[3] = __float_as_uint(conx);
+            item[4] = __float_as_uint(cony);
+            item[5] = __float_as_uint(conz);
+            item[6] = __float_as_uint(p_view.z);
+            item[7] = (uint32_t)minx | ((uint32_t)maxx << 16);
+            item[8] = (uint32_t)miny | ((uint32_t)maxy << 16);
+            if (a.cov3D_precomp == nullptr) {
+#pragma unroll
+              for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov3D[i];
+            }
+          }
+        }
+      }
+      a.radii[idx] = my_radius_i;
+    }
+    // push survivors: one LDS atomic per wave
+    const uint64_t m = __ballot(keep);
+    if (m != 0ull) {
+      uint32_t wbase = 0;
+      if (lane == 0) wbase = atomicAdd(&q_tail, (uint32_t)__popcll(m));
+      wbase = __shfl(wbase, 0, 64);
+      if (keep) {
+        const uint32_t slot = (wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (Q_CAP - 1);
+#pragma unroll
+        for (int k = 0; k < Q_WORDS; k++) q[k][slot] = item[k];
+      }
+    }
+    __syncthreads();
+    if (q_tail - head >= 256u) {  // uniform: q_tail is stable between the two barriers
+      preprocess_phase_b(a, q, (head + tid) & (Q_CAP - 1), head + tid, my_list);
+      head += 256u;
+    }
+    __syncthreads();
+  }
+  const uint32_t tail = q_tail;
+  if (head + tid < tail) preprocess_phase_b(a, q, (head + tid) & (Q_CAP - 1), head + tid, my_list);
+  if (tid == 0) a.vis_count[blockIdx.x] = tail;
 }
 
 // ------------------------------------------------------------------------------------- K2
@@ -266,13 +326,66 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
   if (tid == 1023) *total = part[1023];
 }
 
+// Tile-count scan for the counting-sort binning: in: cursor[t] = #instances of tile t (K1's
+// atomics); out: ranges[t] = [start,end) (what identifyTileRanges produces upstream,
+// cr/rasterizer_impl.cu:104-124), cursor[t] = start (scatter write cursor),
+// total_and_max[0] = num_rendered, [1] = longest tile list.  One 1024-thread block, coalesced
+// 1024-tile chunks (counters are GCR_CURSOR_STRIDE apart): T is small.
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ cursor, int stride,
+                                                     uint32_t* __restrict__ ranges, int T,
+                                                     unsigned long long* __restrict__ total_and_max) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ uint32_t wmax[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  unsigned long long running = 0;
+  uint32_t mx = 0;
+  for (int base = 0; base < T; base += 1024) {
+    const int i = base + tid;
+    const uint32_t c = i < T ? cursor[(size_t)i * stride] : 0u;
+    mx = c > mx ? c : mx;
+    const uint32_t incl = gcr_wave_incl_scan_u32(c, lane);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    unsigned long long before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const unsigned long long v = wsum[k];
+      if (k < w) before += v;
+      total += v;
+    }
+    const unsigned long long st64 = running + before + (incl - c);
+    if (i < T) {
+      // saturate: an overflowing frame is rejected on the host (num_rendered > 2^31-1)
+      const unsigned long long e64 = st64 + c;
+      const uint32_t st = st64 > 0xffffffffull ? 0xffffffffu : (uint32_t)st64;
+      ranges[2 * i + 0] = st;
+      ranges[2 * i + 1] = e64 > 0xffffffffull ? 0xffffffffu : (uint32_t)e64;
+      cursor[(size_t)i * stride] = st;
+    }
+    running += total;
+    __syncthreads();
+  }
+  const uint32_t m = gcr_wave_max_u32(mx);
+  if (lane == 0) wmax[w] = m;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t mm = 0;
+    for (int k = 0; k < 16; k++) mm = wmax[k] > mm ? wmax[k] : mm;
+    total_and_max[0] = running;
+    total_and_max[1] = mm;
+  }
+}
+
 // ------------------------------------------------------------------------------------- K8
 // Fused cr/backward.cu:143-293 (computeCov2DCUDA, "K8a") and :378-425 (preprocessCUDA, "K8b").
 // K8a assigns dL_dmean3D, K8b adds the projection and SH terms -- done here in registers in
 // the same order: cov2D part, + projection part, + SH part.
 __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdArgs a) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.P || !(a.radii[idx] > 0)) return;
+  // dense walk over K1's survivors (== the Gaussians with radii > 0 upstream, cr/backward.cu:151,387)
+  const uint32_t nvis = a.vis_count[blockIdx.x];
+  const uint32_t* __restrict__ my_list = a.vis_list + (size_t)blockIdx.x * a.chunk;
+  for (uint32_t it = threadIdx.x; it < nvis; it += 256) {
+  const int idx = (int)my_list[it];
   const float* __restrict__ vm = a.view;
   const float* __restrict__ proj = a.proj;
   const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
@@ -491,6 +604,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
     reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
   }
 }
+}
 
 }  // namespace
 
@@ -503,7 +617,7 @@ hipError_t gcr_launch_mark_visible(int P, const float* means3D, const float* vie
 
 hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
-  k_preprocess<<<(a.P + 255) / 256, 256, 0, s>>>(a);
+  k_preprocess<<<a.nblocks, 256, 0, s>>>(a);
   return hipGetLastError();
 }
 
@@ -513,8 +627,14 @@ hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long
   return hipGetLastError();
 }
 
+hipError_t gcr_launch_scan_tiles(uint32_t* tile_cursor, int stride, uint32_t* ranges, int T,
+                                 unsigned long long* total_and_max, hipStream_t s) {
+  k_scan_tiles<<<1, 1024, 0, s>>>(tile_cursor, stride, ranges, T, total_and_max);
+  return hipGetLastError();
+}
+
 hipError_t gcr_launch_preprocess_bwd(const GcrPreprocessBwdArgs& a, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
-  k_preprocess_bwd<<<(a.P + 255) / 256, 256, 0, s>>>(a);
+  k_preprocess_bwd<<<a.nblocks, 256, 0, s>>>(a);
   return hipGetLastError();
 }

@@ -91,14 +91,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     L = N.lib()
     device = means3D.device
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-    out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=device)
-    radii = torch.zeros((P,), dtype=torch.int32, device=device)
     byte = dict(dtype=torch.uint8, device=device)
-    geom = torch.empty((0,), **byte)
-    binning = torch.empty((0,), **byte)
-    img = torch.empty((0,), **byte)
-    if P == 0:  # dgr/rasterize_points.cu:71
-        return 0, out_color, radii, geom, binning, img
+    if P == 0:  # dgr/rasterize_points.cu:71: zero image, nothing rendered
+        e = torch.empty((0,), **byte)
+        return (0, torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=device),
+                torch.zeros((0,), dtype=torch.int32, device=device), e, e.clone(), e.clone())
+    # every pixel / every radius is written by the kernels, so no zero-fill launches are needed
+    out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=device)
+    radii = torch.empty((P,), dtype=torch.int32, device=device)
     with torch.cuda.device(device):
         cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
                               tan_fovy, H, W, scale_modifier, degree, prefiltered, debug)
@@ -107,17 +107,19 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         stream = _stream(device)
         geom = torch.empty((L.gcr_geometry_bytes(P),), **byte)
         img = torch.empty((L.gcr_image_bytes(W, H),), **byte)
-        R = C.c_int64(0)
+        info = N.FrameInfo()
         N.check(L.gcr_forward_preprocess(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
-                                         radii.data_ptr(), C.byref(R), stream),
+                                         img.data_ptr(), img.numel(), radii.data_ptr(),
+                                         C.byref(info), stream),
                 "gcr_forward_preprocess")
-        binning = torch.empty((L.gcr_binning_bytes(R.value, W, H),), **byte)
+        R = int(info.num_rendered)
+        binning = torch.empty((L.gcr_binning_bytes(R, W, H),), **byte)
         N.check(L.gcr_forward_render(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
                                      binning.data_ptr(), binning.numel(), img.data_ptr(),
-                                     img.numel(), R.value, out_color.data_ptr(), stream),
+                                     img.numel(), C.byref(info), out_color.data_ptr(), stream),
                 "gcr_forward_render")
         del keep_c, keep_g
-    return int(R.value), out_color, radii, geom, binning, img
+    return R, out_color, radii, geom, binning, img
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations,

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define GCR_ABI_VERSION 1
+#define GCR_ABI_VERSION 2
 #define GCR_BLOCK_X 16 /* cr/config.h:16 */
 #define GCR_BLOCK_Y 16 /* cr/config.h:17 */
 #define GCR_NUM_CHANNELS 3 /* cr/config.h:15 */
@@ -103,14 +103,19 @@ typedef struct gcr_layout {
                                 r,g | b,depth,rect_x(min|max<<16),rect_y(min|max<<16) */
   size_t geom_cov3D;         /* float[6] per Gaussian */
   size_t geom_clamped;       /* uint8 bitmask per Gaussian (bit ch set = channel clamped) */
-  size_t geom_tiles_touched; /* uint32 per Gaussian */
-  size_t geom_block_sums;    /* uint32 per 256-Gaussian block; exclusive-scanned in place */
+  size_t geom_tiles_touched; /* uint32 per Gaussian   (radix fallback path only) */
+  size_t geom_block_sums;    /* uint32 per 256-Gaussian block (radix fallback path only) */
+  size_t geom_vis_list;      /* uint32 per Gaussian: K1 block b's survivors, packed at b*chunk */
+  size_t geom_vis_count;     /* uint32 per K1 block */
   size_t geom_num_rendered;  /* uint64 total */
   size_t geom_total;
   /* image buffer */
   size_t img_final_T;   /* float per pixel   (ImageState::accum_alpha) */
   size_t img_n_contrib; /* uint32 per pixel */
   size_t img_ranges;    /* uint32[2] per tile */
+  size_t img_tile_cursor; /* one uint32 per tile, 128 B apart: instance count (after K1), then
+                             scatter write cursor */
+  size_t img_tile_table;  /* uint32 [groups][T]: per-group tile counts, then exclusive prefixes */
   size_t img_total;
   /* binning buffer (per instance) */
   size_t bin_keys[2]; /* uint64 per instance, ping/pong */
@@ -120,6 +125,13 @@ typedef struct gcr_layout {
   size_t bin_total;
 } gcr_layout;
 
+/* Host-side summary of K1+K2, produced by gcr_forward_preprocess and consumed by
+ * gcr_forward_render (the library keeps no state between calls). */
+typedef struct gcr_frame_info {
+  int64_t num_rendered;       /* R: total (Gaussian,tile) instances == the reference's return value */
+  int64_t max_tile_instances; /* longest per-tile list; selects the binning strategy */
+} gcr_frame_info;
+
 int gcr_abi_version(void);
 const char *gcr_last_error(void);
 
@@ -128,18 +140,21 @@ size_t gcr_image_bytes(int32_t W, int32_t H);
 size_t gcr_binning_bytes(int64_t R, int32_t W, int32_t H);
 int gcr_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout *out);
 
-/* K1 (project, cov2D, SH colour, tile rect) + K2 (scan of tiles touched).  Writes radii[P],
- * fills geom, and returns num_rendered through *num_rendered_host after ONE 8-byte D2H copy
- * (the sync the reference has at cr/rasterizer_impl.cu:236-238). */
+/* K1 (project, cov2D, SH colour, tile rect, per-tile instance counts) + K2 (scan of the tile
+ * counts -> tile ranges).  Writes radii[P], fills geom and the tile tables of img, and returns
+ * the frame summary through *info_host after ONE 16-byte D2H copy (the sync the reference has
+ * at cr/rasterizer_impl.cu:236-238). */
 int gcr_forward_preprocess(const gcr_camera *cam, const gcr_gaussians *g, void *geom,
-                           size_t geom_bytes, int32_t *radii, int64_t *num_rendered_host,
-                           void *hip_stream);
+                           size_t geom_bytes, void *img, size_t img_bytes, int32_t *radii,
+                           gcr_frame_info *info_host, void *hip_stream);
 
-/* K3 (key emit) + K4 (stable radix sort by tile|depth) + K5 (tile ranges) + K6 (blend).
- * out_color is [3,H,W].  R must be the value gcr_forward_preprocess returned. */
+/* K3 (instance emit) + K4 (depth sort inside every tile, ties in ascending Gaussian index ==
+ * the reference's stable radix sort by tile|depth) + K5 (tile ranges) + K6 (blend).
+ * out_color is [3,H,W].  *info must be what gcr_forward_preprocess returned. */
 int gcr_forward_render(const gcr_camera *cam, const gcr_gaussians *g, void *geom,
                        size_t geom_bytes, void *binning, size_t binning_bytes, void *img,
-                       size_t img_bytes, int64_t R, float *out_color, void *hip_stream);
+                       size_t img_bytes, const gcr_frame_info *info, float *out_color,
+                       void *hip_stream);
 
 /* K7 (reverse-walk blend gradient) + K8 (preprocess gradient). dL_dpix is [3,H,W]. */
 int gcr_backward(const gcr_camera *cam, const gcr_gaussians *g, const int32_t *radii,
@@ -161,8 +176,13 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
                               const gcr_camera *cam, const gcr_gaussians *g, float *out_color,
                               int32_t *radii, void *hip_stream);
 
-/* Blend-kernel variant knobs (process-wide; for A/B measurement, defaults are the parity
- * configuration).  name in {"fast_exp"}; returns previous value or <0 if unknown. */
+/* Process-wide knobs for A/B measurement (defaults are the shipping/parity configuration):
+ *   "fast_exp"     1: v_exp_f32 in the blend kernels (NOT bit-reproducible)          default 0
+ *   "force_radix"  1: always use the global LSD radix sort path for binning          default 0
+ *   "force_global_cursor" 1: count/scatter with device-scope atomics instead of LDS  default 0
+ *                     tile tables (the variant used when T*4 B does not fit in LDS)
+ *   "timing"       1: record per-stage HIP events (see gcr_get_stage_ms)             default 0
+ * Returns the previous value or <0 if the name is unknown. */
 int gcr_set_option(const char *name, int value);
 
 /* Average per-stage device time (ms) on this thread since the previous call,

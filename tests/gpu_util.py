@@ -53,17 +53,14 @@ def decode(P, W, H, out):
         R=R, out_color=color.cpu().numpy(), radii=radii.cpu().numpy(),
         means2D=rec[:, 0:2], conic_opacity=np.concatenate([rec[:, 2:5], rec[:, 5:6]], 1),
         rgb=rec[:, 6:9], depths=rec[:, 9],
-        rect=rec[:, 10:12].copy().view(np.uint32),
+        rect=rec[:, 10:12].copy().view(np.uint32),   # (min | max << 16) in x and y, tile units
         cov3D=gb[L.geom_cov3D:L.geom_cov3D + P * 24].view(np.float32).reshape(P, 6),
         clamped=gb[L.geom_clamped:L.geom_clamped + P],
-        tiles_touched=gb[L.geom_tiles_touched:L.geom_tiles_touched + 4 * P].view(np.uint32),
         final_T=ib[L.img_final_T:L.img_final_T + 4 * W * H].view(np.float32),
         n_contrib=ib[L.img_n_contrib:L.img_n_contrib + 4 * W * H].view(np.uint32),
         ranges=ib[L.img_ranges:L.img_ranges + 8 * T].view(np.uint32).reshape(T, 2),
     )
     if R > 0:
         s = L.bin_sorted
-        d["keys"] = bb[L.bin_keys[s]:L.bin_keys[s] + 8 * R].view(np.uint64)
         d["point_list"] = bb[L.bin_vals[s]:L.bin_vals[s] + 4 * R].view(np.uint32)
-        d["keys_unsorted"] = bb[L.bin_keys[0]:L.bin_keys[0] + 8 * R].view(np.uint64) if s == 1 else None
     return d

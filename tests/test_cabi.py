@@ -28,12 +28,12 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", N.LIB_PATH]).decode()
     exported = set(re.findall(r" T (gcr_[a-z_]+)", out))
     assert set(declared) <= exported
-    assert lib.gcr_abi_version() == 1
+    assert lib.gcr_abi_version() == N.ABI_VERSION == 2
 
 
 def test_library_contains_gfx950_code_object():
     blob = open(N.LIB_PATH, "rb").read()
-    assert b"gfx950" in blob and b"k_blend_fwd" in blob and b"k_radix_scatter" in blob
+    assert b"gfx950" in blob and all(k in blob for k in (b"k_blend_fwd", b"k_radix_scatter", b"k_tile_sort"))
 
 
 def test_scratch_sizes_and_layout():
@@ -49,7 +49,7 @@ def test_scratch_sizes_and_layout():
             L.geom_num_rendered, L.geom_total]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
     assert L.geom_total == lib.gcr_geometry_bytes(5000)
-    assert L.img_total == lib.gcr_image_bytes(640, 448)
+    assert L.img_total == lib.gcr_image_bytes(640, 448) and L.img_ranges < L.img_tile_cursor < L.img_total
     assert L.bin_total == lib.gcr_binning_bytes(123456, 640, 448)
     # 1120 tiles -> 11 tile bits -> 43 key bits -> 6 radix passes -> result in half 0
     assert L.bin_sorted == 0
@@ -58,10 +58,10 @@ def test_scratch_sizes_and_layout():
 
 def test_argument_errors_are_reported_without_touching_the_gpu():
     lib = N.lib()
-    R = C.c_int64(-1)
+    R = N.FrameInfo(-1, -1)
     cam = N.Camera(16, 16, 0.3, 0.3, 1.0, 0, 0, 0, None, None, None, None)
     g = N.Gaussians(4, 0, None, None, None, None, None, None, None)
-    rc = lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), None, 0, None, C.byref(R), None)
+    rc = lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), None, 0, None, 0, None, C.byref(R), None)
     assert rc == -1 and b"non-null" in lib.gcr_last_error()
     with pytest.raises(RuntimeError, match="gcr_status -1"):
         N.check(rc, "gcr_forward_preprocess")
@@ -70,22 +70,22 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     cam = N.Camera(16, 16, 0.3, 0.3, 1.0, 0, 0, 0, p, p, p, p)
     # exactly one of SH / precomputed colour
     g = N.Gaussians(4, 0, p, p, None, None, p, p, None)
-    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), None, 0, None, C.byref(R), None) == -1
+    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), None, 0, None, 0, None, C.byref(R), None) == -1
     assert b"exactly one of SHs" in lib.gcr_last_error()
     # scale without rotation
     g = N.Gaussians(4, 0, p, p, None, p, p, None, None)
-    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), None, 0, None, C.byref(R), None) == -1
+    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), None, 0, None, 0, None, C.byref(R), None) == -1
     assert b"scale/rotation" in lib.gcr_last_error()
     # SH table too small for the requested degree
     cam3 = N.Camera(16, 16, 0.3, 0.3, 1.0, 3, 0, 0, p, p, p, p)
     g = N.Gaussians(4, 4, p, p, p, None, p, p, None)
-    assert lib.gcr_forward_preprocess(C.byref(cam3), C.byref(g), None, 0, None, C.byref(R), None) == -1
+    assert lib.gcr_forward_preprocess(C.byref(cam3), C.byref(g), None, 0, None, 0, None, C.byref(R), None) == -1
     # geometry buffer too small -> -2, before any launch
     g = N.Gaussians(4, 0, p, p, None, p, p, p, None)
-    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), p, 8, p, C.byref(R), None) == -2
+    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), p, 8, p, 8, p, C.byref(R), None) == -2
     # P == 0 short-circuits successfully (dgr/rasterize_points.cu:71)
     g0 = N.Gaussians(0, 0, None, None, None, None, None, None, None)
-    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g0), None, 0, None, C.byref(R), None) == 0
-    assert R.value == 0
+    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g0), None, 0, None, 0, None, C.byref(R), None) == 0
+    assert R.num_rendered == 0 and R.max_tile_instances == 0
     assert lib.gcr_mark_visible(-1, None, None, None, None, None) == -1
     assert lib.gcr_set_option(b"no_such_option", 1) < 0
