@@ -109,7 +109,7 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   L->img_tile_cursor = o;  o = align_up(o + T * GCR_CURSOR_STRIDE * sizeof(uint32_t));
   {
     int G = 1;
-    const int ng = gcr_tile_table_groups((int)T, 2048, &G);  // 2048 = max K1 blocks -> max groups
+    const int ng = gcr_tile_table_groups((int)T, GCR_K1_MAX_BLOCKS, &G);  // upper bound on groups
     L->img_tile_table = o;   o = align_up(o + (size_t)ng * T * sizeof(uint32_t));
   }
   L->img_total = o;
@@ -236,7 +236,7 @@ int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* 
   a.tile_count = (uint32_t*)(ib + L.img_tile_cursor);
   a.vis_list = (uint32_t*)(gb + L.geom_vis_list);
   a.vis_count = (uint32_t*)(gb + L.geom_vis_count);
-  gcr_preprocess_grid(g->P, &a.nblocks, &a.chunk);
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &a.nblocks, &a.chunk);
   unsigned long long* total_and_max = (unsigned long long*)(gb + L.geom_num_rendered);
   int G = 1;
   const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, a.nblocks, &G);
@@ -300,7 +300,7 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   const uint32_t* vis_list = (const uint32_t*)(gb + L.geom_vis_list);
   const uint32_t* vis_count = (const uint32_t*)(gb + L.geom_vis_count);
   int nblocks, chunk;
-  gcr_preprocess_grid(g->P, &nblocks, &chunk);
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &nblocks, &chunk);
   uint64_t* k0 = (uint64_t*)(bb + L.bin_keys[0]);
   uint64_t* k1 = (uint64_t*)(bb + L.bin_keys[1]);
   uint32_t* v0 = (uint32_t*)(bb + L.bin_vals[0]);
@@ -430,7 +430,7 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   a.clamped = (const uint8_t*)(gb + L.geom_clamped);
   a.vis_list = (const uint32_t*)(gb + L.geom_vis_list);
   a.vis_count = (const uint32_t*)(gb + L.geom_vis_count);
-  gcr_preprocess_grid(g->P, &a.nblocks, &a.chunk);
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &a.nblocks, &a.chunk);
   a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dconic = gr->dL_dconic; a.dL_dcolor = gr->dL_dcolors;
   a.dL_dmean3D = gr->dL_dmeans3D; a.dL_dcov3D = gr->dL_dcov3D; a.dL_dsh = gr->dL_dsh;
   a.dL_dscale = gr->dL_dscales; a.dL_drot = gr->dL_drotations;

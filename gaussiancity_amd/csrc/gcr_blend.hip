@@ -1,17 +1,22 @@
 // gcr_blend.hip -- K6 forward alpha compositing and K7 reverse-walk gradient for gfx950.
 //
-// One 256-thread workgroup (4 x wave64) per 16x16 tile; wave w owns pixel rows 4w..4w+3.
-// A tile's depth-sorted list is consumed in chunks of 256 entries: the 256 threads gather
-// one 48-byte Gaussian record each (3 x dwordx4 from <= 2 cache lines) and stage it in LDS
-// as SoA quads, so the blend loop reads wave-uniform (broadcast) ds_read_b128/b64 and never
+// One 256-thread workgroup (4 x wave64) per 16x16 tile; wave w owns the 8x8-pixel QUADRANT
+// (w&1, w>>1) of the tile.  A tile's depth-sorted list is consumed in chunks of 256 entries: the
+// 256 threads gather one 48-byte Gaussian record each (3 x dwordx4 from <= 2 cache lines) and
+// stage it in LDS as SoA quads, so the blend loop reads wave-uniform (broadcast) LDS and never
 // touches global memory.  Differences from cr/forward.cu:238-346 that do not change results:
 //   * colour is staged in LDS too (the reference gathers it per contributing pixel, :328);
 //   * a per-Gaussian conservative bound pmin = -ln(255*opacity) - 1e-3 is staged; pixels with
-//     power < pmin are skipped before exp() -- exactly the pixels whose alpha < 1/255 test
-//     (:318) would skip them anyway (alpha = o*exp(power) < 1/255 with margin);
-//   * `contributor` is derived from the (wave-uniform) loop index instead of a per-lane counter;
-//   * the wave stops reading LDS as soon as its own 64 pixels are done (wave-level early
-//     out, on top of the block-level vote of :284-286).
+//     power < pmin are skipped before exp() -- exactly pixels the alpha < 1/255 test (:318)
+//     would skip anyway;
+//   * QUADRANT CULLING: the staging thread also computes the axis-aligned box of the ellipse
+//     {power >= pmin} (inflated by 0.1 % + 0.01 px) and a 4-bit mask of the quadrants it
+//     overlaps.  Each wave ballot-compacts the chunk into a 256-bit set and walks only its own
+//     entries with a scalar bit scan.  An entry outside a quadrant's box has power < pmin for
+//     all 64 pixels, i.e. it is skipped by every pixel upstream as well, and skipped entries
+//     never change a pixel's state -- so n_contrib/final_T/colour are unchanged;
+//   * `contributor` is the (wave-uniform) list position instead of a per-lane counter;
+//   * a wave stops as soon as its own 64 pixels are done, on top of the block vote (:284-286).
 // Arithmetic: gcr-fp32-v1 (gcr_device.h) -> out_color / final_T / n_contrib are bit-identical
 // to the oracle.
 #include "gcr_device.h"
@@ -22,29 +27,53 @@ namespace {
 constexpr int CHUNK = 256;
 
 // pmin such that power < pmin  =>  opacity*exp(power) < 1/255 with a 1e-3 safety margin.
+// Clamped to >= -87 so the blend loops may use the guard-free exponential (see gcr_device.h).
 GCR_DEV float gcr_alpha_skip_bound(float opacity) {
   if (!(opacity > 0.0f)) return __builtin_inff();  // alpha <= 0 < 1/255: always skipped
-  return -__builtin_logf(255.0f * opacity) - 1.0e-3f;
+  return gcr_max(-87.0f, -__builtin_logf(255.0f * opacity) - 1.0e-3f);
+}
+
+// 4-bit mask of the 8x8 quadrants of tile (tile_x0, tile_y0) that the region {power >= pmin} of
+// a Gaussian can reach.  Conservative: anything it cannot bound returns 0xF.
+GCR_DEV uint32_t gcr_quadrant_mask(float gx, float gy, float cx, float cy, float cz, float pmin,
+                                   float tile_x0, float tile_y0) {
+  if (!(pmin < 0.0f)) return 0u;  // alpha < 1/255 everywhere (power <= 0 always)
+  const float det = cx * cz - cy * cy;
+  if (!(det > 0.0f)) return 0xFu;
+  const float tau = -2.0f * pmin;
+  float ex = __builtin_sqrtf(tau * cz / det), ey = __builtin_sqrtf(tau * cx / det);
+  if (!(ex == ex) || !(ey == ey)) return 0xFu;
+  ex = ex * 1.001f + 0.01f;
+  ey = ey * 1.001f + 0.01f;
+  const float lox = gx - ex, hix = gx + ex, loy = gy - ey, hiy = gy + ey;
+  const bool x0 = hix >= tile_x0 && lox <= tile_x0 + 7.0f;
+  const bool x1 = hix >= tile_x0 + 8.0f && lox <= tile_x0 + 15.0f;
+  const bool y0 = hiy >= tile_y0 && loy <= tile_y0 + 7.0f;
+  const bool y1 = hiy >= tile_y0 + 8.0f && loy <= tile_y0 + 15.0f;
+  return (x0 && y0 ? 1u : 0u) | (x1 && y0 ? 2u : 0u) | (x0 && y1 ? 4u : 0u) | (x1 && y1 ? 8u : 0u);
 }
 
 template <bool FAST_EXP>
 GCR_DEV float blend_exp(float x) {
-  return FAST_EXP ? gcr_expf_fast(x) : gcr_expf(x);
+  return FAST_EXP ? gcr_expf_fast(x) : gcr_expf_noguard(x);
 }
 
 // ------------------------------------------------------------------------------------- K6
 template <bool FAST_EXP>
 __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
-  __shared__ float4 sA[CHUNK];  // x, y, conic.x, conic.y
-  __shared__ float4 sB[CHUNK];  // conic.z, opacity, r, g
-  __shared__ float2 sC[CHUNK];  // b, pmin
+  __shared__ float4 sA[CHUNK];    // x, y, conic.x, conic.y
+  __shared__ float4 sB[CHUNK];    // conic.z, opacity, r, g
+  __shared__ float2 sC[CHUNK];    // b, pmin
+  __shared__ uint32_t sM[CHUNK];  // quadrant mask
 
   const int tile = blockIdx.x;
   const int tx = tile % a.gx, ty = tile / a.gx;
-  const int tid = threadIdx.x;
-  const int pxi = tx * GCR_TILE_X + (tid & 15), pyi = ty * GCR_TILE_Y + (tid >> 4);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int pxi = tx * GCR_TILE_X + (w & 1) * 8 + (lane & 7);
+  const int pyi = ty * GCR_TILE_Y + (w >> 1) * 8 + (lane >> 3);
   const bool inside = pxi < a.W && pyi < a.H;
   const float pixx = (float)pxi, pixy = (float)pyi;
+  const float tile_x0 = (float)(tx * GCR_TILE_X), tile_y0 = (float)(ty * GCR_TILE_Y);
   const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
   const int total = (int)(r1 - r0);
 
@@ -56,35 +85,57 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
     // block-wide vote (cr/forward.cu:284-286); also fences the previous chunk's LDS reads
     if (__syncthreads_count(done) == 256) break;
     const int n = min(CHUNK, total - base);
+    uint32_t my_mask = 0;
     if (tid < n) {
       const uint32_t id = a.list[r0 + base + tid];
       const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
       const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+      const float pmin = gcr_alpha_skip_bound(q1.y);
       sA[tid] = q0;
       sB[tid] = q1;
-      sC[tid] = make_float2(q2.x, gcr_alpha_skip_bound(q1.y));
+      sC[tid] = make_float2(q2.x, pmin);
+      my_mask = gcr_quadrant_mask(q0.x, q0.y, q0.z, q0.w, q1.x, pmin, tile_x0, tile_y0);
     }
+    sM[tid] = my_mask;
     __syncthreads();
-    for (int j = 0; !done && j < n; j++) {
-      const float4 qa = sA[j];
-      const float2 qc = sC[j];
-      const float dx = qa.x - pixx, dy = qa.y - pixy;
-      const float4 qb = sB[j];
-      const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
-      if (power > 0.0f) continue;
-      if (power < qc.y) continue;  // certain alpha < 1/255
-      const float alpha = gcr_min(0.99f, qb.y * blend_exp<FAST_EXP>(power));
-      if (alpha < 1.0f / 255.0f) continue;
-      const float test_T = T * (1 - alpha);
-      if (test_T < 0.0001f) {
-        done = true;
-        continue;
+    if (__ballot(!done) == 0ull) continue;  // this wave's quadrant is finished; keep voting
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+      uint64_t m = __ballot((sM[k * 64 + lane] >> w) & 1u);
+      while (m != 0ull) {
+        const int j = k * 64 + __builtin_ctzll(m);
+        m &= m - 1ull;
+        // Branch-free body (the scalar unit, one per CU, was the bottleneck of the branchy
+        // version: ~45 SALU instructions per entry for exec-mask bookkeeping).  A lane that
+        // upstream would `continue` keeps its state through selects.
+        const float4 qa = sA[j];
+        const float2 qc = sC[j];
+        const float4 qb = sB[j];
+        const float dx = qa.x - pixx, dy = qa.y - pixy;
+        const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
+        const bool in_range = !done && !(power > 0.0f) && !(power < qc.y);
+        if (__ballot(in_range) != 0ull) {  // wave-uniform
+          const float pw = gcr_max(-87.0f, gcr_min(power, 0.0f));  // keeps masked lanes finite
+          const float araw = gcr_min(0.99f, qb.y * blend_exp<FAST_EXP>(pw));
+          const bool valid = in_range && !(araw < 1.0f / 255.0f);
+          const float test_T = T * (1 - araw);
+          const bool kill = valid && test_T < 0.0001f;
+          const bool use = valid && !kill;
+          const float n0 = __builtin_fmaf(qb.z * araw, T, C0);
+          const float n1 = __builtin_fmaf(qb.w * araw, T, C1);
+          const float n2 = __builtin_fmaf(qc.x * araw, T, C2);
+          C0 = use ? n0 : C0;
+          C1 = use ? n1 : C1;
+          C2 = use ? n2 : C2;
+          T = use ? test_T : T;
+          last_contributor = use ? (uint32_t)(base + j + 1) : last_contributor;
+          done = done || kill;
+          if (__ballot(!done) == 0ull) {
+            m = 0ull;
+            k = 4;
+          }
+        }
       }
-      C0 = __builtin_fmaf(qb.z * alpha, T, C0);
-      C1 = __builtin_fmaf(qb.w * alpha, T, C1);
-      C2 = __builtin_fmaf(qc.x * alpha, T, C2);
-      T = test_T;
-      last_contributor = (uint32_t)(base + j + 1);
     }
   }
   if (inside) {
@@ -107,12 +158,14 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
 //   3. after the chunk, thread t flushes entry t with nine global_atomic_add_f32
 // so global atomics drop from 9 per (pixel,Gaussian) to 9 per (tile,Gaussian).
 // Only entries [0, max n_contrib of the tile) are visited: later entries are skipped by every
-// pixel in the reference too (contributor >= last_contributor, :511-512).
+// pixel in the reference too (contributor >= last_contributor, :511-512); and each wave visits
+// only the entries whose quadrant mask includes its 8x8 quadrant (see K6).
 template <bool FAST_EXP>
 __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
   __shared__ float4 sA[CHUNK];
   __shared__ float4 sB[CHUNK];
   __shared__ float2 sC[CHUNK];
+  __shared__ uint32_t sM[CHUNK];
   __shared__ uint32_t sId[CHUNK];
   __shared__ float sAcc[9][CHUNK];
   __shared__ uint32_t sMax[4];
@@ -120,9 +173,11 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
   const int tile = blockIdx.x;
   const int tx = tile % a.gx, ty = tile / a.gx;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int pxi = tx * GCR_TILE_X + (tid & 15), pyi = ty * GCR_TILE_Y + (tid >> 4);
+  const int pxi = tx * GCR_TILE_X + (w & 1) * 8 + (lane & 7);
+  const int pyi = ty * GCR_TILE_Y + (w >> 1) * 8 + (lane >> 3);
   const bool inside = pxi < a.W && pyi < a.H;
   const float pixx = (float)pxi, pixy = (float)pyi;
+  const float tile_x0 = (float)(tx * GCR_TILE_X), tile_y0 = (float)(ty * GCR_TILE_Y);
   const uint32_t r0 = a.ranges[2 * tile];
   const size_t pix_id = (size_t)a.W * pyi + pxi;
   const size_t plane = (size_t)a.H * a.W;
@@ -143,10 +198,8 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
   const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
 
   // entries any pixel of this tile consumed
-  {
-    const uint32_t m = gcr_wave_max_u32(last_contributor);
-    if (lane == 0) sMax[w] = m;
-  }
+  const uint32_t wave_max = gcr_wave_max_u32(last_contributor);
+  if (lane == 0) sMax[w] = wave_max;
   __syncthreads();
   const int total = (int)max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
   if (total == 0) return;
@@ -158,89 +211,100 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
   for (int base = 0; base < total; base += CHUNK) {
     const int n = min(CHUNK, total - base);
     __syncthreads();  // previous chunk fully flushed before its LDS is reused
+    uint32_t my_mask = 0;
     if (tid < n) {
       // back to front: chunk slot `tid` holds list entry e = total-1-(base+tid)
       const uint32_t id = a.list[r0 + (uint32_t)(total - 1 - (base + tid))];
       const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
       const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+      const float pmin = gcr_alpha_skip_bound(q1.y);
       sA[tid] = q0;
       sB[tid] = q1;
-      sC[tid] = make_float2(q2.x, gcr_alpha_skip_bound(q1.y));
+      sC[tid] = make_float2(q2.x, pmin);
       sId[tid] = id;
+      my_mask = gcr_quadrant_mask(q0.x, q0.y, q0.z, q0.w, q1.x, pmin, tile_x0, tile_y0);
     }
+    sM[tid] = my_mask;
 #pragma unroll
     for (int k = 0; k < 9; k++) sAcc[k][tid] = 0.0f;
     __syncthreads();
 
-    for (int j = 0; j < n; j++) {
-      const uint32_t entry = (uint32_t)(total - 1 - (base + j));  // == `contributor` upstream
-      bool act = entry < last_contributor;
-      const float4 qa = sA[j];
-      const float2 qc = sC[j];
-      const float4 qb = sB[j];
-      const float dx = qa.x - pixx, dy = qa.y - pixy;
-      const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
-      act = act && !(power > 0.0f) && !(power < qc.y);
-      if (__ballot(act) == 0ull) continue;  // whole wave skips this Gaussian
-      float v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0;
-      if (act) {
-        const float G = blend_exp<FAST_EXP>(power);
+    // slots whose list entry this wave's pixels still consume: entry < wave_max
+    //   entry = total-1-(base+j) < wave_max  <=>  j > total-1-base-wave_max
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+      const int jj = k * 64 + lane;
+      const uint32_t entry_l = (uint32_t)(total - 1 - (base + jj));
+      uint64_t m = __ballot(jj < n && ((sM[jj] >> w) & 1u) && entry_l < wave_max);
+      while (m != 0ull) {
+        const int j = k * 64 + __builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t entry = (uint32_t)(total - 1 - (base + j));  // == `contributor` upstream
+        const float4 qa = sA[j];
+        const float2 qc = sC[j];
+        const float4 qb = sB[j];
+        const float dx = qa.x - pixx, dy = qa.y - pixy;
+        const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
+        const bool in_range = entry < last_contributor && !(power > 0.0f) && !(power < qc.y);
+        if (__ballot(in_range) == 0ull) continue;  // whole wave skips this Gaussian
+        // Branch-free body: lanes that upstream would `continue` keep their state via selects
+        // and contribute exact zeros to the wave reduction (see K6 for why: SALU pressure).
+        const float pw = gcr_max(-87.0f, gcr_min(power, 0.0f));
+        const float G = blend_exp<FAST_EXP>(pw);
         const float alpha = gcr_min(0.99f, qb.y * G);
-        if (!(alpha < 1.0f / 255.0f)) {
-          T = T / (1.f - alpha);
-          const float dchannel_dcolor = alpha * T;
-          float dL_dalpha = 0.0f;
-          // channel 0
-          acc0 = __builtin_fmaf(last_alpha, lc0, (1.f - last_alpha) * acc0);
-          lc0 = qb.z;
-          dL_dalpha = __builtin_fmaf(qb.z - acc0, dLp0, dL_dalpha);
-          v0 = dchannel_dcolor * dLp0;
-          // channel 1
-          acc1 = __builtin_fmaf(last_alpha, lc1, (1.f - last_alpha) * acc1);
-          lc1 = qb.w;
-          dL_dalpha = __builtin_fmaf(qb.w - acc1, dLp1, dL_dalpha);
-          v1 = dchannel_dcolor * dLp1;
-          // channel 2
-          acc2 = __builtin_fmaf(last_alpha, lc2, (1.f - last_alpha) * acc2);
-          lc2 = qc.x;
-          dL_dalpha = __builtin_fmaf(qc.x - acc2, dLp2, dL_dalpha);
-          v2 = dchannel_dcolor * dLp2;
-
-          dL_dalpha *= T;
-          last_alpha = alpha;
-          dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-
-          const float dL_dG = qb.y * dL_dalpha;
-          const float gdx = G * dx, gdy = G * dy;
-          const float dG_ddelx = -gdx * qa.z - gdy * qa.w;
-          const float dG_ddely = -gdy * qb.x - gdx * qa.w;
-          v3 = dL_dG * dG_ddelx * ddelx_dx;
-          v4 = dL_dG * dG_ddely * ddely_dy;
-          v5 = -0.5f * gdx * dx * dL_dG;
-          v6 = -0.5f * gdx * dy * dL_dG;
-          v7 = -0.5f * gdy * dy * dL_dG;
-          v8 = G * dL_dalpha;
+        const bool use = in_range && !(alpha < 1.0f / 255.0f);
+        const float Tn = T / (1.f - alpha);
+        const float dchannel_dcolor = alpha * Tn;
+        const float a0 = __builtin_fmaf(last_alpha, lc0, (1.f - last_alpha) * acc0);
+        const float a1 = __builtin_fmaf(last_alpha, lc1, (1.f - last_alpha) * acc1);
+        const float a2 = __builtin_fmaf(last_alpha, lc2, (1.f - last_alpha) * acc2);
+        float dL_dalpha = 0.0f;
+        dL_dalpha = __builtin_fmaf(qb.z - a0, dLp0, dL_dalpha);
+        dL_dalpha = __builtin_fmaf(qb.w - a1, dLp1, dL_dalpha);
+        dL_dalpha = __builtin_fmaf(qc.x - a2, dLp2, dL_dalpha);
+        dL_dalpha *= Tn;
+        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+        const float dL_dG = qb.y * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        const float dG_ddelx = -gdx * qa.z - gdy * qa.w;
+        const float dG_ddely = -gdy * qb.x - gdx * qa.w;
+        float v0 = use ? dchannel_dcolor * dLp0 : 0.0f;
+        float v1 = use ? dchannel_dcolor * dLp1 : 0.0f;
+        float v2 = use ? dchannel_dcolor * dLp2 : 0.0f;
+        float v3 = use ? dL_dG * dG_ddelx * ddelx_dx : 0.0f;
+        float v4 = use ? dL_dG * dG_ddely * ddely_dy : 0.0f;
+        float v5 = use ? -0.5f * gdx * dx * dL_dG : 0.0f;
+        float v6 = use ? -0.5f * gdx * dy * dL_dG : 0.0f;
+        float v7 = use ? -0.5f * gdy * dy * dL_dG : 0.0f;
+        float v8 = use ? G * dL_dalpha : 0.0f;
+        T = use ? Tn : T;
+        acc0 = use ? a0 : acc0;
+        acc1 = use ? a1 : acc1;
+        acc2 = use ? a2 : acc2;
+        lc0 = use ? qb.z : lc0;
+        lc1 = use ? qb.w : lc1;
+        lc2 = use ? qc.x : lc2;
+        last_alpha = use ? alpha : last_alpha;
+        v0 = gcr_wave_sum_to_lane63(v0);
+        v1 = gcr_wave_sum_to_lane63(v1);
+        v2 = gcr_wave_sum_to_lane63(v2);
+        v3 = gcr_wave_sum_to_lane63(v3);
+        v4 = gcr_wave_sum_to_lane63(v4);
+        v5 = gcr_wave_sum_to_lane63(v5);
+        v6 = gcr_wave_sum_to_lane63(v6);
+        v7 = gcr_wave_sum_to_lane63(v7);
+        v8 = gcr_wave_sum_to_lane63(v8);
+        if (lane == 63) {
+          atomicAdd(&sAcc[0][j], v0);
+          atomicAdd(&sAcc[1][j], v1);
+          atomicAdd(&sAcc[2][j], v2);
+          atomicAdd(&sAcc[3][j], v3);
+          atomicAdd(&sAcc[4][j], v4);
+          atomicAdd(&sAcc[5][j], v5);
+          atomicAdd(&sAcc[6][j], v6);
+          atomicAdd(&sAcc[7][j], v7);
+          atomicAdd(&sAcc[8][j], v8);
         }
-      }
-      v0 = gcr_wave_sum_to_lane63(v0);
-      v1 = gcr_wave_sum_to_lane63(v1);
-      v2 = gcr_wave_sum_to_lane63(v2);
-      v3 = gcr_wave_sum_to_lane63(v3);
-      v4 = gcr_wave_sum_to_lane63(v4);
-      v5 = gcr_wave_sum_to_lane63(v5);
-      v6 = gcr_wave_sum_to_lane63(v6);
-      v7 = gcr_wave_sum_to_lane63(v7);
-      v8 = gcr_wave_sum_to_lane63(v8);
-      if (lane == 63) {
-        atomicAdd(&sAcc[0][j], v0);
-        atomicAdd(&sAcc[1][j], v1);
-        atomicAdd(&sAcc[2][j], v2);
-        atomicAdd(&sAcc[3][j], v3);
-        atomicAdd(&sAcc[4][j], v4);
-        atomicAdd(&sAcc[5][j], v5);
-        atomicAdd(&sAcc[6][j], v6);
-        atomicAdd(&sAcc[7][j], v7);
-        atomicAdd(&sAcc[8][j], v8);
       }
     }
     __syncthreads();

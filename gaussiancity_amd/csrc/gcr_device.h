@@ -47,6 +47,23 @@ GCR_DEV float gcr_expf(float x) {
   return p * __int_as_float(((int)n + 127) << 23);
 }
 
+// Same function without the range guards, for callers that guarantee -87 <= x <= 0 (the blend
+// kernels clamp their skip bound to >= -87, which is exactly what the x < -87 guard does:
+// exp -> 0 -> alpha = 0 < 1/255 -> skipped).  Bit-identical to gcr_expf on that domain.
+GCR_DEV float gcr_expf_noguard(float x) {
+  const float n = __builtin_rintf(x * 1.44269504088896341f);
+  float r = __builtin_fmaf(n, -0.693145751953125f, x);
+  r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+  float p = 0.0013933652080595493f;
+  p = __builtin_fmaf(p, r, 0.008363181725144386f);
+  p = __builtin_fmaf(p, r, 0.04166646674275398f);
+  p = __builtin_fmaf(p, r, 0.16666576266288757f);
+  p = __builtin_fmaf(p, r, 0.5f);
+  p = __builtin_fmaf(p, r, 1.0f);
+  p = __builtin_fmaf(p, r, 1.0f);
+  return p * __int_as_float(((int)n + 127) << 23);
+}
+
 // Non-parity variant (option "fast_exp"): hardware v_exp_f32, ~1 ulp, NOT bit-reproducible.
 GCR_DEV float gcr_expf_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 

@@ -30,9 +30,11 @@ struct GcrPreprocessArgs {
   int nblocks, chunk;    // persistent grid: block b owns Gaussians [b*chunk, (b+1)*chunk)
 };
 
-// Persistent-grid geometry of K1 (also used by the kernels that walk its visible lists).
-static inline void gcr_preprocess_grid(int P, int* nblocks, int* chunk) {
-  const int max_blocks = 2048;  // 8 workgroups per CU x 256 CUs
+// Persistent-grid geometry of K1 (also used by the kernels that walk its visible lists):
+// as many blocks as are co-resident (one round, no tail), at most GCR_K1_MAX_BLOCKS.
+#define GCR_K1_MAX_BLOCKS 2048
+int gcr_preprocess_resident_blocks(void);  // occupancy x CUs of the current device (cached)
+static inline void gcr_preprocess_grid(int P, int max_blocks, int* nblocks, int* chunk) {
   int nb = (P + 255) / 256;
   if (nb > max_blocks) nb = max_blocks;
   if (nb < 1) nb = 1;

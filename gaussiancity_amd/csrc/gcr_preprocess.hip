@@ -615,6 +615,21 @@ hipError_t gcr_launch_mark_visible(int P, const float* means3D, const float* vie
   return hipGetLastError();
 }
 
+int gcr_preprocess_resident_blocks(void) {
+  static int cached = [] {
+    int dev = 0, cus = 256, per_cu = 4;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_preprocess, 256, 0) != hipSuccess || per_cu < 1)
+      per_cu = 4;
+    int n = per_cu * cus;
+    return n > GCR_K1_MAX_BLOCKS ? GCR_K1_MAX_BLOCKS : (n < 1 ? 1 : n);
+  }();
+  return cached;
+}
+
 hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
   k_preprocess<<<a.nblocks, 256, 0, s>>>(a);
