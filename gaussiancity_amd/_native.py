@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_CSRC, "libgcr_hip.so")
 # Every symbol include/gcr.h declares; tests check that the built library exports all of them.
 EXPORTED_SYMBOLS = (
     "gcr_abi_version", "gcr_last_error", "gcr_geometry_bytes", "gcr_image_bytes",
-    "gcr_binning_bytes", "gcr_get_layout", "gcr_forward_preprocess", "gcr_forward_render",
+    "gcr_binning_bytes", "gcr_get_layout", "gcr_forward", "gcr_forward_preprocess", "gcr_forward_render",
     "gcr_backward", "gcr_mark_visible", "gcr_rasterize_forward", "gcr_set_option",
     "gcr_get_stage_ms",
 )
@@ -67,7 +67,7 @@ class FrameInfo(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("max_tile_instances", C.c_int64)]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 _lib = None
@@ -106,6 +106,10 @@ def lib():
     L.gcr_forward_preprocess.argtypes = [C.POINTER(Camera), C.POINTER(Gaussians), C.c_void_p,
                                          C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                          C.POINTER(FrameInfo), C.c_void_p]
+    L.gcr_forward.restype = C.c_int
+    L.gcr_forward.argtypes = [C.POINTER(Camera), C.POINTER(Gaussians), C.c_void_p, C.c_size_t,
+                              C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
+                              C.c_void_p, C.c_void_p, C.POINTER(FrameInfo), C.c_void_p]
     L.gcr_forward_render.restype = C.c_int
     L.gcr_forward_render.argtypes = [C.POINTER(Camera), C.POINTER(Gaussians), C.c_void_p,
                                      C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,

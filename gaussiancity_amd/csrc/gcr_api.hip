@@ -96,7 +96,7 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   L->geom_block_sums = o;     o = align_up(o + (nblk + 1) * sizeof(uint32_t));
   L->geom_vis_list = o;       o = align_up(o + p * sizeof(uint32_t));
   L->geom_vis_count = o;      o = align_up(o + (nblk + 1) * sizeof(uint32_t));
-  L->geom_num_rendered = o;   o = align_up(o + 2 * sizeof(uint64_t));  // {R, longest tile list}
+  L->geom_num_rendered = o;   o = align_up(o + 4 * sizeof(uint64_t));  // {R, longest tile list, go flag}
   L->geom_total = o;
 
   const size_t npix = (size_t)(W > 0 ? W : 0) * (size_t)(H > 0 ? H : 0);
@@ -116,13 +116,15 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
 
   const size_t r = (size_t)(R > 0 ? R : 0);
   const int end_bit = 32 + (int)gcr_higher_msb((uint32_t)T);
+  // The sorted instance list sits at offset 0 whatever R is, so a forward that carved the
+  // buffer by *capacity* and a backward that carves it by the actual R find it in the same place.
+  L->bin_sorted = (size_t)(gcr_sort_passes(end_bit) & 1);
   o = 0;
+  L->bin_vals[L->bin_sorted] = o;      o = align_up(o + r * sizeof(uint32_t));
+  L->bin_vals[1 - L->bin_sorted] = o;  o = align_up(o + r * sizeof(uint32_t));
   L->bin_keys[0] = o;  o = align_up(o + r * sizeof(uint64_t));
   L->bin_keys[1] = o;  o = align_up(o + r * sizeof(uint64_t));
-  L->bin_vals[0] = o;  o = align_up(o + r * sizeof(uint32_t));
-  L->bin_vals[1] = o;  o = align_up(o + r * sizeof(uint32_t));
   L->bin_hist = o;     o = align_up(o + gcr_sort_hist_bytes((int64_t)r, end_bit));
-  L->bin_sorted = (size_t)(gcr_sort_passes(end_bit) & 1);
   L->bin_total = o;
 }
 
@@ -200,20 +202,16 @@ int gcr_get_stage_ms(float* ms_out, int capacity) {
   return n;
 }
 
-int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* geom,
-                           size_t geom_bytes, void* img, size_t img_bytes, int32_t* radii,
-                           gcr_frame_info* info_host, void* hip_stream) {
-  if (int rc = check_inputs(cam, g)) return rc;
-  if (!info_host) return fail(GCR_ERR_INVALID_ARGUMENT, "info_host is null");
-  info_host->num_rendered = 0;
-  info_host->max_tile_instances = 0;
-  if (g->P == 0) return 0;  // dgr/rasterize_points.cu:71
+// Enqueues K1 + tile counting + tile scan; leaves {R, longest list, go flag} in the geometry
+// buffer (*frame_dev_out).  cap_* only influence the go flag used by speculative launches.
+static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes,
+                              void* img, size_t img_bytes, int32_t* radii, unsigned long long cap_instances,
+                              unsigned long long cap_list, unsigned long long** frame_dev_out, hipStream_t s) {
   if (!geom || !radii || !img) return fail(GCR_ERR_INVALID_ARGUMENT, "geom/img/radii must be non-null");
   gcr_layout L;
   compute_layout(g->P, cam->img_w, cam->img_h, 0, &L);
   if (geom_bytes < L.geom_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "geometry buffer too small");
   if (img_bytes < L.img_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "image buffer too small");
-  hipStream_t s = (hipStream_t)hip_stream;
   char *gb = (char*)geom, *ib = (char*)img;
 
   GcrPreprocessArgs a;
@@ -237,7 +235,8 @@ int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* 
   a.vis_list = (uint32_t*)(gb + L.geom_vis_list);
   a.vis_count = (uint32_t*)(gb + L.geom_vis_count);
   gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &a.nblocks, &a.chunk);
-  unsigned long long* total_and_max = (unsigned long long*)(gb + L.geom_num_rendered);
+  unsigned long long* frame = (unsigned long long*)(gb + L.geom_num_rendered);
+  *frame_dev_out = frame;
   int G = 1;
   const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, a.nblocks, &G);
   uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
@@ -254,7 +253,7 @@ int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* 
     HIP_TRY(gcr_launch_tile_count(T, a.gx, NG, G, a.nblocks, a.chunk, a.vis_list, a.vis_count, a.rec,
                                   (uint32_t*)(ib + L.img_tile_table), cursor, s),
             "tile count");
-    HIP_TRY(gcr_launch_scan_tiles(cursor, 1, ranges, T, total_and_max, s), "tile scan");
+    HIP_TRY(gcr_launch_scan_tiles(cursor, 1, ranges, T, frame, cap_instances, cap_list, s), "tile scan");
   } else {
     {
       StageTimer t(s, ST_PRE);
@@ -263,16 +262,147 @@ int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* 
     }
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
-    HIP_TRY(gcr_launch_scan_tiles(cursor, GCR_CURSOR_STRIDE, ranges, T, total_and_max, s), "tile scan");
+    HIP_TRY(gcr_launch_scan_tiles(cursor, GCR_CURSOR_STRIDE, ranges, T, frame, cap_instances, cap_list, s), "tile scan");
   }
+  return 0;
+}
+
+// Enqueues scatter + per-tile LDS sort + forward blend (the default binning path).
+// `frame_guard` (device {R, max, go}) makes the three kernels no-ops when go == 0.
+static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, void* geom, void* binning, void* img,
+                              int64_t R_layout, int64_t lds_list_capacity, const unsigned long long* frame_guard,
+                              float* out_color, hipStream_t s) {
+  gcr_layout L;
+  compute_layout(g->P, cam->img_w, cam->img_h, R_layout, &L);
+  char *gb = (char*)geom, *bb = (char*)binning, *ib = (char*)img;
+  const int gx = (cam->img_w + GCR_BLOCK_X - 1) / GCR_BLOCK_X;
+  const int gy = (cam->img_h + GCR_BLOCK_Y - 1) / GCR_BLOCK_Y;
+  const int T = gx * gy;
+  const float4* rec = (const float4*)(gb + L.geom_rec);
+  const uint32_t* vis_list = (const uint32_t*)(gb + L.geom_vis_list);
+  const uint32_t* vis_count = (const uint32_t*)(gb + L.geom_vis_count);
+  uint32_t* ranges = (uint32_t*)(ib + L.img_ranges);
+  uint64_t* pairs = (uint64_t*)(bb + L.bin_keys[0]);
+  uint32_t* list = (uint32_t*)(bb + L.bin_vals[L.bin_sorted]);
+  int nblocks, chunk;
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &nblocks, &chunk);
+  if (R_layout > 0) {
+    {
+      StageTimer t(s, ST_EMIT);
+      int G = 1;
+      const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, nblocks, &G);
+      if (NG > 0)
+        HIP_TRY(gcr_launch_tile_scatter(T, gx, NG, G, nblocks, chunk, vis_list, vis_count, rec,
+                                        (uint32_t*)(ib + L.img_tile_table), ranges, pairs, frame_guard, s),
+                "tile scatter");
+      else
+        HIP_TRY(gcr_launch_scatter_instances(nblocks, chunk, vis_list, vis_count, rec, gx,
+                                             (uint32_t*)(ib + L.img_tile_cursor), pairs, s),
+                "scatter instances");
+    }
+    if (int rc = debug_sync(cam, s, "scatter instances")) return rc;
+    {
+      StageTimer t(s, ST_SORT);
+      HIP_TRY(gcr_launch_tile_sort(ranges, T, pairs, list, lds_list_capacity, frame_guard, s), "tile sort");
+    }
+    if (int rc = debug_sync(cam, s, "tile sort")) return rc;
+  }
+  GcrBlendArgs b;
+  memset(&b, 0, sizeof(b));
+  b.ranges = ranges;
+  b.list = list;
+  b.rec = rec;
+  b.W = cam->img_w; b.H = cam->img_h; b.gx = gx; b.gy = gy;
+  b.bg = cam->bg;
+  b.final_T = (float*)(ib + L.img_final_T);
+  b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
+  b.out_color = out_color;
+  b.frame = frame_guard;
+  {
+    StageTimer t(s, ST_BLEND_FWD);
+    HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, s), "blend forward");
+  }
+  return debug_sync(cam, s, "blend forward");
+}
+
+// pinned landing zone + event for the asynchronous {R, max, go} read-back (per host thread)
+struct FrameReadback {
+  unsigned long long* pinned = nullptr;
+  hipEvent_t ev = nullptr;
+  int ensure() {
+    if (!pinned && hipHostMalloc((void**)&pinned, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
+      return fail(GCR_ERR_DEVICE, "hipHostMalloc for the frame read-back failed");
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+      return fail(GCR_ERR_DEVICE, "hipEventCreate for the frame read-back failed");
+    return 0;
+  }
+};
+thread_local FrameReadback g_readback;
+
+int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* geom,
+                           size_t geom_bytes, void* img, size_t img_bytes, int32_t* radii,
+                           gcr_frame_info* info_host, void* hip_stream) {
+  if (int rc = check_inputs(cam, g)) return rc;
+  if (!info_host) return fail(GCR_ERR_INVALID_ARGUMENT, "info_host is null");
+  info_host->num_rendered = 0;
+  info_host->max_tile_instances = 0;
+  if (g->P == 0) return 0;  // dgr/rasterize_points.cu:71
+  hipStream_t s = (hipStream_t)hip_stream;
+  unsigned long long* frame = nullptr;
+  if (int rc = enqueue_preprocess(cam, g, geom, geom_bytes, img, img_bytes, radii, ~0ull, ~0ull, &frame, s)) return rc;
   unsigned long long r[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(r, total_and_max, sizeof(r), hipMemcpyDeviceToHost, s), "num_rendered copy");
+  HIP_TRY(hipMemcpyAsync(r, frame, sizeof(r), hipMemcpyDeviceToHost, s), "num_rendered copy");
   HIP_TRY(hipStreamSynchronize(s), "num_rendered sync");  // cr/rasterizer_impl.cu:236-238
   if (r[0] > 0x7fffffffull)
     return fail(GCR_ERR_OVERFLOW, "num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)");
   info_host->num_rendered = (int64_t)r[0];
   info_host->max_tile_instances = (int64_t)r[1];
   return 0;
+}
+
+int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes, void* binning,
+                size_t binning_bytes, int64_t binning_capacity, int64_t tile_list_capacity, void* img,
+                size_t img_bytes, int32_t* radii, float* out_color, gcr_frame_info* info_host, void* hip_stream) {
+  if (int rc = check_inputs(cam, g)) return rc;
+  if (!info_host) return fail(GCR_ERR_INVALID_ARGUMENT, "info_host is null");
+  info_host->num_rendered = 0;
+  info_host->max_tile_instances = 0;
+  if (g->P == 0) return 0;
+  if (!out_color) return fail(GCR_ERR_INVALID_ARGUMENT, "out_color is null");
+  if (binning_capacity < 0 || binning_capacity > 0x7fffffffll)
+    return fail(GCR_ERR_INVALID_ARGUMENT, "binning_capacity out of range");
+  if (binning_capacity > 0 && (!binning || binning_bytes < gcr_binning_bytes(binning_capacity, cam->img_w, cam->img_h)))
+    return fail(GCR_ERR_BUFFER_TOO_SMALL, "binning buffer smaller than gcr_binning_bytes(binning_capacity)");
+  if (int rc = g_readback.ensure()) return rc;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const bool speculate = binning_capacity > 0 && !g_force_radix.load() && !cam->debug;
+  unsigned long long cap_list = (unsigned long long)gcr_tile_sort_capacity();
+  if (tile_list_capacity > 0 && (unsigned long long)tile_list_capacity < cap_list) {
+    cap_list = 64;  // round the guess up to a power of two: that is what the LDS sort allocates
+    while (cap_list < (unsigned long long)tile_list_capacity) cap_list <<= 1;
+  }
+  unsigned long long* frame = nullptr;
+  if (int rc = enqueue_preprocess(cam, g, geom, geom_bytes, img, img_bytes, radii,
+                                  speculate ? (unsigned long long)binning_capacity : 0ull, cap_list, &frame, s))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(g_readback.pinned, frame, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s),
+          "frame info copy");
+  HIP_TRY(hipEventRecord(g_readback.ev, s), "frame info event");
+  if (speculate) {
+    // Everything else of the frame is enqueued before the host knows R: the kernels read the
+    // tile ranges from device memory and are vetoed by frame[2] if the capacity guess was short.
+    if (int rc = enqueue_render_lds(cam, g, geom, binning, img, binning_capacity, (int64_t)cap_list, frame,
+                                    out_color, s))
+      return rc;
+  }
+  HIP_TRY(hipEventSynchronize(g_readback.ev), "frame info sync");  // the one host wait of the frame
+  const unsigned long long R = g_readback.pinned[0], mx = g_readback.pinned[1], go = g_readback.pinned[2];
+  if (R > 0x7fffffffull)
+    return fail(GCR_ERR_OVERFLOW, "num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)");
+  info_host->num_rendered = (int64_t)R;
+  info_host->max_tile_instances = (int64_t)mx;
+  if (speculate && go) return 0;
+  return 1;  // GCR_RETRY_RENDER: call gcr_forward_render with a binning buffer sized for info_host
 }
 
 int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes,
@@ -291,12 +421,19 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   if (img_bytes < L.img_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "image buffer too small");
   if (R > 0 && binning_bytes < L.bin_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "binning buffer too small");
   hipStream_t s = (hipStream_t)hip_stream;
+  const bool lds_sort = !g_force_radix.load() && info->max_tile_instances <= gcr_tile_sort_capacity();
+  if (R == 0 || lds_sort)
+    return enqueue_render_lds(cam, g, geom, binning, img, R, info->max_tile_instances, nullptr, out_color, s);
+
+  // Fallback (a tile list longer than the LDS capacity, or "force_radix"): the reference's own
+  // scheme -- emit tile|depth keys in index order, stable global radix sort, boundary scan.
   char *gb = (char*)geom, *bb = (char*)binning, *ib = (char*)img;
   const int gx = (cam->img_w + GCR_BLOCK_X - 1) / GCR_BLOCK_X;
   const int gy = (cam->img_h + GCR_BLOCK_Y - 1) / GCR_BLOCK_Y;
   const int T = gx * gy;
   const float4* rec = (const float4*)(gb + L.geom_rec);
   uint32_t* tiles_touched = (uint32_t*)(gb + L.geom_tiles_touched);
+  uint32_t* block_sums = (uint32_t*)(gb + L.geom_block_sums);
   const uint32_t* vis_list = (const uint32_t*)(gb + L.geom_vis_list);
   const uint32_t* vis_count = (const uint32_t*)(gb + L.geom_vis_count);
   int nblocks, chunk;
@@ -305,63 +442,32 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   uint64_t* k1 = (uint64_t*)(bb + L.bin_keys[1]);
   uint32_t* v0 = (uint32_t*)(bb + L.bin_vals[0]);
   uint32_t* v1 = (uint32_t*)(bb + L.bin_vals[1]);
-  uint32_t* ranges = (uint32_t*)(ib + L.img_ranges);  // already valid: written by k_scan_tiles
-  const int sorted_half = (int)L.bin_sorted;
-  uint32_t* list = sorted_half ? v1 : v0;
-  if (R > 0) {
-    const bool lds_sort = !g_force_radix.load() && info->max_tile_instances <= gcr_tile_sort_capacity();
-    if (lds_sort) {
-      // counting-sort binning: scatter into tile segments, then sort every segment in LDS
-      {
-        StageTimer t(s, ST_EMIT);
-        int G = 1;
-        const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, nblocks, &G);
-        if (NG > 0)
-          HIP_TRY(gcr_launch_tile_scatter(T, gx, NG, G, nblocks, chunk, vis_list, vis_count, rec,
-                                          (uint32_t*)(ib + L.img_tile_table), ranges, k0, s),
-                  "tile scatter");
-        else
-          HIP_TRY(gcr_launch_scatter_instances(nblocks, chunk, vis_list, vis_count, rec, gx,
-                                               (uint32_t*)(ib + L.img_tile_cursor), k0, s),
-                  "scatter instances");
-      }
-      if (int rc = debug_sync(cam, s, "scatter instances")) return rc;
-      {
-        StageTimer t(s, ST_SORT);
-        HIP_TRY(gcr_launch_tile_sort(ranges, T, k0, list, info->max_tile_instances, s), "tile sort");
-      }
-      if (int rc = debug_sync(cam, s, "tile sort")) return rc;
-    } else {
-      // fallback (a tile list longer than the LDS capacity): the reference's own scheme --
-      // emit tile|depth keys in index order, stable global radix sort, boundary scan.
-      int half = sorted_half;
-      {
-        StageTimer t(s, ST_EMIT);
-        uint32_t* block_sums = (uint32_t*)(gb + L.geom_block_sums);
-        unsigned long long* scratch_total = (unsigned long long*)(bb + L.bin_hist);
-        HIP_TRY(gcr_launch_tiles_touched(g->P, nblocks, chunk, vis_list, vis_count, rec, tiles_touched, block_sums, s),
-                "tiles touched");
-        HIP_TRY(gcr_launch_scan_block_sums(block_sums, (g->P + 255) / 256, scratch_total, s), "scan");
-        HIP_TRY(gcr_launch_emit(g->P, tiles_touched, block_sums, rec, gx, k0, v0, s), "emit");
-      }
-      if (int rc = debug_sync(cam, s, "emit")) return rc;
-      {
-        StageTimer t(s, ST_SORT);
-        const int end_bit = 32 + (int)gcr_higher_msb((uint32_t)T);  // cr/rasterizer_impl.cu:252
-        HIP_TRY(gcr_launch_sort(k0, v0, k1, v1, R, end_bit, (uint32_t*)(bb + L.bin_hist), &half, s), "sort");
-      }
-      if (int rc = debug_sync(cam, s, "sort")) return rc;
-      {
-        StageTimer t(s, ST_RANGES);
-        HIP_TRY(gcr_launch_tile_ranges(half ? k1 : k0, R, ranges, T, s), "tile ranges");
-      }
-      if (int rc = debug_sync(cam, s, "tile ranges")) return rc;
-    }
+  uint32_t* ranges = (uint32_t*)(ib + L.img_ranges);
+  int half = (int)L.bin_sorted;
+  {
+    StageTimer t(s, ST_EMIT);
+    unsigned long long* scratch_total = (unsigned long long*)(bb + L.bin_hist);
+    HIP_TRY(gcr_launch_tiles_touched(g->P, nblocks, chunk, vis_list, vis_count, rec, tiles_touched, block_sums, s),
+            "tiles touched");
+    HIP_TRY(gcr_launch_scan_block_sums(block_sums, (g->P + 255) / 256, scratch_total, s), "scan");
+    HIP_TRY(gcr_launch_emit(g->P, tiles_touched, block_sums, rec, gx, k0, v0, s), "emit");
   }
+  if (int rc = debug_sync(cam, s, "emit")) return rc;
+  {
+    StageTimer t(s, ST_SORT);
+    const int end_bit = 32 + (int)gcr_higher_msb((uint32_t)T);  // cr/rasterizer_impl.cu:252
+    HIP_TRY(gcr_launch_sort(k0, v0, k1, v1, R, end_bit, (uint32_t*)(bb + L.bin_hist), &half, s), "sort");
+  }
+  if (int rc = debug_sync(cam, s, "sort")) return rc;
+  {
+    StageTimer t(s, ST_RANGES);
+    HIP_TRY(gcr_launch_tile_ranges(half ? k1 : k0, R, ranges, T, s), "tile ranges");
+  }
+  if (int rc = debug_sync(cam, s, "tile ranges")) return rc;
   GcrBlendArgs b;
   memset(&b, 0, sizeof(b));
   b.ranges = ranges;
-  b.list = list;
+  b.list = half ? v1 : v0;
   b.rec = rec;
   b.W = cam->img_w; b.H = cam->img_h; b.gx = gx; b.gy = gy;
   b.bg = cam->bg;

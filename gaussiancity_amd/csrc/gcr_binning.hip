@@ -70,9 +70,11 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
                                                            const float4* __restrict__ rec,
                                                            uint32_t* __restrict__ table,
                                                            const uint32_t* __restrict__ ranges,
-                                                           uint64_t* __restrict__ pairs) {
+                                                           uint64_t* __restrict__ pairs,
+                                                           const unsigned long long* __restrict__ frame) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
   uint32_t* cnt = reinterpret_cast<uint32_t*>(gcr_smem);  // [T]
+  if (SCATTER && frame != nullptr && frame[2] == 0ull) return;  // speculative launch vetoed
   __shared__ uint32_t pre[TT_MAX_GROUP + 1];              // prefix of the group's list lengths
   const int tid = threadIdx.x;
   uint32_t* __restrict__ row = table + (size_t)blockIdx.x * T;
@@ -193,9 +195,11 @@ __global__ __launch_bounds__(256) void k_scatter_instances(int chunk, const uint
 // power of two with ~0), then the Gaussian indices (low 32 bits) go to the sorted list.
 __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ ranges,
                                                    const uint64_t* __restrict__ pairs,
-                                                   uint32_t* __restrict__ list) {
+                                                   uint32_t* __restrict__ list,
+                                                   const unsigned long long* __restrict__ frame) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
   uint64_t* s = reinterpret_cast<uint64_t*>(gcr_smem);
+  if (frame != nullptr && frame[2] == 0ull) return;  // speculative launch vetoed
   const int tid = threadIdx.x;
   const uint32_t r0 = ranges[2 * blockIdx.x], r1 = ranges[2 * blockIdx.x + 1];
   const int n = (int)(r1 - r0);
@@ -396,18 +400,20 @@ hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, i
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
   k_tile_table<false><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(T, gx, G, nblocks_k1, chunk, vis_list,
-                                                                         vis_count, rec, table, nullptr, nullptr);
+                                                                         vis_count, rec, table, nullptr, nullptr,
+                                                                         nullptr);
   k_table_colscan<<<(T + 63) / 64, 1024, 0, s>>>(table, NG, T, totals);
   return hipGetLastError();
 }
 
 hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                    const uint32_t* vis_count, const float4* rec, uint32_t* table,
-                                   const uint32_t* ranges, uint64_t* pairs, hipStream_t s) {
+                                   const uint32_t* ranges, uint64_t* pairs, const unsigned long long* frame,
+                                   hipStream_t s) {
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
   k_tile_table<true><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(T, gx, G, nblocks_k1, chunk, vis_list,
-                                                                        vis_count, rec, table, ranges, pairs);
+                                                                        vis_count, rec, table, ranges, pairs, frame);
   return hipGetLastError();
 }
 
@@ -460,11 +466,11 @@ hipError_t gcr_launch_tiles_touched(int P, int nblocks, int chunk, const uint32_
 int gcr_tile_sort_capacity(void) { return 4096; }  // 32 KiB of LDS per workgroup at most
 
 hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, const uint64_t* pairs, uint32_t* list,
-                                int64_t max_tile_instances, hipStream_t s) {
+                                int64_t max_tile_instances, const unsigned long long* frame, hipStream_t s) {
   if (T <= 0) return hipSuccess;
   size_t n2 = 2;
   while ((int64_t)n2 < max_tile_instances) n2 <<= 1;
-  k_tile_sort<<<T, 256, n2 * sizeof(uint64_t), s>>>(ranges, pairs, list);
+  k_tile_sort<<<T, 256, n2 * sizeof(uint64_t), s>>>(ranges, pairs, list, frame);
   return hipGetLastError();
 }
 

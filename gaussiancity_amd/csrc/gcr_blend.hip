@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   __shared__ float2 sC[CHUNK];    // b, pmin
   __shared__ uint32_t sM[CHUNK];  // quadrant mask
 
+  if (a.frame != nullptr && a.frame[2] == 0ull) return;  // speculative launch vetoed
   const int tile = blockIdx.x;
   const int tx = tile % a.gx, ty = tile / a.gx;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

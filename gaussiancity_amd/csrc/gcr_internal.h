@@ -68,6 +68,7 @@ struct GcrBlendArgs {
   float* final_T;
   uint32_t* n_contrib;
   float* out_color;         // fwd
+  const unsigned long long* frame;  // optional device guard: frame[2]==0 -> kernel does nothing
   const float* dL_dpix;     // bwd
   float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor;  // bwd
 };
@@ -87,20 +88,22 @@ hipError_t gcr_launch_emit(int P, const uint32_t* tiles_touched, const uint32_t*
                            hipStream_t s);
 // Fast binning path: tile counts -> ranges/cursors (+ total, max), scatter, per-tile LDS sort.
 hipError_t gcr_launch_scan_tiles(uint32_t* tile_cursor, int stride, uint32_t* ranges, int T,
-                                 unsigned long long* total_and_max, hipStream_t s);
+                                 unsigned long long* frame, unsigned long long cap_instances,
+                                 unsigned long long cap_list, hipStream_t s);
 int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out);
 hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,
                                  uint32_t* totals, hipStream_t s);
 hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                    const uint32_t* vis_count, const float4* rec, uint32_t* table,
-                                   const uint32_t* ranges, uint64_t* pairs, hipStream_t s);
+                                   const uint32_t* ranges, uint64_t* pairs, const unsigned long long* frame,
+                                   hipStream_t s);
 hipError_t gcr_launch_scatter_instances(int nblocks, int chunk, const uint32_t* vis_list,
                                         const uint32_t* vis_count, const float4* rec, int gx,
                                         uint32_t* tile_cursor, uint64_t* pairs, hipStream_t s);
 int gcr_tile_sort_capacity(void);  // longest per-tile list the LDS sort accepts
 hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, const uint64_t* pairs, uint32_t* list,
-                                int64_t max_tile_instances, hipStream_t s);
+                                int64_t max_tile_instances, const unsigned long long* frame, hipStream_t s);
 // Stable LSD radix sort of R (u64 key, u32 value) pairs on bits [0, end_bit).  Ping-pongs
 // between (k0,v0) and (k1,v1); returns in *sorted_half which half holds the result.
 size_t gcr_sort_hist_bytes(int64_t R, int end_bit);

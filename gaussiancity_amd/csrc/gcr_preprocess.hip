@@ -326,53 +326,65 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
   if (tid == 1023) *total = part[1023];
 }
 
-// Tile-count scan for the counting-sort binning: in: cursor[t] = #instances of tile t (K1's
-// atomics); out: ranges[t] = [start,end) (what identifyTileRanges produces upstream,
-// cr/rasterizer_impl.cu:104-124), cursor[t] = start (scatter write cursor),
-// total_and_max[0] = num_rendered, [1] = longest tile list.  One 1024-thread block, coalesced
-// 1024-tile chunks (counters are GCR_CURSOR_STRIDE apart): T is small.
+// Tile-count scan for the counting-sort binning: in: cursor[t*stride] = #instances of tile t;
+// out: ranges[t] = [start,end) (what identifyTileRanges produces upstream,
+// cr/rasterizer_impl.cu:104-124), cursor[t*stride] = start, frame[0] = num_rendered,
+// frame[1] = longest tile list, frame[2] = 1 if the speculatively enqueued rest of the frame may
+// run (num_rendered <= cap_instances and longest list <= cap_list), else 0.
+// One 1024-thread block; thread i owns the contiguous slice [i*per, (i+1)*per) so that all its
+// loads are in flight at once; wave-shuffle scan of the 1024 slice sums -> two barriers in total.
 __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ cursor, int stride,
                                                      uint32_t* __restrict__ ranges, int T,
-                                                     unsigned long long* __restrict__ total_and_max) {
+                                                     unsigned long long* __restrict__ frame,
+                                                     unsigned long long cap_instances,
+                                                     unsigned long long cap_list) {
   __shared__ unsigned long long wsum[16];
   __shared__ uint32_t wmax[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  unsigned long long running = 0;
+  const int per = (T + 1023) / 1024;
+  const int beg = min(T, tid * per), end = min(T, beg + per);
+  unsigned long long s = 0;
   uint32_t mx = 0;
-  for (int base = 0; base < T; base += 1024) {
-    const int i = base + tid;
-    const uint32_t c = i < T ? cursor[(size_t)i * stride] : 0u;
+  for (int i = beg; i < end; i++) {
+    const uint32_t c = cursor[(size_t)i * stride];
+    s += c;
     mx = c > mx ? c : mx;
-    const uint32_t incl = gcr_wave_incl_scan_u32(c, lane);
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    unsigned long long before = 0, total = 0;
+  }
+  // inclusive scan of the slice sums across the wave (64-bit), then across the 16 waves
+  unsigned long long incl = s;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const unsigned long long v = wsum[k];
-      if (k < w) before += v;
-      total += v;
-    }
-    const unsigned long long st64 = running + before + (incl - c);
-    if (i < T) {
-      // saturate: an overflowing frame is rejected on the host (num_rendered > 2^31-1)
-      const unsigned long long e64 = st64 + c;
-      const uint32_t st = st64 > 0xffffffffull ? 0xffffffffu : (uint32_t)st64;
-      ranges[2 * i + 0] = st;
-      ranges[2 * i + 1] = e64 > 0xffffffffull ? 0xffffffffu : (uint32_t)e64;
-      cursor[(size_t)i * stride] = st;
-    }
-    running += total;
-    __syncthreads();
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
   }
   const uint32_t m = gcr_wave_max_u32(mx);
+  if (lane == 63) wsum[w] = incl;
   if (lane == 0) wmax[w] = m;
   __syncthreads();
+  unsigned long long before = 0, total = 0;
+  uint32_t mm = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const unsigned long long v = wsum[k];
+    if (k < w) before += v;
+    total += v;
+    mm = wmax[k] > mm ? wmax[k] : mm;
+  }
+  unsigned long long run = before + incl - s;
+  for (int i = beg; i < end; i++) {
+    const uint32_t c = cursor[(size_t)i * stride];
+    // saturate: an overflowing frame is rejected on the host (num_rendered > 2^31-1)
+    const unsigned long long e64 = run + c;
+    const uint32_t st = run > 0xffffffffull ? 0xffffffffu : (uint32_t)run;
+    ranges[2 * i + 0] = st;
+    ranges[2 * i + 1] = e64 > 0xffffffffull ? 0xffffffffu : (uint32_t)e64;
+    cursor[(size_t)i * stride] = st;
+    run = e64;
+  }
   if (tid == 0) {
-    uint32_t mm = 0;
-    for (int k = 0; k < 16; k++) mm = wmax[k] > mm ? wmax[k] : mm;
-    total_and_max[0] = running;
-    total_and_max[1] = mm;
+    frame[0] = total;
+    frame[1] = mm;
+    frame[2] = (total <= cap_instances && (unsigned long long)mm <= cap_list) ? 1ull : 0ull;
   }
 }
 
@@ -643,8 +655,9 @@ hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long
 }
 
 hipError_t gcr_launch_scan_tiles(uint32_t* tile_cursor, int stride, uint32_t* ranges, int T,
-                                 unsigned long long* total_and_max, hipStream_t s) {
-  k_scan_tiles<<<1, 1024, 0, s>>>(tile_cursor, stride, ranges, T, total_and_max);
+                                 unsigned long long* frame, unsigned long long cap_instances,
+                                 unsigned long long cap_list, hipStream_t s) {
+  k_scan_tiles<<<1, 1024, 0, s>>>(tile_cursor, stride, ranges, T, frame, cap_instances, cap_list);
   return hipGetLastError();
 }
 

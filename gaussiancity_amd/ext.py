@@ -19,6 +19,11 @@ from . import _native as N
 
 NUM_CHANNELS = 3  # cr/config.h:15
 
+# num_rendered of the last frame per (device, P, W, H): the next frame's binning buffer is
+# allocated for 1.5x that before the frame starts, which lets gcr_forward enqueue the whole frame
+# without a mid-frame host stall.  A wrong guess only costs the staged path for that frame.
+_capacity_hint = {}
+
 
 def _dev_f32(t, name, device):
     """Return (tensor_or_None, data_ptr_or_None); numel()==0 is the reference's 'absent'."""
@@ -108,16 +113,23 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         geom = torch.empty((L.gcr_geometry_bytes(P),), **byte)
         img = torch.empty((L.gcr_image_bytes(W, H),), **byte)
         info = N.FrameInfo()
-        N.check(L.gcr_forward_preprocess(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
-                                         img.data_ptr(), img.numel(), radii.data_ptr(),
-                                         C.byref(info), stream),
-                "gcr_forward_preprocess")
+        key = (device.index, P, W, H)
+        capacity, list_cap = _capacity_hint.get(key, (0, 0))
+        binning = torch.empty((L.gcr_binning_bytes(capacity, W, H) if capacity else 0,), **byte)
+        rc = N.check(L.gcr_forward(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
+                                   binning.data_ptr() if capacity else None, binning.numel(), capacity,
+                                   list_cap, img.data_ptr(), img.numel(), radii.data_ptr(), out_color.data_ptr(),
+                                   C.byref(info), stream),
+                     "gcr_forward")
         R = int(info.num_rendered)
-        binning = torch.empty((L.gcr_binning_bytes(R, W, H),), **byte)
-        N.check(L.gcr_forward_render(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
-                                     binning.data_ptr(), binning.numel(), img.data_ptr(),
-                                     img.numel(), C.byref(info), out_color.data_ptr(), stream),
-                "gcr_forward_render")
+        if rc == 1:  # GCR_RETRY_RENDER: no/too small a guess, or a tile list beyond the LDS sort
+            binning = torch.empty((L.gcr_binning_bytes(R, W, H),), **byte)
+            N.check(L.gcr_forward_render(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
+                                         binning.data_ptr(), binning.numel(), img.data_ptr(),
+                                         img.numel(), C.byref(info), out_color.data_ptr(), stream),
+                    "gcr_forward_render")
+        longest = int(info.max_tile_instances)
+        _capacity_hint[key] = (R + R // 2 + 4096, longest + longest // 2 + 64)
         del keep_c, keep_g
     return R, out_color, radii, geom, binning, img
 

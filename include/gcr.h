@@ -12,6 +12,8 @@
  * gcr_rasterize_forward            CudaRasterizer::Rasterizer::forward   cr/rasterizer.h:25-37
  *                                  (== cr/rasterizer_impl.cu:178-283, std::function resize
  *                                  callbacks become C callbacks)
+ * gcr_forward                      the same forward with every launch enqueued before the host
+ *                                  learns num_rendered (no GPU idle gap at the sync)
  * gcr_forward_preprocess +         the same forward split at its one host sync
  *   gcr_forward_render             (cr/rasterizer_impl.cu:236-238) so the caller allocates
  *                                  the binning buffer itself (dgr/rasterize_points.cu:27-33)
@@ -40,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GCR_ABI_VERSION 2
+#define GCR_ABI_VERSION 3
 #define GCR_BLOCK_X 16 /* cr/config.h:16 */
 #define GCR_BLOCK_Y 16 /* cr/config.h:17 */
 #define GCR_NUM_CHANNELS 3 /* cr/config.h:15 */
@@ -147,6 +149,25 @@ int gcr_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout *out);
 int gcr_forward_preprocess(const gcr_camera *cam, const gcr_gaussians *g, void *geom,
                            size_t geom_bytes, void *img, size_t img_bytes, int32_t *radii,
                            gcr_frame_info *info_host, void *hip_stream);
+
+/* Whole forward in ONE call without a mid-frame host stall.  `binning` must hold
+ * gcr_binning_bytes(binning_capacity) bytes; binning_capacity is the caller's guess of
+ * num_rendered (e.g. 1.5 x the previous frame's value; 0 = no guess) and tile_list_capacity its
+ * guess of the longest per-tile list (sizes the LDS of the per-tile sort; 0 = the maximum the
+ * LDS sort supports).  All kernels of the frame
+ * are enqueued at once -- they take the tile ranges from device memory and a device-side flag
+ * vetoes them if the guess was too small -- and the host waits only for the 24-byte frame
+ * summary, which lands in pinned memory as soon as K2 is done.
+ * Returns 0: frame complete, *info_host valid.
+ * Returns 1 (GCR_RETRY_RENDER): *info_host valid, nothing rendered yet (guess too small, a
+ *   tile list longer than the LDS sort capacity, or "force_radix"): allocate
+ *   gcr_binning_bytes(info_host->num_rendered) and call gcr_forward_render.
+ * Returns <0: error. */
+#define GCR_RETRY_RENDER 1
+int gcr_forward(const gcr_camera *cam, const gcr_gaussians *g, void *geom, size_t geom_bytes,
+                void *binning, size_t binning_bytes, int64_t binning_capacity,
+                int64_t tile_list_capacity, void *img, size_t img_bytes, int32_t *radii,
+                float *out_color, gcr_frame_info *info_host, void *hip_stream);
 
 /* K3 (instance emit) + K4 (depth sort inside every tile, ties in ascending Gaussian index ==
  * the reference's stable radix sort by tile|depth) + K5 (tile ranges) + K6 (blend).

@@ -189,8 +189,31 @@ def test_tile_list_longer_than_lds_capacity(oracle_mod, cuda_device):
     sc = scenes.blob_scene(P, 61, 0, spread=2.0, smin=0.5, smax=2.0, omin=0.01, omax=0.05)
     fr = _frame(oracle_mod, rs, sc, use_sh=False)
     assert (fr.ranges[:, 1] - fr.ranges[:, 0]).max() > 4096
-    args, out = G.run_forward(rs, sc, cuda_device, use_sh=False)
-    _check_forward(fr, G.decode(P, W, H, out), P, False)
+    for _ in range(2):  # second call carries a capacity guess; the device flag must veto it
+        args, out = G.run_forward(rs, sc, cuda_device, use_sh=False)
+        _check_forward(fr, G.decode(P, W, H, out), P, False)
+
+
+def test_fused_forward_speculation_and_retry(oracle_mod, cuda_device):
+    """gcr_forward enqueues the whole frame on a capacity guess: first call (no guess) goes
+    through the staged path, the second speculates, a deliberately short guess must be vetoed on
+    the device and retried -- all three give the oracle's bits."""
+    from gaussiancity_amd import ext
+    P, W, H = 3500, 176, 128
+    rs = scenes.camera(W, H)._replace(sh_degree=2)
+    sc = scenes.blob_scene(P, 71, 2)
+    fr = _frame(oracle_mod, rs, sc)
+    key = (cuda_device.index, P, W, H)
+    ext._capacity_hint.pop(key, None)
+    for mode in ("no_guess", "speculative", "short_guess", "speculative_again"):
+        if mode == "short_guess":
+            ext._capacity_hint[key] = (max(fr.R // 3, 16), 64)
+        args, out = G.run_forward(rs, sc, cuda_device)
+        _check_forward(fr, G.decode(P, W, H, out), P, True)
+        assert ext._capacity_hint[key][0] >= fr.R
+    dpix = np.random.default_rng(4).normal(size=(3, H, W)).astype(np.float32)
+    _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device),
+                 ["dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"])
 
 
 def test_autograd_api_matches_oracle(oracle_mod, cuda_device):
