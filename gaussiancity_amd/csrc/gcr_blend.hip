@@ -26,6 +26,16 @@ namespace {
 
 constexpr int CHUNK = 256;
 
+// One staged list entry: 48 bytes so that a single address (j * 48) + immediate offsets serves
+// the three wave-uniform (broadcast) reads of the blend loop.
+struct __attribute__((aligned(16))) StagedEntry {
+  float4 a;     // x, y, conic.x, conic.y
+  float4 b;     // conic.z, opacity, r, g
+  float2 c;     // b, pmin
+  uint32_t id;  // Gaussian index (backward only)
+  uint32_t mask;  // quadrant mask
+};
+
 // pmin such that power < pmin  =>  opacity*exp(power) < 1/255 with a 1e-3 safety margin.
 // Clamped to >= -87 so the blend loops may use the guard-free exponential (see gcr_device.h).
 GCR_DEV float gcr_alpha_skip_bound(float opacity) {
@@ -59,12 +69,19 @@ GCR_DEV float blend_exp(float x) {
 }
 
 // ------------------------------------------------------------------------------------- K6
+// Scalar-unit budget: a CU has ONE scalar ALU for its four SIMDs, and the first versions of this
+// loop were bound by it (exec-mask bookkeeping of nested branches, 64-bit bit scans, lane masks
+// carried in SGPRs).  Hence
+//   * each wave first compacts the indices of the chunk entries that can touch its quadrant into
+//     a private LDS list, so the hot loop is a plain counted loop;
+//   * the body is branch-free (selects), with one wave-uniform skip;
+//   * "done" is folded into a working transmittance Tw that drops to 0 when the pixel is finished
+//     (T*(1-a) < 1e-4 upstream): test_T = Tw*(1-a) is then 0 and the entry can never be `use`d;
+//     Tout keeps the value upstream leaves in T.
 template <bool FAST_EXP>
 __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
-  __shared__ float4 sA[CHUNK];    // x, y, conic.x, conic.y
-  __shared__ float4 sB[CHUNK];    // conic.z, opacity, r, g
-  __shared__ float2 sC[CHUNK];    // b, pmin
-  __shared__ uint32_t sM[CHUNK];  // quadrant mask
+  __shared__ StagedEntry sE[CHUNK];
+  __shared__ uint16_t sIdx[4][CHUNK];  // per-wave compacted entry indices
 
   if (a.frame != nullptr && a.frame[2] == 0ull) return;  // speculative launch vetoed
   const int tile = blockIdx.x;
@@ -77,14 +94,15 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   const float tile_x0 = (float)(tx * GCR_TILE_X), tile_y0 = (float)(ty * GCR_TILE_Y);
   const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
   const int total = (int)(r1 - r0);
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-  bool done = !inside;
-  float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+  float Tw = inside ? 1.0f : 0.0f;  // working transmittance, 0 == pixel finished
+  float Tout = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
   uint32_t last_contributor = 0;
 
   for (int base = 0; base < total; base += CHUNK) {
     // block-wide vote (cr/forward.cu:284-286); also fences the previous chunk's LDS reads
-    if (__syncthreads_count(done) == 256) break;
+    if (__syncthreads_count(Tw == 0.0f) == 256) break;
     const int n = min(CHUNK, total - base);
     uint32_t my_mask = 0;
     if (tid < n) {
@@ -92,61 +110,59 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
       const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
       const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
       const float pmin = gcr_alpha_skip_bound(q1.y);
-      sA[tid] = q0;
-      sB[tid] = q1;
-      sC[tid] = make_float2(q2.x, pmin);
+      sE[tid].a = q0;
+      sE[tid].b = q1;
+      sE[tid].c = make_float2(q2.x, pmin);
       my_mask = gcr_quadrant_mask(q0.x, q0.y, q0.z, q0.w, q1.x, pmin, tile_x0, tile_y0);
     }
-    sM[tid] = my_mask;
+    sE[tid].mask = my_mask;
     __syncthreads();
-    if (__ballot(!done) == 0ull) continue;  // this wave's quadrant is finished; keep voting
-#pragma unroll 1
+    if (__ballot(Tw != 0.0f) == 0ull) continue;  // this wave's quadrant is finished; keep voting
+    // compact this wave's entries (ascending list order is preserved)
+    int cnt = 0;
+#pragma unroll
     for (int k = 0; k < 4; k++) {
-      uint64_t m = __ballot((sM[k * 64 + lane] >> w) & 1u);
-      while (m != 0ull) {
-        const int j = k * 64 + __builtin_ctzll(m);
-        m &= m - 1ull;
-        // Branch-free body (the scalar unit, one per CU, was the bottleneck of the branchy
-        // version: ~45 SALU instructions per entry for exec-mask bookkeeping).  A lane that
-        // upstream would `continue` keeps its state through selects.
-        const float4 qa = sA[j];
-        const float2 qc = sC[j];
-        const float4 qb = sB[j];
-        const float dx = qa.x - pixx, dy = qa.y - pixy;
-        const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
-        const bool in_range = !done && !(power > 0.0f) && !(power < qc.y);
-        if (__ballot(in_range) != 0ull) {  // wave-uniform
-          const float pw = gcr_max(-87.0f, gcr_min(power, 0.0f));  // keeps masked lanes finite
-          const float araw = gcr_min(0.99f, qb.y * blend_exp<FAST_EXP>(pw));
-          const bool valid = in_range && !(araw < 1.0f / 255.0f);
-          const float test_T = T * (1 - araw);
-          const bool kill = valid && test_T < 0.0001f;
-          const bool use = valid && !kill;
-          const float n0 = __builtin_fmaf(qb.z * araw, T, C0);
-          const float n1 = __builtin_fmaf(qb.w * araw, T, C1);
-          const float n2 = __builtin_fmaf(qc.x * araw, T, C2);
-          C0 = use ? n0 : C0;
-          C1 = use ? n1 : C1;
-          C2 = use ? n2 : C2;
-          T = use ? test_T : T;
-          last_contributor = use ? (uint32_t)(base + j + 1) : last_contributor;
-          done = done || kill;
-          if (__ballot(!done) == 0ull) {
-            m = 0ull;
-            k = 4;
-          }
-        }
-      }
+      const int jj = k * 64 + lane;
+      const bool rel = (sE[jj].mask >> w) & 1u;
+      const uint64_t m = __ballot(rel);
+      if (rel) sIdx[w][cnt + __popcll(m & lt_mask)] = (uint16_t)jj;
+      cnt += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < cnt; i++) {
+      const int j = sIdx[w][i];
+      const float4 qa = sE[j].a;
+      const float2 qc = sE[j].c;
+      const float4 qb = sE[j].b;
+      const float dx = qa.x - pixx, dy = qa.y - pixy;
+      const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
+      const bool in_range = !(power > 0.0f) && !(power < qc.y);
+      if (__ballot(in_range) == 0ull) continue;  // wave-uniform
+      // lanes outside [pmin, 0] may produce garbage here; every use below is behind a select
+      const float araw = __builtin_fminf(0.99f, qb.y * blend_exp<FAST_EXP>(power));
+      const bool valid = in_range && !(araw < 1.0f / 255.0f);
+      const float test_T = Tw * (1 - araw);
+      const bool use = valid && !(test_T < 0.0001f);
+      const float n0 = __builtin_fmaf(qb.z * araw, Tw, C0);
+      const float n1 = __builtin_fmaf(qb.w * araw, Tw, C1);
+      const float n2 = __builtin_fmaf(qc.x * araw, Tw, C2);
+      C0 = use ? n0 : C0;
+      C1 = use ? n1 : C1;
+      C2 = use ? n2 : C2;
+      Tout = use ? test_T : Tout;
+      last_contributor = use ? (uint32_t)(base + j + 1) : last_contributor;
+      Tw = use ? test_T : (valid ? 0.0f : Tw);
+      if (__ballot(Tw != 0.0f) == 0ull) break;
     }
   }
   if (inside) {
     const size_t pix_id = (size_t)a.W * pyi + pxi;
     const size_t plane = (size_t)a.H * a.W;
-    a.final_T[pix_id] = T;
+    a.final_T[pix_id] = Tout;
     a.n_contrib[pix_id] = last_contributor;
-    a.out_color[pix_id] = C0 + T * a.bg[0];
-    a.out_color[plane + pix_id] = C1 + T * a.bg[1];
-    a.out_color[2 * plane + pix_id] = C2 + T * a.bg[2];
+    a.out_color[pix_id] = C0 + Tout * a.bg[0];
+    a.out_color[plane + pix_id] = C1 + Tout * a.bg[1];
+    a.out_color[2 * plane + pix_id] = C2 + Tout * a.bg[2];
   }
 }
 
@@ -163,11 +179,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
 // only the entries whose quadrant mask includes its 8x8 quadrant (see K6).
 template <bool FAST_EXP>
 __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
-  __shared__ float4 sA[CHUNK];
-  __shared__ float4 sB[CHUNK];
-  __shared__ float2 sC[CHUNK];
-  __shared__ uint32_t sM[CHUNK];
-  __shared__ uint32_t sId[CHUNK];
+  __shared__ StagedEntry sE[CHUNK];
+  __shared__ uint16_t sIdx[4][CHUNK];  // per-wave compacted slots
   __shared__ float sAcc[9][CHUNK];
   __shared__ uint32_t sMax[4];
 
@@ -182,6 +195,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
   const uint32_t r0 = a.ranges[2 * tile];
   const size_t pix_id = (size_t)a.W * pyi + pxi;
   const size_t plane = (size_t)a.H * a.W;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
 
   const float T_final = inside ? a.final_T[pix_id] : 0.0f;
   const uint32_t last_contributor = inside ? a.n_contrib[pix_id] : 0u;
@@ -219,98 +233,100 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
       const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
       const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
       const float pmin = gcr_alpha_skip_bound(q1.y);
-      sA[tid] = q0;
-      sB[tid] = q1;
-      sC[tid] = make_float2(q2.x, pmin);
-      sId[tid] = id;
+      sE[tid].a = q0;
+      sE[tid].b = q1;
+      sE[tid].c = make_float2(q2.x, pmin);
+      sE[tid].id = id;
       my_mask = gcr_quadrant_mask(q0.x, q0.y, q0.z, q0.w, q1.x, pmin, tile_x0, tile_y0);
     }
-    sM[tid] = my_mask;
+    sE[tid].mask = my_mask;
 #pragma unroll
     for (int k = 0; k < 9; k++) sAcc[k][tid] = 0.0f;
     __syncthreads();
 
-    // slots whose list entry this wave's pixels still consume: entry < wave_max
-    //   entry = total-1-(base+j) < wave_max  <=>  j > total-1-base-wave_max
-#pragma unroll 1
+    // compact the slots this wave still consumes: quadrant bit set and list entry < wave_max
+    int cnt = 0;
+#pragma unroll
     for (int k = 0; k < 4; k++) {
       const int jj = k * 64 + lane;
       const uint32_t entry_l = (uint32_t)(total - 1 - (base + jj));
-      uint64_t m = __ballot(jj < n && ((sM[jj] >> w) & 1u) && entry_l < wave_max);
-      while (m != 0ull) {
-        const int j = k * 64 + __builtin_ctzll(m);
-        m &= m - 1ull;
-        const uint32_t entry = (uint32_t)(total - 1 - (base + j));  // == `contributor` upstream
-        const float4 qa = sA[j];
-        const float2 qc = sC[j];
-        const float4 qb = sB[j];
-        const float dx = qa.x - pixx, dy = qa.y - pixy;
-        const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
-        const bool in_range = entry < last_contributor && !(power > 0.0f) && !(power < qc.y);
-        if (__ballot(in_range) == 0ull) continue;  // whole wave skips this Gaussian
-        // Branch-free body: lanes that upstream would `continue` keep their state via selects
-        // and contribute exact zeros to the wave reduction (see K6 for why: SALU pressure).
-        const float pw = gcr_max(-87.0f, gcr_min(power, 0.0f));
-        const float G = blend_exp<FAST_EXP>(pw);
-        const float alpha = gcr_min(0.99f, qb.y * G);
-        const bool use = in_range && !(alpha < 1.0f / 255.0f);
-        const float Tn = T / (1.f - alpha);
-        const float dchannel_dcolor = alpha * Tn;
-        const float a0 = __builtin_fmaf(last_alpha, lc0, (1.f - last_alpha) * acc0);
-        const float a1 = __builtin_fmaf(last_alpha, lc1, (1.f - last_alpha) * acc1);
-        const float a2 = __builtin_fmaf(last_alpha, lc2, (1.f - last_alpha) * acc2);
-        float dL_dalpha = 0.0f;
-        dL_dalpha = __builtin_fmaf(qb.z - a0, dLp0, dL_dalpha);
-        dL_dalpha = __builtin_fmaf(qb.w - a1, dLp1, dL_dalpha);
-        dL_dalpha = __builtin_fmaf(qc.x - a2, dLp2, dL_dalpha);
-        dL_dalpha *= Tn;
-        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-        const float dL_dG = qb.y * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddelx = -gdx * qa.z - gdy * qa.w;
-        const float dG_ddely = -gdy * qb.x - gdx * qa.w;
-        float v0 = use ? dchannel_dcolor * dLp0 : 0.0f;
-        float v1 = use ? dchannel_dcolor * dLp1 : 0.0f;
-        float v2 = use ? dchannel_dcolor * dLp2 : 0.0f;
-        float v3 = use ? dL_dG * dG_ddelx * ddelx_dx : 0.0f;
-        float v4 = use ? dL_dG * dG_ddely * ddely_dy : 0.0f;
-        float v5 = use ? -0.5f * gdx * dx * dL_dG : 0.0f;
-        float v6 = use ? -0.5f * gdx * dy * dL_dG : 0.0f;
-        float v7 = use ? -0.5f * gdy * dy * dL_dG : 0.0f;
-        float v8 = use ? G * dL_dalpha : 0.0f;
-        T = use ? Tn : T;
-        acc0 = use ? a0 : acc0;
-        acc1 = use ? a1 : acc1;
-        acc2 = use ? a2 : acc2;
-        lc0 = use ? qb.z : lc0;
-        lc1 = use ? qb.w : lc1;
-        lc2 = use ? qc.x : lc2;
-        last_alpha = use ? alpha : last_alpha;
-        v0 = gcr_wave_sum_to_lane63(v0);
-        v1 = gcr_wave_sum_to_lane63(v1);
-        v2 = gcr_wave_sum_to_lane63(v2);
-        v3 = gcr_wave_sum_to_lane63(v3);
-        v4 = gcr_wave_sum_to_lane63(v4);
-        v5 = gcr_wave_sum_to_lane63(v5);
-        v6 = gcr_wave_sum_to_lane63(v6);
-        v7 = gcr_wave_sum_to_lane63(v7);
-        v8 = gcr_wave_sum_to_lane63(v8);
-        if (lane == 63) {
-          atomicAdd(&sAcc[0][j], v0);
-          atomicAdd(&sAcc[1][j], v1);
-          atomicAdd(&sAcc[2][j], v2);
-          atomicAdd(&sAcc[3][j], v3);
-          atomicAdd(&sAcc[4][j], v4);
-          atomicAdd(&sAcc[5][j], v5);
-          atomicAdd(&sAcc[6][j], v6);
-          atomicAdd(&sAcc[7][j], v7);
-          atomicAdd(&sAcc[8][j], v8);
-        }
+      const bool rel = jj < n && ((sE[jj].mask >> w) & 1u) && entry_l < wave_max;
+      const uint64_t m = __ballot(rel);
+      if (rel) sIdx[w][cnt + __popcll(m & lt_mask)] = (uint16_t)jj;
+      cnt += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < cnt; i++) {
+      const int j = sIdx[w][i];
+      const uint32_t entry = (uint32_t)(total - 1 - (base + j));  // == `contributor` upstream
+      const float4 qa = sE[j].a;
+      const float2 qc = sE[j].c;
+      const float4 qb = sE[j].b;
+      const float dx = qa.x - pixx, dy = qa.y - pixy;
+      const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
+      const bool in_range = entry < last_contributor && !(power > 0.0f) && !(power < qc.y);
+      if (__ballot(in_range) == 0ull) continue;  // whole wave skips this Gaussian
+      // Branch-free body: lanes that upstream would `continue` keep their state via selects
+      // and contribute exact zeros to the wave reduction (see K6: scalar-unit pressure).
+      const float G = blend_exp<FAST_EXP>(power);
+      const float alpha = __builtin_fminf(0.99f, qb.y * G);
+      const bool use = in_range && !(alpha < 1.0f / 255.0f);
+      const float Tn = T / (1.f - alpha);
+      const float dchannel_dcolor = alpha * Tn;
+      const float a0 = __builtin_fmaf(last_alpha, lc0, (1.f - last_alpha) * acc0);
+      const float a1 = __builtin_fmaf(last_alpha, lc1, (1.f - last_alpha) * acc1);
+      const float a2 = __builtin_fmaf(last_alpha, lc2, (1.f - last_alpha) * acc2);
+      float dL_dalpha = 0.0f;
+      dL_dalpha = __builtin_fmaf(qb.z - a0, dLp0, dL_dalpha);
+      dL_dalpha = __builtin_fmaf(qb.w - a1, dLp1, dL_dalpha);
+      dL_dalpha = __builtin_fmaf(qc.x - a2, dLp2, dL_dalpha);
+      dL_dalpha *= Tn;
+      dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+      const float dL_dG = qb.y * dL_dalpha;
+      const float gdx = G * dx, gdy = G * dy;
+      const float dG_ddelx = -gdx * qa.z - gdy * qa.w;
+      const float dG_ddely = -gdy * qb.x - gdx * qa.w;
+      float v0 = use ? dchannel_dcolor * dLp0 : 0.0f;
+      float v1 = use ? dchannel_dcolor * dLp1 : 0.0f;
+      float v2 = use ? dchannel_dcolor * dLp2 : 0.0f;
+      float v3 = use ? dL_dG * dG_ddelx * ddelx_dx : 0.0f;
+      float v4 = use ? dL_dG * dG_ddely * ddely_dy : 0.0f;
+      float v5 = use ? -0.5f * gdx * dx * dL_dG : 0.0f;
+      float v6 = use ? -0.5f * gdx * dy * dL_dG : 0.0f;
+      float v7 = use ? -0.5f * gdy * dy * dL_dG : 0.0f;
+      float v8 = use ? G * dL_dalpha : 0.0f;
+      T = use ? Tn : T;
+      acc0 = use ? a0 : acc0;
+      acc1 = use ? a1 : acc1;
+      acc2 = use ? a2 : acc2;
+      lc0 = use ? qb.z : lc0;
+      lc1 = use ? qb.w : lc1;
+      lc2 = use ? qc.x : lc2;
+      last_alpha = use ? alpha : last_alpha;
+      v0 = gcr_wave_sum_to_lane63(v0);
+      v1 = gcr_wave_sum_to_lane63(v1);
+      v2 = gcr_wave_sum_to_lane63(v2);
+      v3 = gcr_wave_sum_to_lane63(v3);
+      v4 = gcr_wave_sum_to_lane63(v4);
+      v5 = gcr_wave_sum_to_lane63(v5);
+      v6 = gcr_wave_sum_to_lane63(v6);
+      v7 = gcr_wave_sum_to_lane63(v7);
+      v8 = gcr_wave_sum_to_lane63(v8);
+      if (lane == 63) {
+        atomicAdd(&sAcc[0][j], v0);
+        atomicAdd(&sAcc[1][j], v1);
+        atomicAdd(&sAcc[2][j], v2);
+        atomicAdd(&sAcc[3][j], v3);
+        atomicAdd(&sAcc[4][j], v4);
+        atomicAdd(&sAcc[5][j], v5);
+        atomicAdd(&sAcc[6][j], v6);
+        atomicAdd(&sAcc[7][j], v7);
+        atomicAdd(&sAcc[8][j], v8);
       }
     }
     __syncthreads();
     if (tid < n) {
-      const uint32_t id = sId[tid];
+      const uint32_t id = sE[tid].id;
       float g[9];
 #pragma unroll
       for (int k = 0; k < 9; k++) g[k] = sAcc[k][tid];

@@ -149,16 +149,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
-    opts = dict(dtype=torch.float32, device=device)
-    dL_dmeans3D = torch.zeros((P, 3), **opts)
-    dL_dmeans2D = torch.zeros((P, 3), **opts)
-    dL_dcolors = torch.zeros((P, NUM_CHANNELS), **opts)
-    dL_dconic = torch.zeros((P, 2, 2), **opts)
-    dL_dopacity = torch.zeros((P, 1), **opts)
-    dL_dcov3D = torch.zeros((P, 6), **opts)
-    dL_dsh = torch.zeros((P, M, 3), **opts)
-    dL_dscales = torch.zeros((P, 3), **opts)
-    dL_drotations = torch.zeros((P, 4), **opts)
+    # The reference allocates nine torch::zeros tensors (dgr/rasterize_points.cu:118-126); here
+    # they are nine views of ONE zero-filled buffer, i.e. a single fill launch.
+    shapes = ((P, 3), (P, 3), (P, NUM_CHANNELS), (P, 2, 2), (P, 1), (P, 6), (P, M, 3), (P, 3), (P, 4))
+    sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+    starts, off = [], 0
+    for n in sizes:  # every view starts 256-byte aligned (the kernels use float4 stores)
+        starts.append(off)
+        off += (n + 63) // 64 * 64
+    flat = torch.zeros((off,), dtype=torch.float32, device=device)
+    views = [flat[st:st + n].view(sh) for st, n, sh in zip(starts, sizes, shapes)]
+    (dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales,
+     dL_drotations) = views
     if P != 0:
         with torch.cuda.device(device):
             cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
