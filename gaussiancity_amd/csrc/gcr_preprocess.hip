@@ -120,15 +120,15 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
 //   * persistent grid: block b owns the contiguous chunk [b*chunk, (b+1)*chunk) of Gaussians
 //     and walks it 256 at a time;
 //   * phase A (all lanes): project, covariance, conic, radius, tile rect -> radii[] and, for
-//     survivors, a 9-word item pushed into a ring queue in LDS (wave ballot + one LDS atomic
-//     per wave);
-//   * phase B (whenever >= 256 items are queued, and once at the end): one item per thread --
+//     survivors, a 9-word item pushed into the wave's own ring queue in LDS (wave ballot; no
+//     block barrier); the next iteration's attributes are prefetched before the math starts;
+//   * phase B (whenever a wave has >= 64 items queued, and once at the end): one item per lane --
 //     SH -> RGB, 48-byte record, clamp mask, per-tile instance counts (atomics on 128-byte
 //     padded counters), and the Gaussian's index appended to the block's visible list, which
 //     the scatter kernel and the backward preprocess iterate densely.
 // Per-Gaussian arithmetic is unchanged (gcr-fp32-v1, bit-identical to the oracle).
-constexpr int Q_CAP = 512;   // ring capacity (items); < 256 queued before a push round
-constexpr int Q_WORDS = 9;   // idx, px, py, conic.xyz, depth, rect_x, rect_y
+constexpr int Q_CAP = 128;  // per-wave ring capacity (items); < 64 queued before a push round
+constexpr int Q_WORDS = 9;  // idx, px, py, conic.xyz, depth, rect_x, rect_y
 
 GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, const uint32_t (*q)[Q_CAP], uint32_t slot,
                                 uint32_t list_pos, uint32_t* __restrict__ vis_list) {
@@ -195,27 +195,68 @@ GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, const uint32_t (*q)[
         atomicAdd(&a.tile_count[(size_t)(ty * a.gx + tx) * GCR_CURSOR_STRIDE], 1u);
 }
 
+// Raw per-Gaussian inputs of phase A, fetched one iteration ahead so that the ~460-instruction
+// covariance math of the current Gaussian overlaps the HBM latency of the next.
+struct PhaseAIn {
+  V3 p;
+  float c0, c1, c2, c3, c4, c5, c6;  // scale.xyz + rot.rxyz, or cov3D[0..5] (scalars: stay in VGPRs)
+};
+
+// The load is unconditional (callers clamp idx into range): a predicated prefetch makes the
+// compiler's s_waitcnt placement lose count across the loop back-edge and wait for everything.
+template <bool PRECOMP_COV>
+GCR_DEV void phase_a_load(const GcrPreprocessArgs& a, long long idx, PhaseAIn& in) {
+  in.p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+  if (PRECOMP_COV) {
+    const float* __restrict__ c = a.cov3D_precomp + 6 * (size_t)idx;
+    in.c0 = c[0]; in.c1 = c[1]; in.c2 = c[2]; in.c3 = c[3]; in.c4 = c[4]; in.c5 = c[5];
+  } else {
+    in.c0 = a.scales[3 * idx];
+    in.c1 = a.scales[3 * idx + 1];
+    in.c2 = a.scales[3 * idx + 2];
+    const float4 rot = reinterpret_cast<const float4*>(a.rotations)[idx];
+    in.c3 = rot.x; in.c4 = rot.y; in.c5 = rot.z; in.c6 = rot.w;
+  }
+}
+
+// Wave-uniform float forced into an SGPR.  The camera matrices are read once per kernel this way:
+// left to itself the compiler re-fetched them with VECTOR loads in every loop iteration (it
+// cannot prove them invariant next to the kernel's stores, so no s_load).
+GCR_DEV float gcr_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+template <bool PRECOMP_COV>
 __global__ __launch_bounds__(256) void k_preprocess(const GcrPreprocessArgs a) {
-  __shared__ uint32_t q[Q_WORDS][Q_CAP];
-  __shared__ uint32_t q_tail;  // items ever pushed by this block
-  const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) q_tail = 0;
+  __shared__ uint32_t q[4][Q_WORDS][Q_CAP];  // one ring per wave: no block barrier in the loop
+  __shared__ uint32_t list_tail;             // length of this block's visible list
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) list_tail = 0;
   __syncthreads();
-  const float* __restrict__ vm = a.view;
-  const float* __restrict__ pm = a.proj;
+  float vm[16], pm[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    vm[i] = gcr_uniform(a.view[i]);
+    pm[i] = gcr_uniform(a.proj[i]);
+  }
   const long long chunk_begin = (long long)blockIdx.x * a.chunk;
   const long long chunk_end = chunk_begin + a.chunk < a.P ? chunk_begin + a.chunk : a.P;
   uint32_t* __restrict__ my_list = a.vis_list + chunk_begin;
-  uint32_t head = 0;  // items already consumed (uniform across the block)
+  const uint32_t (*qw)[Q_CAP] = q[w];
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  uint32_t head = 0, tail = 0;  // wave-uniform ring cursors
 
+  PhaseAIn cur, nxt;
+  long long idx64 = chunk_begin + tid;
+  const long long last = (long long)a.P - 1;
+  phase_a_load<PRECOMP_COV>(a, idx64 < last ? idx64 : last, cur);
   for (long long base = chunk_begin; base < chunk_end; base += 256) {
-    const long long idx64 = base + tid;
+    idx64 = base + tid;
+    phase_a_load<PRECOMP_COV>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);  // prefetch
     bool keep = false;
     uint32_t item[Q_WORDS];
     if (idx64 < chunk_end) {
       const int idx = (int)idx64;
       int my_radius_i = 0;
-      const V3 p_orig = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+      const V3 p_orig = cur.p;
       const V3 p_view = transform_point_4x3(p_orig, vm);
       if (!(p_view.z <= 0.2f)) {  // in_frustum
         const float hx = pm[0] * p_orig.x + pm[4] * p_orig.y + pm[8] * p_orig.z + pm[12];
@@ -224,13 +265,12 @@ __global__ __launch_bounds__(256) void k_preprocess(const GcrPreprocessArgs a) {
         const float p_w = 1.0f / (hw + 0.0000001f);
         const float projx = hx * p_w, projy = hy * p_w;
         float cov3D[6];
-        if (a.cov3D_precomp != nullptr) {
-#pragma unroll
-          for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+        if (PRECOMP_COV) {
+          cov3D[0] = cur.c0; cov3D[1] = cur.c1; cov3D[2] = cur.c2;
+          cov3D[3] = cur.c3; cov3D[4] = cur.c4; cov3D[5] = cur.c5;
         } else {
-          const V3 sc = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
-          const float4 rot = reinterpret_cast<const float4*>(a.rotations)[idx];
-          compute_cov3d(sc, a.scale_modifier, rot, cov3D);
+          const V3 sc = {cur.c0, cur.c1, cur.c2};
+          compute_cov3d(sc, a.scale_modifier, make_float4(cur.c3, cur.c4, cur.c5, cur.c6), cov3D);
         }
         Cov2DCtx cc;
         float cov[3];
@@ -264,7 +304,7 @@ __global__ __launch_bounds__(256) void k_preprocess(const GcrPreprocessArgs a) {
             item[6] = __float_as_uint(p_view.z);
             item[7] = (uint32_t)minx | ((uint32_t)maxx << 16);
             item[8] = (uint32_t)miny | ((uint32_t)maxy << 16);
-            if (a.cov3D_precomp == nullptr) {
+            if (!PRECOMP_COV) {
 #pragma unroll
               for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov3D[i];
             }
@@ -273,28 +313,34 @@ __global__ __launch_bounds__(256) void k_preprocess(const GcrPreprocessArgs a) {
       }
       a.radii[idx] = my_radius_i;
     }
-    // push survivors: one LDS atomic per wave
+    // push survivors into this wave's ring
     const uint64_t m = __ballot(keep);
-    if (m != 0ull) {
-      uint32_t wbase = 0;
-      if (lane == 0) wbase = atomicAdd(&q_tail, (uint32_t)__popcll(m));
-      wbase = __shfl(wbase, 0, 64);
-      if (keep) {
-        const uint32_t slot = (wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (Q_CAP - 1);
+    if (keep) {
+      const uint32_t slot = (tail + (uint32_t)__popcll(m & lt_mask)) & (Q_CAP - 1);
 #pragma unroll
-        for (int k = 0; k < Q_WORDS; k++) q[k][slot] = item[k];
-      }
+      for (int k = 0; k < Q_WORDS; k++) q[w][k][slot] = item[k];
     }
-    __syncthreads();
-    if (q_tail - head >= 256u) {  // uniform: q_tail is stable between the two barriers
-      preprocess_phase_b(a, q, (head + tid) & (Q_CAP - 1), head + tid, my_list);
-      head += 256u;
+    tail += (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (tail - head >= 64u) {  // wave-uniform: a full wave of survivors is ready
+      uint32_t lbase = 0;
+      if (lane == 0) lbase = atomicAdd(&list_tail, 64u);
+      lbase = __shfl(lbase, 0, 64);
+      preprocess_phase_b(a, qw, (head + lane) & (Q_CAP - 1), lbase + lane, my_list);
+      head += 64u;
+      __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
+    cur = nxt;
   }
-  const uint32_t tail = q_tail;
-  if (head + tid < tail) preprocess_phase_b(a, q, (head + tid) & (Q_CAP - 1), head + tid, my_list);
-  if (tid == 0) a.vis_count[blockIdx.x] = tail;
+  const uint32_t rest = tail - head;  // < 64
+  if (rest != 0u) {
+    uint32_t lbase = 0;
+    if (lane == 0) lbase = atomicAdd(&list_tail, rest);
+    lbase = __shfl(lbase, 0, 64);
+    if ((uint32_t)lane < rest) preprocess_phase_b(a, qw, (head + lane) & (Q_CAP - 1), lbase + lane, my_list);
+  }
+  __syncthreads();
+  if (tid == 0) a.vis_count[blockIdx.x] = list_tail;
 }
 
 // ------------------------------------------------------------------------------------- K2
@@ -634,7 +680,7 @@ int gcr_preprocess_resident_blocks(void) {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_preprocess, 256, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_preprocess<false>, 256, 0) != hipSuccess || per_cu < 1)
       per_cu = 4;
     int n = per_cu * cus;
     return n > GCR_K1_MAX_BLOCKS ? GCR_K1_MAX_BLOCKS : (n < 1 ? 1 : n);
@@ -644,7 +690,10 @@ int gcr_preprocess_resident_blocks(void) {
 
 hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
-  k_preprocess<<<a.nblocks, 256, 0, s>>>(a);
+  if (a.cov3D_precomp != nullptr)
+    k_preprocess<true><<<a.nblocks, 256, 0, s>>>(a);
+  else
+    k_preprocess<false><<<a.nblocks, 256, 0, s>>>(a);
   return hipGetLastError();
 }
 
