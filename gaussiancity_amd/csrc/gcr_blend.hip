@@ -170,8 +170,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
 // cr/backward.cu:428-581.  Per pixel the reverse walk is the reference's; what changes is how
 // the nine per-(pixel,Gaussian) gradient terms reach memory.  The reference issues nine global
 // float atomics per pixel per Gaussian; here
-//   1. each wave sums its 64 lanes with a DPP butterfly (no LDS traffic),
-//   2. lane 63 adds the wave sum into a per-chunk LDS accumulator (ds_add_f32),
+//   1. each wave reduce-scatters the nine terms over its four 16-lane DPP rows (31 VALU ops,
+//      gcr_row_reduce_scatter9; no LDS traffic),
+//   2. lanes 0..8 of each row add the row sums into a per-chunk LDS accumulator (one ds_add_f32),
 //   3. after the chunk, thread t flushes entry t with nine global_atomic_add_f32
 // so global atomics drop from 9 per (pixel,Gaussian) to 9 per (tile,Gaussian).
 // Only entries [0, max n_contrib of the tile) are visited: later entries are skipped by every
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
   const size_t pix_id = (size_t)a.W * pyi + pxi;
   const size_t plane = (size_t)a.H * a.W;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const int acc_slot = (lane & 15) <= 8 ? (lane & 15) : -1;  // which of the 9 terms this lane flushes
 
   const float T_final = inside ? a.final_T[pix_id] : 0.0f;
   const uint32_t last_contributor = inside ? a.n_contrib[pix_id] : 0u;
@@ -286,15 +288,16 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
       const float gdx = G * dx, gdy = G * dy;
       const float dG_ddelx = -gdx * qa.z - gdy * qa.w;
       const float dG_ddely = -gdy * qb.x - gdx * qa.w;
-      float v0 = use ? dchannel_dcolor * dLp0 : 0.0f;
-      float v1 = use ? dchannel_dcolor * dLp1 : 0.0f;
-      float v2 = use ? dchannel_dcolor * dLp2 : 0.0f;
-      float v3 = use ? dL_dG * dG_ddelx * ddelx_dx : 0.0f;
-      float v4 = use ? dL_dG * dG_ddely * ddely_dy : 0.0f;
-      float v5 = use ? -0.5f * gdx * dx * dL_dG : 0.0f;
-      float v6 = use ? -0.5f * gdx * dy * dL_dG : 0.0f;
-      float v7 = use ? -0.5f * gdy * dy * dL_dG : 0.0f;
-      float v8 = use ? G * dL_dalpha : 0.0f;
+      float v[9];
+      v[0] = use ? dchannel_dcolor * dLp0 : 0.0f;
+      v[1] = use ? dchannel_dcolor * dLp1 : 0.0f;
+      v[2] = use ? dchannel_dcolor * dLp2 : 0.0f;
+      v[3] = use ? dL_dG * dG_ddelx * ddelx_dx : 0.0f;
+      v[4] = use ? dL_dG * dG_ddely * ddely_dy : 0.0f;
+      v[5] = use ? -0.5f * gdx * dx * dL_dG : 0.0f;
+      v[6] = use ? -0.5f * gdx * dy * dL_dG : 0.0f;
+      v[7] = use ? -0.5f * gdy * dy * dL_dG : 0.0f;
+      v[8] = use ? G * dL_dalpha : 0.0f;
       T = use ? Tn : T;
       acc0 = use ? a0 : acc0;
       acc1 = use ? a1 : acc1;
@@ -303,26 +306,10 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
       lc1 = use ? qb.w : lc1;
       lc2 = use ? qc.x : lc2;
       last_alpha = use ? alpha : last_alpha;
-      v0 = gcr_wave_sum_to_lane63(v0);
-      v1 = gcr_wave_sum_to_lane63(v1);
-      v2 = gcr_wave_sum_to_lane63(v2);
-      v3 = gcr_wave_sum_to_lane63(v3);
-      v4 = gcr_wave_sum_to_lane63(v4);
-      v5 = gcr_wave_sum_to_lane63(v5);
-      v6 = gcr_wave_sum_to_lane63(v6);
-      v7 = gcr_wave_sum_to_lane63(v7);
-      v8 = gcr_wave_sum_to_lane63(v8);
-      if (lane == 63) {
-        atomicAdd(&sAcc[0][j], v0);
-        atomicAdd(&sAcc[1][j], v1);
-        atomicAdd(&sAcc[2][j], v2);
-        atomicAdd(&sAcc[3][j], v3);
-        atomicAdd(&sAcc[4][j], v4);
-        atomicAdd(&sAcc[5][j], v5);
-        atomicAdd(&sAcc[6][j], v6);
-        atomicAdd(&sAcc[7][j], v7);
-        atomicAdd(&sAcc[8][j], v8);
-      }
+      // reduce-scatter over each 16-lane row, then ONE ds_add_f32: lanes 0..8 of the four rows
+      // add their row's sum of term (lane & 15) into the chunk accumulator
+      const float rsum = gcr_row_reduce_scatter9(v, lane);
+      if (acc_slot >= 0) atomicAdd(&sAcc[acc_slot][j], rsum);
     }
     __syncthreads();
     if (tid < n) {

@@ -95,6 +95,46 @@ GCR_DEV float gcr_wave_sum_to_lane63(float v) {
   return v;
 }
 
+// ---- reduce-scatter of nine per-lane values over each 16-lane DPP row ----------------------
+// Lane-xor exchanges: xor 1 / 2 are quad permutes; xor 4 / 8 take two bank-masked row shifts
+// (lanes with the bit clear read from lane+n via row_shl:n, lanes with it set from lane-n via
+// row_shr:n; bank_mask picks which 4-lane banks each instruction writes).
+template <int CTRL, int BANK_MASK>
+GCR_DEV float gcr_dpp_keep(float old, float src) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, BANK_MASK, false));
+}
+GCR_DEV float gcr_lane_xor1(float v) { return gcr_dpp_keep<0xB1, 0xf>(0.0f, v); }  // quad_perm [1,0,3,2]
+GCR_DEV float gcr_lane_xor2(float v) { return gcr_dpp_keep<0x4E, 0xf>(0.0f, v); }  // quad_perm [2,3,0,1]
+GCR_DEV float gcr_lane_xor4(float v) {
+  const float t = gcr_dpp_keep<0x114, 0xA>(0.0f, v);  // row_shr:4 -> banks 1,3
+  return gcr_dpp_keep<0x104, 0x5>(t, v);              // row_shl:4 -> banks 0,2
+}
+GCR_DEV float gcr_lane_xor8(float v) {
+  const float t = gcr_dpp_keep<0x118, 0xC>(0.0f, v);  // row_shr:8 -> banks 2,3
+  return gcr_dpp_keep<0x108, 0x3>(t, v);              // row_shl:8 -> banks 0,1
+}
+// One butterfly level on a pair: the lane whose `bit` is clear ends up with a's partial sum,
+// its partner with b's -- one register leaves the level instead of two.
+#define GCR_RS_MERGE(a, b, bit, XORFN) (((bit) ? (b) : (a)) + XORFN((bit) ? (a) : (b)))
+// In: v[0..8] per lane.  Out (return value): within every 16-lane row, lane r holds the row sum
+// of v[r] for r = 0..7 and lanes 8..15 hold the row sum of v[8].  31 VALU ops (9 plain
+// row all-reduces would be 36, a full wave all-reduce 54).
+GCR_DEV float gcr_row_reduce_scatter9(const float (&v)[9], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  const float m01 = GCR_RS_MERGE(v[0], v[1], b0, gcr_lane_xor1);
+  const float m23 = GCR_RS_MERGE(v[2], v[3], b0, gcr_lane_xor1);
+  const float m45 = GCR_RS_MERGE(v[4], v[5], b0, gcr_lane_xor1);
+  const float m67 = GCR_RS_MERGE(v[6], v[7], b0, gcr_lane_xor1);
+  float s8 = v[8] + gcr_lane_xor1(v[8]);
+  const float m03 = GCR_RS_MERGE(m01, m23, b1, gcr_lane_xor2);
+  const float m47 = GCR_RS_MERGE(m45, m67, b1, gcr_lane_xor2);
+  s8 += gcr_lane_xor2(s8);
+  const float m07 = GCR_RS_MERGE(m03, m47, b2, gcr_lane_xor4);
+  s8 += gcr_dpp_keep<0x141, 0xf>(0.0f, s8);  // row_half_mirror: the other quad of the 8-lane half
+  return GCR_RS_MERGE(m07, s8, b3, gcr_lane_xor8);
+}
+
 GCR_DEV uint32_t gcr_wave_sum_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
