@@ -288,10 +288,13 @@ __global__ __launch_bounds__(256) void k_preprocess(const GcrPreprocessArgs a) {
           // getRect, cr/auxiliary.h:36-46
           const int ri = gcr_f2i_sat(my_radius);
           const float rf = (float)ri;
-          const int minx = min(a.gx, max(0, gcr_f2i_sat((px - rf) / 16.0f)));
-          const int miny = min(a.gy, max(0, gcr_f2i_sat((py - rf) / 16.0f)));
-          const int maxx = min(a.gx, max(0, gcr_f2i_sat((px + rf + 16.0f - 1.0f) / 16.0f)));
-          const int maxy = min(a.gy, max(0, gcr_f2i_sat((py + rf + 16.0f - 1.0f) / 16.0f)));
+          // min(grid, max(0, (int)x)) == (int)clamp(x, 0, grid) for every x incl. NaN/inf (the
+          // float clamp returns the non-NaN operand); 3 VALU ops instead of ~9 per bound.
+          const float gxf = (float)a.gx, gyf = (float)a.gy;
+          const int minx = (int)__builtin_fminf(__builtin_fmaxf((px - rf) / 16.0f, 0.0f), gxf);
+          const int miny = (int)__builtin_fminf(__builtin_fmaxf((py - rf) / 16.0f, 0.0f), gyf);
+          const int maxx = (int)__builtin_fminf(__builtin_fmaxf((px + rf + 16.0f - 1.0f) / 16.0f, 0.0f), gxf);
+          const int maxy = (int)__builtin_fminf(__builtin_fmaxf((py + rf + 16.0f - 1.0f) / 16.0f, 0.0f), gyf);
           if ((uint32_t)(maxx - minx) * (uint32_t)(maxy - miny) != 0) {
             keep = true;
             my_radius_i = ri;
