@@ -250,10 +250,11 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
     }
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
+    // tile_total | tile_local | blk_total share the (T x 128 B) cursor region, unused on this path
     HIP_TRY(gcr_launch_tile_count(T, a.gx, NG, G, a.nblocks, a.chunk, a.vis_list, a.vis_count, a.rec,
-                                  (uint32_t*)(ib + L.img_tile_table), cursor, s),
+                                  (uint32_t*)(ib + L.img_tile_table), cursor, cursor + (size_t)T,
+                                  cursor + 2 * (size_t)T, frame, s),
             "tile count");
-    HIP_TRY(gcr_launch_scan_tiles(cursor, 1, ranges, T, frame, cap_instances, cap_list, s), "tile scan");
   } else {
     {
       StageTimer t(s, ST_PRE);
@@ -270,8 +271,9 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
 // Enqueues scatter + per-tile LDS sort + forward blend (the default binning path).
 // `frame_guard` (device {R, max, go}) makes the three kernels no-ops when go == 0.
 static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, void* geom, void* binning, void* img,
-                              int64_t R_layout, int64_t lds_list_capacity, const unsigned long long* frame_guard,
-                              float* out_color, hipStream_t s) {
+                              int64_t R_layout, int64_t lds_list_capacity, bool speculative,
+                              unsigned long long cap_instances, unsigned long long cap_list, float* out_color,
+                              hipStream_t s) {
   gcr_layout L;
   compute_layout(g->P, cam->img_w, cam->img_h, R_layout, &L);
   char *gb = (char*)geom, *bb = (char*)binning, *ib = (char*)img;
@@ -284,29 +286,33 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   uint32_t* ranges = (uint32_t*)(ib + L.img_ranges);
   uint64_t* pairs = (uint64_t*)(bb + L.bin_keys[0]);
   uint32_t* list = (uint32_t*)(bb + L.bin_vals[L.bin_sorted]);
+  unsigned long long* frame_dev = (unsigned long long*)(gb + L.geom_num_rendered);
+  const unsigned long long* frame_guard = speculative ? frame_dev : nullptr;
   int nblocks, chunk;
   gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &nblocks, &chunk);
-  if (R_layout > 0) {
-    {
-      StageTimer t(s, ST_EMIT);
-      int G = 1;
-      const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, nblocks, &G);
-      if (NG > 0)
-        HIP_TRY(gcr_launch_tile_scatter(T, gx, NG, G, nblocks, chunk, vis_list, vis_count, rec,
-                                        (uint32_t*)(ib + L.img_tile_table), ranges, pairs, frame_guard, s),
-                "tile scatter");
-      else
-        HIP_TRY(gcr_launch_scatter_instances(nblocks, chunk, vis_list, vis_count, rec, gx,
-                                             (uint32_t*)(ib + L.img_tile_cursor), pairs, s),
-                "scatter instances");
+  int G = 1;
+  const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, nblocks, &G);
+  {
+    StageTimer t(s, ST_EMIT);
+    if (NG > 0) {
+      // also rebuilds `ranges` from the block totals, so it runs even when nothing is rendered
+      uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
+      HIP_TRY(gcr_launch_tile_scatter(T, gx, NG, G, nblocks, chunk, vis_list, vis_count, rec,
+                                      (uint32_t*)(ib + L.img_tile_table), cursor, cursor + (size_t)T,
+                                      cursor + 2 * (size_t)T, ranges, pairs, frame_dev, cap_instances, cap_list, s),
+              "tile scatter");
+    } else if (R_layout > 0) {
+      HIP_TRY(gcr_launch_scatter_instances(nblocks, chunk, vis_list, vis_count, rec, gx,
+                                           (uint32_t*)(ib + L.img_tile_cursor), pairs, s),
+              "scatter instances");
     }
-    if (int rc = debug_sync(cam, s, "scatter instances")) return rc;
-    {
-      StageTimer t(s, ST_SORT);
-      HIP_TRY(gcr_launch_tile_sort(ranges, T, pairs, list, lds_list_capacity, frame_guard, s), "tile sort");
-    }
-    if (int rc = debug_sync(cam, s, "tile sort")) return rc;
   }
+  if (int rc = debug_sync(cam, s, "scatter instances")) return rc;
+  if (R_layout > 0) {
+    StageTimer t(s, ST_SORT);
+    HIP_TRY(gcr_launch_tile_sort(ranges, T, pairs, list, lds_list_capacity, frame_guard, s), "tile sort");
+  }
+  if (int rc = debug_sync(cam, s, "tile sort")) return rc;
   GcrBlendArgs b;
   memset(&b, 0, sizeof(b));
   b.ranges = ranges;
@@ -385,18 +391,20 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
   if (int rc = enqueue_preprocess(cam, g, geom, geom_bytes, img, img_bytes, radii,
                                   speculate ? (unsigned long long)binning_capacity : 0ull, cap_list, &frame, s))
     return rc;
-  HIP_TRY(hipMemcpyAsync(g_readback.pinned, frame, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s),
+  HIP_TRY(hipMemcpyAsync(g_readback.pinned, frame, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s),
           "frame info copy");
   HIP_TRY(hipEventRecord(g_readback.ev, s), "frame info event");
   if (speculate) {
     // Everything else of the frame is enqueued before the host knows R: the kernels read the
     // tile ranges from device memory and are vetoed by frame[2] if the capacity guess was short.
-    if (int rc = enqueue_render_lds(cam, g, geom, binning, img, binning_capacity, (int64_t)cap_list, frame,
-                                    out_color, s))
+    if (int rc = enqueue_render_lds(cam, g, geom, binning, img, binning_capacity, (int64_t)cap_list, true,
+                                    (unsigned long long)binning_capacity, cap_list, out_color, s))
       return rc;
   }
   HIP_TRY(hipEventSynchronize(g_readback.ev), "frame info sync");  // the one host wait of the frame
-  const unsigned long long R = g_readback.pinned[0], mx = g_readback.pinned[1], go = g_readback.pinned[2];
+  const unsigned long long R = g_readback.pinned[0], mx = g_readback.pinned[1];
+  // the same decision the scatter kernel takes on the device from the same two numbers
+  const bool go = R <= (unsigned long long)binning_capacity && mx <= cap_list;
   if (R > 0x7fffffffull)
     return fail(GCR_ERR_OVERFLOW, "num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)");
   info_host->num_rendered = (int64_t)R;
@@ -423,7 +431,8 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   hipStream_t s = (hipStream_t)hip_stream;
   const bool lds_sort = !g_force_radix.load() && info->max_tile_instances <= gcr_tile_sort_capacity();
   if (R == 0 || lds_sort)
-    return enqueue_render_lds(cam, g, geom, binning, img, R, info->max_tile_instances, nullptr, out_color, s);
+    return enqueue_render_lds(cam, g, geom, binning, img, R, info->max_tile_instances, false, ~0ull, ~0ull,
+                              out_color, s);
 
   // Fallback (a tile list longer than the LDS capacity, or "force_radix"): the reference's own
   // scheme -- emit tile|depth keys in index order, stable global radix sort, boundary scan.

@@ -50,9 +50,10 @@ __global__ __launch_bounds__(256) void k_emit(int P, const uint32_t* __restrict_
 //       workgroup g counts its instances per tile in an LDS table (ds_add) and stores the row
 //       to table[g][0..T).
 //   B'  k_table_colscan: exclusive prefix down every tile column (base[g][t] = instances of
-//       tile t owned by groups < g) and the tile totals; k_scan_tiles (gcr_preprocess.hip)
-//       turns the totals into tile ranges, num_rendered and the longest list.
-//   C'  k_tile_table<true>: workgroup g loads range[t].start + base[g][t] into LDS cursors and
+//       tile t owned by groups < g), the tile totals, their prefix inside each 64-tile block and
+//       the block totals; R and the longest list are accumulated into the frame summary.
+//   C'  k_tile_table<true>: every workgroup rebuilds the tile starts from the block totals
+//       (a <= 640-element scan), writes its slice of `ranges`, loads start + base[g][t] into LDS cursors and
 //       claims slots with LDS returning atomics; the (depth<<32|index) key goes straight to its
 //       final tile segment.
 //   D'  k_tile_sort: bitonic sort of every tile segment in LDS.
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void k_emit(int P, const uint32_t* __restrict_
 // in index order (cr/rasterizer_impl.cu:66-99,255-260).
 constexpr int TT_THREADS = 512;
 constexpr int TT_MAX_GROUP = 64;  // K1 blocks per group (host guarantees G <= this)
+constexpr int TT_MAX_TBLOCKS = 640;  // 64-tile blocks: T <= 40960 > the LDS limit of 150 KiB / 4 B
 
 template <bool SCATTER>
 __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G, int nblocks_k1, int chunk,
@@ -69,16 +71,68 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
                                                            const uint32_t* __restrict__ vis_count,
                                                            const float4* __restrict__ rec,
                                                            uint32_t* __restrict__ table,
-                                                           const uint32_t* __restrict__ ranges,
+                                                           const uint32_t* __restrict__ tile_total,
+                                                           const uint32_t* __restrict__ tile_local,
+                                                           const uint32_t* __restrict__ blk_total,
+                                                           uint32_t* __restrict__ ranges,
                                                            uint64_t* __restrict__ pairs,
-                                                           const unsigned long long* __restrict__ frame) {
+                                                           unsigned long long* __restrict__ frame,
+                                                           unsigned long long cap_instances,
+                                                           unsigned long long cap_list) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
   uint32_t* cnt = reinterpret_cast<uint32_t*>(gcr_smem);  // [T]
-  if (SCATTER && frame != nullptr && frame[2] == 0ull) return;  // speculative launch vetoed
   __shared__ uint32_t pre[TT_MAX_GROUP + 1];              // prefix of the group's list lengths
-  const int tid = threadIdx.x;
+  __shared__ uint32_t blk_base[TT_MAX_TBLOCKS];           // first instance of every 64-tile block
+  __shared__ uint32_t wtot[TT_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   uint32_t* __restrict__ row = table + (size_t)blockIdx.x * T;
-  for (int t = tid; t < T; t += TT_THREADS) cnt[t] = SCATTER ? ranges[2 * t] + row[t] : 0u;
+  if (!SCATTER) {
+    if (blockIdx.x == 0 && tid == 0) {  // frame = {R, longest list, go}: accumulated by the column scan
+      frame[0] = 0ull;
+      frame[1] = 0ull;
+      frame[2] = 0ull;
+    }
+    for (int t = tid; t < T; t += TT_THREADS) cnt[t] = 0u;
+  } else {
+    // Speculative launch: the host may not know R yet.  Every workgroup takes the same decision
+    // from the device-side frame summary; workgroup 0 publishes it for the later kernels.
+    const bool go = frame[0] <= cap_instances && frame[1] <= cap_list;
+    if (blockIdx.x == 0 && tid == 0) frame[2] = go ? 1ull : 0ull;
+    if (!go) return;
+    // tile starts = exclusive prefix of the 64-tile block totals (<= TT_MAX_TBLOCKS values, so
+    // every workgroup redoes this tiny scan instead of paying a single-block kernel for it)
+    const int ntb = (T + 63) / 64;
+    uint32_t running = 0;
+    for (int b0 = 0; b0 < ntb; b0 += TT_THREADS) {
+      const int bi = b0 + tid;
+      const uint32_t v = bi < ntb ? blk_total[bi] : 0u;
+      const uint32_t incl = gcr_wave_incl_scan_u32(v, lane);
+      if (lane == 63) wtot[w] = incl;
+      __syncthreads();
+      uint32_t before = 0, all = 0;
+#pragma unroll
+      for (int k = 0; k < TT_THREADS / 64; k++) {
+        const uint32_t x = wtot[k];
+        if (k < w) before += x;
+        all += x;
+      }
+      if (bi < ntb) blk_base[bi] = running + before + incl - v;
+      running += all;
+      __syncthreads();
+    }
+    // this workgroup's slice of the tile ranges (identifyTileRanges upstream,
+    // cr/rasterizer_impl.cu:104-124) and all LDS cursors
+    const int slice = (T + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_lo = blockIdx.x * slice, t_hi = min(T, t_lo + slice);
+    for (int t = tid; t < T; t += TT_THREADS) {
+      const uint32_t start = blk_base[t >> 6] + tile_local[t];
+      cnt[t] = start + row[t];
+      if (t >= t_lo && t < t_hi) {
+        ranges[2 * t] = start;
+        ranges[2 * t + 1] = start + tile_total[t];
+      }
+    }
+  }
   const int kb0 = blockIdx.x * G;
   const int kbn = min(G, nblocks_k1 - kb0);
   if (tid == 0) {
@@ -116,11 +170,17 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
   }
 }
 
-// table[g][t] (g < NG <= 512) -> exclusive prefix over g in place; totals[t] = column sum.
+// table[g][t] (g < NG <= 512) -> exclusive prefix over g in place; tile_total[t] = column sum.
 // Workgroup = 64 tiles x 16 row groups; every thread keeps its <= 32 rows in registers, so the
-// column is read exactly once with all loads in flight.
+// column is read exactly once with all loads in flight.  Wave 0 then scans the workgroup's 64 tile
+// totals (tile_local = exclusive prefix inside the 64-tile block, blk_total = their sum) and adds
+// the block's contribution to the frame summary {R, longest list} with two device-scope atomics
+// (one per 64 tiles -- fire-and-forget, unlike per-instance atomics these are negligible).
 __global__ __launch_bounds__(1024) void k_table_colscan(uint32_t* __restrict__ table, int NG, int T,
-                                                        uint32_t* __restrict__ totals) {
+                                                        uint32_t* __restrict__ tile_total,
+                                                        uint32_t* __restrict__ tile_local,
+                                                        uint32_t* __restrict__ blk_total,
+                                                        unsigned long long* __restrict__ frame) {
   __shared__ uint32_t part[16][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + lane;
@@ -154,7 +214,20 @@ __global__ __launch_bounds__(1024) void k_table_colscan(uint32_t* __restrict__ t
         run += v[r];
       }
     }
-    if (grp == 0) totals[t] = all;
+  }
+  if (grp == 0) {  // wave 0: `all` is this lane's tile total (0 beyond T)
+    const uint32_t mine = t < T ? all : 0u;
+    const uint32_t incl = gcr_wave_incl_scan_u32(mine, lane);
+    const uint32_t mx = gcr_wave_max_u32(mine);
+    if (t < T) {
+      tile_total[t] = mine;
+      tile_local[t] = incl - mine;
+    }
+    if (lane == 63) {
+      blk_total[blockIdx.x] = incl;
+      if (incl) atomicAdd(&frame[0], (unsigned long long)incl);
+      if (mx) atomicMax(&frame[1], (unsigned long long)mx);
+    }
   }
 }
 
@@ -394,7 +467,7 @@ hipError_t gcr_launch_emit(int P, const uint32_t* tiles_touched, const uint32_t*
 // not fit in LDS.
 int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out) {
   const size_t lds = (size_t)T * sizeof(uint32_t);
-  if (lds > 150 * 1024) return 0;
+  if (lds > 150 * 1024 || (T + 63) / 64 > TT_MAX_TBLOCKS) return 0;
   const int per_cu = lds > 64 * 1024 ? 1 : 2;
   int ng = 256 * per_cu;
   if (ng > nblocks_k1) ng = nblocks_k1;
@@ -407,33 +480,37 @@ int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out) {
 
 static hipError_t tile_table_attr() {
   static hipError_t done = [] {
-    hipError_t e = hipFuncSetAttribute((const void*)k_tile_table<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    hipError_t e = hipFuncSetAttribute((const void*)k_tile_table<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_tile_table<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    return hipFuncSetAttribute((const void*)k_tile_table<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   }();
   return done;
 }
 
 hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,
-                                 uint32_t* totals, hipStream_t s) {
+                                 uint32_t* tile_total, uint32_t* tile_local, uint32_t* blk_total,
+                                 unsigned long long* frame, hipStream_t s) {
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
-  k_tile_table<false><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(T, gx, G, nblocks_k1, chunk, vis_list,
-                                                                         vis_count, rec, table, nullptr, nullptr,
-                                                                         nullptr);
-  k_table_colscan<<<(T + 63) / 64, 1024, 0, s>>>(table, NG, T, totals);
+  k_tile_table<false><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(
+      T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, nullptr, nullptr, nullptr, nullptr, nullptr,
+      frame, 0ull, 0ull);
+  k_table_colscan<<<(T + 63) / 64, 1024, 0, s>>>(table, NG, T, tile_total, tile_local, blk_total, frame);
   return hipGetLastError();
 }
 
 hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                    const uint32_t* vis_count, const float4* rec, uint32_t* table,
-                                   const uint32_t* ranges, uint64_t* pairs, const unsigned long long* frame,
-                                   hipStream_t s) {
+                                   const uint32_t* tile_total, const uint32_t* tile_local,
+                                   const uint32_t* blk_total, uint32_t* ranges, uint64_t* pairs,
+                                   unsigned long long* frame, unsigned long long cap_instances,
+                                   unsigned long long cap_list, hipStream_t s) {
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
-  k_tile_table<true><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(T, gx, G, nblocks_k1, chunk, vis_list,
-                                                                        vis_count, rec, table, ranges, pairs, frame);
+  k_tile_table<true><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(
+      T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, tile_total, tile_local, blk_total, ranges, pairs,
+      frame, cap_instances, cap_list);
   return hipGetLastError();
 }
 

@@ -93,11 +93,14 @@ hipError_t gcr_launch_scan_tiles(uint32_t* tile_cursor, int stride, uint32_t* ra
 int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out);
 hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,
-                                 uint32_t* totals, hipStream_t s);
+                                 uint32_t* tile_total, uint32_t* tile_local, uint32_t* blk_total,
+                                 unsigned long long* frame, hipStream_t s);
 hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                    const uint32_t* vis_count, const float4* rec, uint32_t* table,
-                                   const uint32_t* ranges, uint64_t* pairs, const unsigned long long* frame,
-                                   hipStream_t s);
+                                   const uint32_t* tile_total, const uint32_t* tile_local,
+                                   const uint32_t* blk_total, uint32_t* ranges, uint64_t* pairs,
+                                   unsigned long long* frame, unsigned long long cap_instances,
+                                   unsigned long long cap_list, hipStream_t s);
 hipError_t gcr_launch_scatter_instances(int nblocks, int chunk, const uint32_t* vis_list,
                                         const uint32_t* vis_count, const float4* rec, int gx,
                                         uint32_t* tile_cursor, uint64_t* pairs, hipStream_t s);
