@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void k_emit(int P, const uint32_t* __restrict_
 // deterministic: positive-float depth bits ascending, ties in ascending Gaussian index -- the
 // order the reference gets from its stable radix sort on tile<<32|depth over instances emitted
 // in index order (cr/rasterizer_impl.cu:66-99,255-260).
+constexpr int RANK_MERGE_MAX = 1024;  // chunked rank sort + merge below, bitonic network above
 constexpr int TT_THREADS = 512;
 constexpr int TT_MAX_GROUP = 64;  // K1 blocks per group (host guarantees G <= this)
 constexpr int TT_MAX_TBLOCKS = 640;  // 64-tile blocks: T <= 40960 > the LDS limit of 150 KiB / 4 B
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void k_scatter_instances(int chunk, const uint
 }
 
 // One workgroup per tile sorts the tile's n <= capacity keys in LDS and writes the Gaussian
-// indices (low 32 bits) to the sorted list: rank sort for n <= 512, bitonic network (padded to a
+// indices (low 32 bits) to the sorted list: chunked rank sort + merge for n <= RANK_MERGE_MAX, bitonic network (padded to a
 // power of two with ~0) above.
 __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ ranges,
                                                    const uint64_t* __restrict__ pairs,
@@ -282,22 +283,65 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
     if (tid == 0) list[r0] = (uint32_t)pairs[r0];
     return;
   }
-  if (n <= 512) {
-    // Short list (the common case): rank sort.  Keys are unique, so rank(i) = #{j : key_j < key_i}
-    // is a permutation; every thread counts with wave-uniform (broadcast) 16-byte LDS reads.
-    // One barrier instead of the 36+ of a 256-element bitonic network.
-    const int npad = (n + 1) & ~1;
+  if (n <= RANK_MERGE_MAX) {
+    // Chunked rank sort + binary-search merge (one barrier).  Keys are unique, so
+    //   final position(i) = #{keys < key_i} = rank inside its own 64-key chunk
+    //                                         + sum over the other chunks of lower_bound(key_i).
+    // Phase 1: a wave's 64 keys belong to one chunk, so it counts with wave-uniform (broadcast)
+    // 16-byte LDS reads and drops each key at its rank into the sorted copy `sb`.
+    // Phase 2: six-step binary searches in the other sorted chunks.
+    const int nchunks = (n + 63) >> 6, npad = nchunks << 6;
+    uint64_t* sb = s + npad;
     for (int i = tid; i < npad; i += 256) s[i] = i < n ? pairs[r0 + i] : ~0ull;
     __syncthreads();
     const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>(s);
-    for (int i = tid; i < n; i += 256) {
-      const uint64_t mine = s[i];
-      uint32_t rank = 0;
-      for (int j = 0; j < npad / 2; j++) {
-        const ulonglong2 kk = s2[j];
-        rank += (kk.x < mine ? 1u : 0u) + (kk.y < mine ? 1u : 0u);
+    uint64_t mine[RANK_MERGE_MAX / 256];
+    uint32_t rank[RANK_MERGE_MAX / 256];
+#pragma unroll
+    for (int e = 0; e < RANK_MERGE_MAX / 256; e++) {
+      const int i = tid + e * 256;
+      if (i < npad) {  // wave-uniform: npad is a multiple of 64
+        const int c = i >> 6;
+        const uint64_t key = s[i];
+        uint32_t r = 0;
+#pragma unroll 8
+        for (int j = 0; j < 32; j++) {
+          const ulonglong2 kk = s2[c * 32 + j];
+          r += (kk.x < key ? 1u : 0u) + (kk.y < key ? 1u : 0u);
+        }
+        mine[e] = key;
+        rank[e] = r;
+        if (i < n) sb[c * 64 + r] = key;  // pads (~0) rank behind every real key of the chunk
       }
-      list[r0 + rank] = (uint32_t)mine;
+    }
+    __syncthreads();
+    const int last_real = n - (nchunks - 1) * 64;  // real keys in the last chunk (1..64)
+#pragma unroll
+    for (int e = 0; e < RANK_MERGE_MAX / 256; e++) {
+      const int i = tid + e * 256;
+      if (i < n) {
+        const int c = i >> 6;
+        const uint64_t key = mine[e];
+        uint32_t pos = rank[e];
+        for (int c2 = 0; c2 < nchunks; c2++) {
+          if (c2 == c) continue;  // wave-uniform
+          const uint64_t* chunk = sb + c2 * 64;
+          const int len = c2 == nchunks - 1 ? last_real : 64;
+          int lo = 0, hi = len;  // lower_bound: first index whose key is not < key
+#pragma unroll
+          for (int step = 0; step < 7; step++) {
+            if (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (chunk[mid] < key)
+                lo = mid + 1;
+              else
+                hi = mid;
+            }
+          }
+          pos += (uint32_t)lo;
+        }
+        list[r0 + pos] = (uint32_t)key;
+      }
     }
     return;
   }
@@ -305,10 +349,19 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
   while (N2 < n) N2 <<= 1;
   for (int i = tid; i < N2; i += 256) s[i] = i < n ? pairs[r0 + i] : ~0ull;
   __syncthreads();
-  const int half = N2 >> 1;
+  // Bitonic network.  Wave w owns the contiguous span [w*N2/4, (w+1)*N2/4): a stage whose pairs
+  // (a, a|j) stay inside a span (2j <= span) only needs the wave's own LDS ordering, so block
+  // barriers are paid only for the few long-stride stages (3 of 55 for N2 = 1024).
+  const int half = N2 >> 1, wave_pairs = half >> 2;  // pairs per wave and stage
+  const int lane = tid & 63, w = tid >> 6;
+  const int span = N2 >> 2;
+  bool prev_local = false;
   for (int k = 2; k <= N2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < half; i += 256) {
+      const bool local = 2 * j <= span;
+      if (!local && prev_local) __syncthreads();  // other waves' spans are about to be read
+      for (int t = lane; t < wave_pairs; t += 64) {
+        const int i = w * wave_pairs + t;
         const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
         const int b = a | j;
         const uint64_t x = s[a], y = s[b];
@@ -318,9 +371,14 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
           s[b] = x;
         }
       }
-      __syncthreads();
+      if (local)
+        __builtin_amdgcn_wave_barrier();
+      else
+        __syncthreads();
+      prev_local = local;
     }
   }
+  __syncthreads();
   for (int i = tid; i < n; i += 256) list[r0 + i] = (uint32_t)s[i];
 }
 
@@ -565,9 +623,11 @@ int gcr_tile_sort_capacity(void) { return 4096; }  // 32 KiB of LDS per workgrou
 hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, const uint64_t* pairs, uint32_t* list,
                                 int64_t max_tile_instances, const unsigned long long* frame, hipStream_t s) {
   if (T <= 0) return hipSuccess;
-  size_t n2 = 2;
+  size_t n2 = 64;
   while ((int64_t)n2 < max_tile_instances) n2 <<= 1;
-  k_tile_sort<<<T, 256, n2 * sizeof(uint64_t), s>>>(ranges, pairs, list, frame);
+  // bitonic path: n2 keys; rank/merge path (<= RANK_MERGE_MAX keys): two buffers of n rounded up to 64
+  const size_t lds = n2 <= (size_t)RANK_MERGE_MAX ? 2 * n2 * sizeof(uint64_t) : n2 * sizeof(uint64_t);
+  k_tile_sort<<<T, 256, lds, s>>>(ranges, pairs, list, frame);
   return hipGetLastError();
 }
 
