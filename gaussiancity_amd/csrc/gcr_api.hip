@@ -234,6 +234,9 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
   a.tile_count = (uint32_t*)(ib + L.img_tile_cursor);
   a.vis_list = (uint32_t*)(gb + L.geom_vis_list);
   a.vis_count = (uint32_t*)(gb + L.geom_vis_count);
+  // candidate list / counts of K1a live in the arrays only the radix fallback needs later
+  a.cand_list = (uint32_t*)(gb + L.geom_tiles_touched);
+  a.cand_count = (uint32_t*)(gb + L.geom_block_sums);
   gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &a.nblocks, &a.chunk);
   unsigned long long* frame = (unsigned long long*)(gb + L.geom_num_rendered);
   *frame_dev_out = frame;

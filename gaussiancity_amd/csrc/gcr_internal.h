@@ -27,6 +27,8 @@ struct GcrPreprocessArgs {
   uint32_t* tile_count;  // [T * GCR_CURSOR_STRIDE] per-tile instance counts (zeroed before K1)
   uint32_t* vis_list;    // [P] block b's survivors at [b*chunk, b*chunk + vis_count[b])
   uint32_t* vis_count;   // [nblocks]
+  uint32_t* cand_list;   // [P] K1a's candidates of block b at [b*chunk, b*chunk + cand_count[b])
+  uint32_t* cand_count;  // [nblocks]
   int nblocks, chunk;    // persistent grid: block b owns Gaussians [b*chunk, (b+1)*chunk)
 };
 

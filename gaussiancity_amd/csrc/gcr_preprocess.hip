@@ -113,44 +113,211 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------- K1
-// cr/forward.cu:147-233, restructured for wave64 lane efficiency.  In city-scale frames only a
-// few percent of the Gaussians survive culling, so doing the visible-only work (SH colour from
-// 192 B of coefficients, record write, tile counting) in the thread that found the survivor
-// would run it at a few percent lane utilisation in almost every wave.  Instead:
-//   * persistent grid: block b owns the contiguous chunk [b*chunk, (b+1)*chunk) of Gaussians
-//     and walks it 256 at a time;
-//   * phase A (all lanes): project, covariance, conic, radius, tile rect -> radii[] and, for
-//     survivors, a 9-word item pushed into the wave's own ring queue in LDS (wave ballot; no
-//     block barrier); the next iteration's attributes are prefetched before the math starts;
-//   * phase B (whenever a wave has >= 64 items queued, and once at the end): one item per lane --
-//     SH -> RGB, 48-byte record, clamp mask, per-tile instance counts (atomics on 128-byte
-//     padded counters), and the Gaussian's index appended to the block's visible list, which
-//     the scatter kernel and the backward preprocess iterate densely.
-// Per-Gaussian arithmetic is unchanged (gcr-fp32-v1, bit-identical to the oracle).
-constexpr int Q_CAP = 128;  // per-wave ring capacity (items); < 64 queued before a push round
-constexpr int Q_WORDS = 9;  // idx, px, py, conic.xyz, depth, rect_x, rect_y
+// cr/forward.cu:147-233, split in two for wave64 lane efficiency.  In city-scale frames only a few
+// percent of the Gaussians survive culling, and the exact per-Gaussian math (~460 VALU ops: IEEE
+// divisions, sqrt, double-precision ndc2Pix) plus the SH gather are latency-heavy.  Measured on 5M
+// Gaussians: inputs alone stream in 35 us (6.2 TB/s); doing the exact math in the streaming loop
+// cost 92 us; queueing candidates in LDS and draining them inside the same kernel still cost
+// 101 us because every wave fills its queue only at the end of its chunk, so all the gathers pile up
+// where nothing is left to overlap them.  Hence:
+//   K1a k_preprocess_cull (persistent grid, prefetch one iteration ahead): phase A0 -- the exact
+//       near-plane test plus a CONSERVATIVE fast-math screen test -- writes radii = 0 for certain
+//       culls and appends everything else to the block's candidate list.  39 us.
+//   K1b k_preprocess_project (one candidate per thread, dense): phase A1 -- the reference's exact
+//       arithmetic (gcr-fp32-v1) takes EVERY decision (det == 0, radius, tile rect, area == 0) --
+//       then phase B: SH -> RGB, the 48-byte record, clamp mask, and the compacted visible list
+//       that the binning kernels and the backward preprocess iterate.
+// A0 only ever skips Gaussians whose exact result is radius 0 / no tiles, so outputs are unchanged.
+struct PhaseAIn {
+  V3 p;
+  float c0, c1, c2, c3, c4, c5, c6;  // scale.xyz + rot.rxyz, or cov3D[0..5] (scalars: stay in VGPRs)
+};
 
-GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, const uint32_t (*q)[Q_CAP], uint32_t slot,
-                                uint32_t list_pos, uint32_t* __restrict__ vis_list) {
-  const int idx = (int)q[0][slot];
-  const float px = __uint_as_float(q[1][slot]), py = __uint_as_float(q[2][slot]);
-  const float conx = __uint_as_float(q[3][slot]), cony = __uint_as_float(q[4][slot]);
-  const float conz = __uint_as_float(q[5][slot]), depth = __uint_as_float(q[6][slot]);
-  const uint32_t rx = q[7][slot], ry = q[8][slot];
+// The load is unconditional (callers clamp idx into range): a predicated prefetch makes the
+// compiler's s_waitcnt placement lose count across the loop back-edge and wait for everything.
+template <bool PRECOMP_COV>
+GCR_DEV void phase_a_load(const GcrPreprocessArgs& a, long long idx, PhaseAIn& in) {
+  in.p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+  if (PRECOMP_COV) {
+    const float* __restrict__ c = a.cov3D_precomp + 6 * (size_t)idx;
+    in.c0 = c[0]; in.c1 = c[1]; in.c2 = c[2]; in.c3 = c[3]; in.c4 = c[4]; in.c5 = c[5];
+    in.c6 = 0.0f;
+  } else {
+    in.c0 = a.scales[3 * idx];
+    in.c1 = a.scales[3 * idx + 1];
+    in.c2 = a.scales[3 * idx + 2];
+    const float4 rot = reinterpret_cast<const float4*>(a.rotations)[idx];
+    in.c3 = rot.x; in.c4 = rot.y; in.c5 = rot.z; in.c6 = rot.w;
+  }
+}
+
+// Wave-uniform float forced into an SGPR.  The camera matrices are read once per kernel this way:
+// left to itself the compiler re-fetched them with VECTOR loads in every loop iteration (it
+// cannot prove them invariant next to the kernel's stores, so no s_load).
+GCR_DEV float gcr_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// Phase A0.  True = the exact path is CERTAIN to give radius 0 for this Gaussian.
+//  - near plane: the reference's own test on the exactly computed view depth;
+//  - screen: pixel centre known to ~1e-6 relative; radius_ref = ceil(3*sqrt(lambda_1)) with
+//    |cov2D entries| <= E = |T|_F^2 * rho(Sigma),  |T|_F <= |W|_2 * |J|_F  (wf2 >= |W|_2^2 by
+//    Gershgorin on W^T W, once per kernel; 1 for a rigid view matrix),
+//    rho(Sigma) <= (mod*s_max)^2 * |R(q)|_F^2 <= 9 (mod*s_max)^2 rmax^2  with every entry of R(q)
+//    as written at cr/forward.cu:126-130 bounded by rmax = max(1, 2|q|^2 - 1); for a
+//    caller-supplied covariance (need not be PSD) rho <= Frobenius norm.  Then
+//      Sigma PSD:      lambda_1 <= (a + c) + 0.317 <= E + 0.917
+//      any symmetric:  mid <= E + 0.3, mid^2 - det <= 2 E^2  =>  lambda_1 <= 2.42 E + 0.62.
+//    All terms are sums of squares (no cancellation), so 1-ulp rcp/sqrt and FMAs are covered many
+//    times over by the 2 % + 2 px inflation.  NaN anywhere makes the comparisons false -> candidate.
+//    The radius bound is about 2x the true radius for unit quaternions and a rigid camera, so the
+//    extra candidates are the Gaussians within a couple of radii of the screen border.
+template <bool PRECOMP_COV>
+GCR_DEV bool phase_a0_certainly_culled(const GcrPreprocessArgs& a, const float (&vm)[16], const float (&pm)[16],
+                                       float wf2, const PhaseAIn& in) {
+  const float tz = vm[2] * in.p.x + vm[6] * in.p.y + vm[10] * in.p.z + vm[14];  // exact, as transformPoint4x3
+  if (tz <= 0.2f) return true;  // in_frustum, cr/auxiliary.h:145
+  const float tx = __builtin_fmaf(vm[0], in.p.x, __builtin_fmaf(vm[4], in.p.y, __builtin_fmaf(vm[8], in.p.z, vm[12])));
+  const float ty = __builtin_fmaf(vm[1], in.p.x, __builtin_fmaf(vm[5], in.p.y, __builtin_fmaf(vm[9], in.p.z, vm[13])));
+  const float hx = __builtin_fmaf(pm[0], in.p.x, __builtin_fmaf(pm[4], in.p.y, __builtin_fmaf(pm[8], in.p.z, pm[12])));
+  const float hy = __builtin_fmaf(pm[1], in.p.x, __builtin_fmaf(pm[5], in.p.y, __builtin_fmaf(pm[9], in.p.z, pm[13])));
+  const float hw = __builtin_fmaf(pm[3], in.p.x, __builtin_fmaf(pm[7], in.p.y, __builtin_fmaf(pm[11], in.p.z, pm[15])));
+  const float pw = __builtin_amdgcn_rcpf(hw + 0.0000001f);
+  const float half_w = 0.5f * (float)a.W, half_h = 0.5f * (float)a.H;
+  const float px = __builtin_fmaf(hx * pw, half_w, half_w - 0.5f);  // ((ndc+1)*W-1)/2
+  const float py = __builtin_fmaf(hy * pw, half_h, half_h - 0.5f);
+  float rho;  // >= spectral radius of Sigma
+  if (PRECOMP_COV) {
+    rho = __builtin_amdgcn_sqrtf(in.c0 * in.c0 + in.c3 * in.c3 + in.c5 * in.c5 +
+                                 2.0f * (in.c1 * in.c1 + in.c2 * in.c2 + in.c4 * in.c4)) * 1.001f;
+  } else {
+    const float q2 = __builtin_fmaf(in.c3, in.c3, __builtin_fmaf(in.c4, in.c4, __builtin_fmaf(in.c5, in.c5, in.c6 * in.c6)));
+    // diagonal 1 - 2(u^2+v^2) lies in [1 - 2|q|^2, 1]; off-diagonal 2(uv +- rw) <= |q|^2 (AM-GM)
+    const float rmax = __builtin_fmaxf(1.0f, __builtin_fmaf(2.0f, q2, -1.0f)) * 1.0001f;  // >= every |R_ij|
+    const float smax = a.scale_modifier * __builtin_fmaxf(__builtin_fabsf(in.c0),
+                                                          __builtin_fmaxf(__builtin_fabsf(in.c1), __builtin_fabsf(in.c2)));
+    rho = 9.0f * (smax * smax) * (rmax * rmax);
+  }
+  const float rtz = __builtin_amdgcn_rcpf(tz);
+  const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+  const float cx = __builtin_fminf(limx, __builtin_fmaxf(-limx, tx * rtz));
+  const float cy = __builtin_fminf(limy, __builtin_fmaxf(-limy, ty * rtz));
+  const float j0 = a.focal_x * rtz, j1 = a.focal_y * rtz;  // J00, J11; J02 = -j0*cx, J12 = -j1*cy
+  const float jf2 = __builtin_fmaf(j0 * j0, __builtin_fmaf(cx, cx, 1.0f), (j1 * j1) * __builtin_fmaf(cy, cy, 1.0f));
+  const float E = wf2 * jf2 * rho;
+  const float lam = __builtin_fmaf(PRECOMP_COV ? 2.42f : 1.0f, E, 1.0f);
+  const float rb = __builtin_fmaf(3.06f, __builtin_amdgcn_sqrtf(lam), 2.0f);  // 3 * 1.02 * sqrt + 2 >= radius_ref
+  const float slack = 2.0f;
+  // area == 0 upstream  <=>  px + r < 1  or  px - r >= 16*grid_x  (same in y), cr/auxiliary.h:36-46
+  return px + rb < -slack || px - rb > 16.0f * (float)a.gx + slack || py + rb < -slack ||
+         py - rb > 16.0f * (float)a.gy + slack;
+}
+
+// Phase A1: the reference's exact per-Gaussian arithmetic.  Returns whether the Gaussian is
+// rendered; fills the projected state and the integer radius (0 if not rendered).
+struct Projected {
+  float px, py, conx, cony, conz, depth;
+  uint32_t rect_x, rect_y;
+};
+
+template <bool PRECOMP_COV>
+GCR_DEV bool phase_a1_exact(const GcrPreprocessArgs& a, const float (&vm)[16], const float (&pm)[16], int idx,
+                            const PhaseAIn& in, Projected& out, int& radius_out) {
+  radius_out = 0;
+  const V3 p_orig = in.p;
+  const V3 p_view = transform_point_4x3(p_orig, vm);
+  if (p_view.z <= 0.2f) return false;  // in_frustum
+  const float hx = pm[0] * p_orig.x + pm[4] * p_orig.y + pm[8] * p_orig.z + pm[12];
+  const float hy = pm[1] * p_orig.x + pm[5] * p_orig.y + pm[9] * p_orig.z + pm[13];
+  const float hw = pm[3] * p_orig.x + pm[7] * p_orig.y + pm[11] * p_orig.z + pm[15];
+  const float p_w = 1.0f / (hw + 0.0000001f);
+  const float projx = hx * p_w, projy = hy * p_w;
+  float cov3D[6];
+  if (PRECOMP_COV) {
+    cov3D[0] = in.c0; cov3D[1] = in.c1; cov3D[2] = in.c2;
+    cov3D[3] = in.c3; cov3D[4] = in.c4; cov3D[5] = in.c5;
+  } else {
+    const V3 sc = {in.c0, in.c1, in.c2};
+    compute_cov3d(sc, a.scale_modifier, make_float4(in.c3, in.c4, in.c5, in.c6), cov3D);
+  }
+  Cov2DCtx cc;
+  float cov[3];
+  cov2d_setup(p_orig, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy, vm, cc);
+  cov2d_eval(cc, cov3D, cov);
+  const float det = (cov[0] * cov[2] - cov[1] * cov[1]);
+  if (det == 0.0f) return false;
+  const float det_inv = 1.f / det;
+  const float conx = cov[2] * det_inv, cony = -cov[1] * det_inv, conz = cov[0] * det_inv;
+  const float mid = 0.5f * (cov[0] + cov[2]);
+  const float lambda1 = mid + __builtin_sqrtf(gcr_max(0.1f, mid * mid - det));
+  const float lambda2 = mid - __builtin_sqrtf(gcr_max(0.1f, mid * mid - det));
+  const float my_radius = __builtin_ceilf(3.f * __builtin_sqrtf(gcr_max(lambda1, lambda2)));
+  const float px = gcr_ndc2pix(projx, a.W), py = gcr_ndc2pix(projy, a.H);
+  // getRect, cr/auxiliary.h:36-46.  min(grid, max(0, (int)x)) == (int)clamp(x, 0, grid) for every x
+  // incl. NaN/inf (the float clamp returns the non-NaN operand); 3 VALU ops instead of ~9 per bound.
+  const int ri = gcr_f2i_sat(my_radius);
+  const float rf = (float)ri;
+  const float gxf = (float)a.gx, gyf = (float)a.gy;
+  const int minx = (int)__builtin_fminf(__builtin_fmaxf((px - rf) / 16.0f, 0.0f), gxf);
+  const int miny = (int)__builtin_fminf(__builtin_fmaxf((py - rf) / 16.0f, 0.0f), gyf);
+  const int maxx = (int)__builtin_fminf(__builtin_fmaxf((px + rf + 16.0f - 1.0f) / 16.0f, 0.0f), gxf);
+  const int maxy = (int)__builtin_fminf(__builtin_fmaxf((py + rf + 16.0f - 1.0f) / 16.0f, 0.0f), gyf);
+  if ((uint32_t)(maxx - minx) * (uint32_t)(maxy - miny) == 0) return false;
+  radius_out = ri;
+  out.px = px; out.py = py; out.conx = conx; out.cony = cony; out.conz = conz; out.depth = p_view.z;
+  out.rect_x = (uint32_t)minx | ((uint32_t)maxx << 16);
+  out.rect_y = (uint32_t)miny | ((uint32_t)maxy << 16);
+  if (!PRECOMP_COV) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov3D[i];
+  }
+  return true;
+}
+
+// Phase B inputs (SH coefficients / colour, opacity), fetched in one go for the survivors.
+struct PhaseBIn {
+  float sh[48];  // SH coefficients [coef][channel], or colour in sh[0..2] when precomputed
+  float opacity;
+};
+
+GCR_DEV void phase_b_fetch(const GcrPreprocessArgs& a, int idx, PhaseBIn& b) {
+  b.opacity = a.opacities[idx];
+  if (a.colors_precomp == nullptr) {
+    // M == 16 (the degree-3 layout): the 192 contiguous bytes are fetched with 12 dwordx4 loads --
+    // 48 scalar loads with a 192-byte lane stride cost ~11 M cache-line requests per frame.
+    const float* __restrict__ shp = a.shs + (size_t)idx * a.M * 3;
+    if (a.M == 16) {
+      const float4* __restrict__ sh4 = reinterpret_cast<const float4*>(shp);
+#pragma unroll
+      for (int v = 0; v < 12; v++) {
+        const float4 t = sh4[v];
+        b.sh[4 * v] = t.x; b.sh[4 * v + 1] = t.y; b.sh[4 * v + 2] = t.z; b.sh[4 * v + 3] = t.w;
+      }
+    } else {
+      const int nfl = 3 * (a.D + 1) * (a.D + 1);
+#pragma unroll
+      for (int v = 0; v < 48; v++) b.sh[v] = v < nfl ? shp[v] : 0.0f;
+    }
+  } else {
+    b.sh[0] = a.colors_precomp[3 * idx];
+    b.sh[1] = a.colors_precomp[3 * idx + 1];
+    b.sh[2] = a.colors_precomp[3 * idx + 2];
+  }
+}
+
+// Phase B: colour, record, visible-list entry (and tile counts in the global-cursor variant).
+GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 mean, const Projected& pr,
+                                const PhaseBIn& bin, uint32_t list_pos, uint32_t* __restrict__ vis_list) {
   float cr, cg, cb;
   if (a.colors_precomp == nullptr) {
     // computeColorFromSH, cr/forward.cu:20-66
     const float* __restrict__ cp = a.campos;
-    const float ox = a.means3D[3 * idx] - cp[0], oy = a.means3D[3 * idx + 1] - cp[1],
-                oz = a.means3D[3 * idx + 2] - cp[2];
+    const float ox = mean.x - cp[0], oy = mean.y - cp[1], oz = mean.z - cp[2];
     const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
     const float x = ox / len, y = oy / len, z = oz / len;
-    const float* __restrict__ sh = a.shs + (size_t)idx * a.M * 3;
-    float res[3];
     const int deg = a.D;
+    float res[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-#define GCR_S(i) sh[3 * (i) + ch]
+#define GCR_S(i) bin.sh[3 * (i) + ch]
       float result = SH_C0 * GCR_S(0);
       if (deg > 0) {
         result = result - SH_C1 * y * GCR_S(1) + SH_C1 * z * GCR_S(2) - SH_C1 * x * GCR_S(3);
@@ -177,58 +344,33 @@ GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, const uint32_t (*q)[
     cg = gcr_max(res[1], 0.0f);
     cb = gcr_max(res[2], 0.0f);
   } else {
-    cr = a.colors_precomp[3 * idx];
-    cg = a.colors_precomp[3 * idx + 1];
-    cb = a.colors_precomp[3 * idx + 2];
+    cr = bin.sh[0];
+    cg = bin.sh[1];
+    cb = bin.sh[2];
   }
   float4* __restrict__ rec = a.rec + (size_t)idx * GCR_REC_QUADS;
-  rec[0] = make_float4(px, py, conx, cony);
-  rec[1] = make_float4(conz, a.opacities[idx], cr, cg);
-  rec[2] = make_float4(cb, depth, __uint_as_float(rx), __uint_as_float(ry));
+  rec[0] = make_float4(pr.px, pr.py, pr.conx, pr.cony);
+  rec[1] = make_float4(pr.conz, bin.opacity, cr, cg);
+  rec[2] = make_float4(cb, pr.depth, __uint_as_float(pr.rect_x), __uint_as_float(pr.rect_y));
   vis_list[list_pos] = (uint32_t)idx;
   // per-tile instance counts, global-cursor variant only (gcr_binning.hip explains why the
   // default path counts in LDS instead)
-  const int minx = (int)(rx & 0xffffu), maxx = (int)(rx >> 16), miny = (int)(ry & 0xffffu), maxy = (int)(ry >> 16);
-  if (a.tile_count != nullptr)  // only in the global-cursor variant (tile table too big for LDS)
+  if (a.tile_count != nullptr) {
+    const int minx = (int)(pr.rect_x & 0xffffu), maxx = (int)(pr.rect_x >> 16);
+    const int miny = (int)(pr.rect_y & 0xffffu), maxy = (int)(pr.rect_y >> 16);
     for (int ty = miny; ty < maxy; ty++)
       for (int tx = minx; tx < maxx; tx++)
         atomicAdd(&a.tile_count[(size_t)(ty * a.gx + tx) * GCR_CURSOR_STRIDE], 1u);
-}
-
-// Raw per-Gaussian inputs of phase A, fetched one iteration ahead so that the ~460-instruction
-// covariance math of the current Gaussian overlaps the HBM latency of the next.
-struct PhaseAIn {
-  V3 p;
-  float c0, c1, c2, c3, c4, c5, c6;  // scale.xyz + rot.rxyz, or cov3D[0..5] (scalars: stay in VGPRs)
-};
-
-// The load is unconditional (callers clamp idx into range): a predicated prefetch makes the
-// compiler's s_waitcnt placement lose count across the loop back-edge and wait for everything.
-template <bool PRECOMP_COV>
-GCR_DEV void phase_a_load(const GcrPreprocessArgs& a, long long idx, PhaseAIn& in) {
-  in.p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-  if (PRECOMP_COV) {
-    const float* __restrict__ c = a.cov3D_precomp + 6 * (size_t)idx;
-    in.c0 = c[0]; in.c1 = c[1]; in.c2 = c[2]; in.c3 = c[3]; in.c4 = c[4]; in.c5 = c[5];
-  } else {
-    in.c0 = a.scales[3 * idx];
-    in.c1 = a.scales[3 * idx + 1];
-    in.c2 = a.scales[3 * idx + 2];
-    const float4 rot = reinterpret_cast<const float4*>(a.rotations)[idx];
-    in.c3 = rot.x; in.c4 = rot.y; in.c5 = rot.z; in.c6 = rot.w;
   }
 }
 
-// Wave-uniform float forced into an SGPR.  The camera matrices are read once per kernel this way:
-// left to itself the compiler re-fetched them with VECTOR loads in every loop iteration (it
-// cannot prove them invariant next to the kernel's stores, so no s_load).
-GCR_DEV float gcr_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-
+// K1a: streaming cull.  Persistent grid, inputs prefetched one iteration ahead; writes radii = 0
+// for everything phase A0 rules out and appends the rest to the block's candidate list
+// (wave-level ballot compaction, one LDS atomic per wave and iteration).
 template <bool PRECOMP_COV>
-__global__ __launch_bounds__(256) void k_preprocess(const GcrPreprocessArgs a) {
-  __shared__ uint32_t q[4][Q_WORDS][Q_CAP];  // one ring per wave: no block barrier in the loop
-  __shared__ uint32_t list_tail;             // length of this block's visible list
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+__global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs a) {
+  __shared__ uint32_t list_tail;  // length of this block's candidate list
+  const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) list_tail = 0;
   __syncthreads();
   float vm[16], pm[16];
@@ -237,12 +379,24 @@ __global__ __launch_bounds__(256) void k_preprocess(const GcrPreprocessArgs a) {
     vm[i] = gcr_uniform(a.view[i]);
     pm[i] = gcr_uniform(a.proj[i]);
   }
+  // wf2 >= |W|_2^2 for the 3x3 block W the covariance projection uses: Gershgorin row sums of W^T W
+  float wf2 = 0.0f;
+  {
+    const float wc[3][3] = {{vm[0], vm[1], vm[2]}, {vm[4], vm[5], vm[6]}, {vm[8], vm[9], vm[10]}};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      float row = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        row += __builtin_fabsf(wc[0][i] * wc[0][j] + wc[1][i] * wc[1][j] + wc[2][i] * wc[2][j]);
+      wf2 = __builtin_fmaxf(wf2, row);
+    }
+    wf2 *= 1.001f;
+  }
   const long long chunk_begin = (long long)blockIdx.x * a.chunk;
   const long long chunk_end = chunk_begin + a.chunk < a.P ? chunk_begin + a.chunk : a.P;
-  uint32_t* __restrict__ my_list = a.vis_list + chunk_begin;
-  const uint32_t (*qw)[Q_CAP] = q[w];
+  uint32_t* __restrict__ my_cand = a.cand_list + chunk_begin;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  uint32_t head = 0, tail = 0;  // wave-uniform ring cursors
 
   PhaseAIn cur, nxt;
   long long idx64 = chunk_begin + tid;
@@ -251,96 +405,69 @@ __global__ __launch_bounds__(256) void k_preprocess(const GcrPreprocessArgs a) {
   for (long long base = chunk_begin; base < chunk_end; base += 256) {
     idx64 = base + tid;
     phase_a_load<PRECOMP_COV>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);  // prefetch
-    bool keep = false;
-    uint32_t item[Q_WORDS];
+    bool candidate = false;
     if (idx64 < chunk_end) {
-      const int idx = (int)idx64;
-      int my_radius_i = 0;
-      const V3 p_orig = cur.p;
-      const V3 p_view = transform_point_4x3(p_orig, vm);
-      if (!(p_view.z <= 0.2f)) {  // in_frustum
-        const float hx = pm[0] * p_orig.x + pm[4] * p_orig.y + pm[8] * p_orig.z + pm[12];
-        const float hy = pm[1] * p_orig.x + pm[5] * p_orig.y + pm[9] * p_orig.z + pm[13];
-        const float hw = pm[3] * p_orig.x + pm[7] * p_orig.y + pm[11] * p_orig.z + pm[15];
-        const float p_w = 1.0f / (hw + 0.0000001f);
-        const float projx = hx * p_w, projy = hy * p_w;
-        float cov3D[6];
-        if (PRECOMP_COV) {
-          cov3D[0] = cur.c0; cov3D[1] = cur.c1; cov3D[2] = cur.c2;
-          cov3D[3] = cur.c3; cov3D[4] = cur.c4; cov3D[5] = cur.c5;
-        } else {
-          const V3 sc = {cur.c0, cur.c1, cur.c2};
-          compute_cov3d(sc, a.scale_modifier, make_float4(cur.c3, cur.c4, cur.c5, cur.c6), cov3D);
-        }
-        Cov2DCtx cc;
-        float cov[3];
-        cov2d_setup(p_orig, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy, vm, cc);
-        cov2d_eval(cc, cov3D, cov);
-        const float det = (cov[0] * cov[2] - cov[1] * cov[1]);
-        if (det != 0.0f) {
-          const float det_inv = 1.f / det;
-          const float conx = cov[2] * det_inv, cony = -cov[1] * det_inv, conz = cov[0] * det_inv;
-          const float mid = 0.5f * (cov[0] + cov[2]);
-          const float lambda1 = mid + __builtin_sqrtf(gcr_max(0.1f, mid * mid - det));
-          const float lambda2 = mid - __builtin_sqrtf(gcr_max(0.1f, mid * mid - det));
-          const float my_radius = __builtin_ceilf(3.f * __builtin_sqrtf(gcr_max(lambda1, lambda2)));
-          const float px = gcr_ndc2pix(projx, a.W), py = gcr_ndc2pix(projy, a.H);
-          // getRect, cr/auxiliary.h:36-46
-          const int ri = gcr_f2i_sat(my_radius);
-          const float rf = (float)ri;
-          // min(grid, max(0, (int)x)) == (int)clamp(x, 0, grid) for every x incl. NaN/inf (the
-          // float clamp returns the non-NaN operand); 3 VALU ops instead of ~9 per bound.
-          const float gxf = (float)a.gx, gyf = (float)a.gy;
-          const int minx = (int)__builtin_fminf(__builtin_fmaxf((px - rf) / 16.0f, 0.0f), gxf);
-          const int miny = (int)__builtin_fminf(__builtin_fmaxf((py - rf) / 16.0f, 0.0f), gyf);
-          const int maxx = (int)__builtin_fminf(__builtin_fmaxf((px + rf + 16.0f - 1.0f) / 16.0f, 0.0f), gxf);
-          const int maxy = (int)__builtin_fminf(__builtin_fmaxf((py + rf + 16.0f - 1.0f) / 16.0f, 0.0f), gyf);
-          if ((uint32_t)(maxx - minx) * (uint32_t)(maxy - miny) != 0) {
-            keep = true;
-            my_radius_i = ri;
-            item[0] = (uint32_t)idx;
-            item[1] = __float_as_uint(px);
-            item[2] = __float_as_uint(py);
-            item[3] = __float_as_uint(conx);
-            item[4] = __float_as_uint(cony);
-            item[5] = __float_as_uint(conz);
-            item[6] = __float_as_uint(p_view.z);
-            item[7] = (uint32_t)minx | ((uint32_t)maxx << 16);
-            item[8] = (uint32_t)miny | ((uint32_t)maxy << 16);
-            if (!PRECOMP_COV) {
-#pragma unroll
-              for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov3D[i];
-            }
-          }
-        }
-      }
-      a.radii[idx] = my_radius_i;
+      candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur);
+      if (!candidate) a.radii[idx64] = 0;
     }
-    // push survivors into this wave's ring
-    const uint64_t m = __ballot(keep);
-    if (keep) {
-      const uint32_t slot = (tail + (uint32_t)__popcll(m & lt_mask)) & (Q_CAP - 1);
-#pragma unroll
-      for (int k = 0; k < Q_WORDS; k++) q[w][k][slot] = item[k];
-    }
-    tail += (uint32_t)__popcll(m);
-    __builtin_amdgcn_wave_barrier();
-    if (tail - head >= 64u) {  // wave-uniform: a full wave of survivors is ready
-      uint32_t lbase = 0;
-      if (lane == 0) lbase = atomicAdd(&list_tail, 64u);
-      lbase = __shfl(lbase, 0, 64);
-      preprocess_phase_b(a, qw, (head + lane) & (Q_CAP - 1), lbase + lane, my_list);
-      head += 64u;
-      __builtin_amdgcn_wave_barrier();
+    const uint64_t m = __ballot(candidate);
+    if (m != 0ull) {
+      uint32_t wbase = 0;
+      if (lane == 0) wbase = atomicAdd(&list_tail, (uint32_t)__popcll(m));
+      wbase = __shfl(wbase, 0, 64);
+      if (candidate) my_cand[wbase + (uint32_t)__popcll(m & lt_mask)] = (uint32_t)idx64;
     }
     cur = nxt;
   }
-  const uint32_t rest = tail - head;  // < 64
-  if (rest != 0u) {
-    uint32_t lbase = 0;
-    if (lane == 0) lbase = atomicAdd(&list_tail, rest);
-    lbase = __shfl(lbase, 0, 64);
-    if ((uint32_t)lane < rest) preprocess_phase_b(a, qw, (head + lane) & (Q_CAP - 1), lbase + lane, my_list);
+  __syncthreads();
+  if (tid == 0) a.cand_count[blockIdx.x] = list_tail;
+}
+
+// K1b: dense pass over the candidates of K1a block `blockIdx.x`, one candidate per thread: the
+// reference's exact arithmetic takes every decision, survivors get colour + record and are
+// compacted into the block's visible list.  Gather latency is hidden by occupancy here instead of
+// stalling the streaming kernel.  (Tried and measured slower: one-wave workgroups with a global
+// atomic per wave, 115 us; prefetching the SH coefficients before the exact math, no gain.)
+template <bool PRECOMP_COV>
+__global__ __launch_bounds__(256) void k_preprocess_project(const GcrPreprocessArgs a) {
+  __shared__ uint32_t list_tail;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) list_tail = 0;
+  __syncthreads();
+  float vm[16], pm[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    vm[i] = gcr_uniform(a.view[i]);
+    pm[i] = gcr_uniform(a.proj[i]);
+  }
+  const size_t chunk_begin = (size_t)blockIdx.x * a.chunk;
+  const uint32_t* __restrict__ my_cand = a.cand_list + chunk_begin;
+  uint32_t* __restrict__ my_list = a.vis_list + chunk_begin;
+  const uint32_t ncand = a.cand_count[blockIdx.x];
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (uint32_t it0 = 0; it0 < ncand; it0 += 256) {  // block-uniform trip count
+    const uint32_t it = it0 + tid;
+    bool keep = false;
+    int idx = 0, radius = 0;
+    PhaseAIn in;
+    Projected pr;
+    if (it < ncand) {
+      idx = (int)my_cand[it];
+      phase_a_load<PRECOMP_COV>(a, idx, in);
+      keep = phase_a1_exact<PRECOMP_COV>(a, vm, pm, idx, in, pr, radius);
+      a.radii[idx] = radius;
+    }
+    const uint64_t m = __ballot(keep);
+    if (m != 0ull) {
+      uint32_t lbase = 0;
+      if (lane == 0) lbase = atomicAdd(&list_tail, (uint32_t)__popcll(m));
+      lbase = __shfl(lbase, 0, 64);
+      if (keep) {
+        PhaseBIn bin;
+        phase_b_fetch(a, idx, bin);
+        preprocess_phase_b(a, idx, in.p, pr, bin, lbase + (uint32_t)__popcll(m & lt_mask), my_list);
+      }
+    }
   }
   __syncthreads();
   if (tid == 0) a.vis_count[blockIdx.x] = list_tail;
@@ -683,7 +810,7 @@ int gcr_preprocess_resident_blocks(void) {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_preprocess<false>, 256, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_preprocess_cull<false>, 256, 0) != hipSuccess || per_cu < 1)
       per_cu = 4;
     int n = per_cu * cus;
     return n > GCR_K1_MAX_BLOCKS ? GCR_K1_MAX_BLOCKS : (n < 1 ? 1 : n);
@@ -693,10 +820,13 @@ int gcr_preprocess_resident_blocks(void) {
 
 hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
-  if (a.cov3D_precomp != nullptr)
-    k_preprocess<true><<<a.nblocks, 256, 0, s>>>(a);
-  else
-    k_preprocess<false><<<a.nblocks, 256, 0, s>>>(a);
+  if (a.cov3D_precomp != nullptr) {
+    k_preprocess_cull<true><<<a.nblocks, 256, 0, s>>>(a);
+    k_preprocess_project<true><<<a.nblocks, 256, 0, s>>>(a);
+  } else {
+    k_preprocess_cull<false><<<a.nblocks, 256, 0, s>>>(a);
+    k_preprocess_project<false><<<a.nblocks, 256, 0, s>>>(a);
+  }
   return hipGetLastError();
 }
 
