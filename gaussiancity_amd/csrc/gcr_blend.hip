@@ -79,9 +79,10 @@ GCR_DEV float blend_exp(float x) {
 //     (T*(1-a) < 1e-4 upstream): test_T = Tw*(1-a) is then 0 and the entry can never be `use`d;
 //     Tout keeps the value upstream leaves in T.
 template <bool FAST_EXP>
-__global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
+__global__ __launch_bounds__(256, 8) void k_blend_fwd(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[CHUNK];
-  __shared__ uint16_t sIdx[4][CHUNK];  // per-wave compacted entry indices
+  __shared__ uint2 sList[4][CHUNK + 2];  // per-wave compacted entries: {byte offset into sE,
+                                         // contributor number = list position + 1}
 
   if (a.frame != nullptr && a.frame[2] == 0ull) return;  // speculative launch vetoed
   const int tile = blockIdx.x;
@@ -95,14 +96,47 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
   const int total = (int)(r1 - r0);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const char* const sEb = reinterpret_cast<const char*>(sE);
 
-  float Tw = inside ? 1.0f : 0.0f;  // working transmittance, 0 == pixel finished
-  float Tout = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+  // Working transmittance: Tw > 0 while the pixel is live and holds upstream's T; when the pixel
+  // finishes (T*(1-a) < 1e-4 upstream) the sign is flipped, which keeps |Tw| = the T upstream
+  // leaves behind while making test_T = Tw*(1-a) <= 0, so no later entry can be `use`d.
+  float Tw = inside ? 1.0f : -1.0f;
+  float C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
   uint32_t last_contributor = 0;
+
+// One list entry (record QA/QB/QC, contributor CON) against this lane's pixel; sets `live` to
+// whether any lane of the wave still has a live pixel.
+#define GCR_BLEND_STEP(QA, QB, QC, CON)                                                      \
+  {                                                                                          \
+    const float dx = QA.x - pixx, dy = QA.y - pixy;                                          \
+    const float power = gcr_power(QA.z, QA.w, QB.x, dx, dy);                                 \
+    const bool in_range = !(power > 0.0f) && !(power < QC.y);                                \
+    if (__ballot(in_range) != 0ull) { /* wave-uniform */                                     \
+      /* lanes outside [pmin, 0] may produce garbage; every use below is behind a select */  \
+      const float araw = __builtin_fminf(0.99f, QB.y * blend_exp<FAST_EXP>(power));          \
+      const bool valid = in_range && !(araw < 1.0f / 255.0f);                                \
+      const float test_T = Tw * (1 - araw);                                                  \
+      const bool use = valid && !(test_T < 0.0001f);                                         \
+      const float n0 = __builtin_fmaf(QB.z * araw, Tw, C0);                                  \
+      const float n1 = __builtin_fmaf(QB.w * araw, Tw, C1);                                  \
+      const float n2 = __builtin_fmaf(QC.x * araw, Tw, C2);                                  \
+      C0 = use ? n0 : C0;                                                                    \
+      C1 = use ? n1 : C1;                                                                    \
+      C2 = use ? n2 : C2;                                                                    \
+      last_contributor = use ? (CON) : last_contributor;                                     \
+      Tw = use ? test_T : (valid ? -__builtin_fabsf(Tw) : Tw);                               \
+      live = __ballot(Tw > 0.0f) != 0ull;                                                    \
+    }                                                                                        \
+  }
+#define GCR_BLEND_LOAD(QA, QB, QC, OFF)                            \
+  QA = *reinterpret_cast<const float4*>(sEb + (OFF));             \
+  QB = *reinterpret_cast<const float4*>(sEb + (OFF) + 16);         \
+  QC = *reinterpret_cast<const float2*>(sEb + (OFF) + 32);
 
   for (int base = 0; base < total; base += CHUNK) {
     // block-wide vote (cr/forward.cu:284-286); also fences the previous chunk's LDS reads
-    if (__syncthreads_count(Tw == 0.0f) == 256) break;
+    if (__syncthreads_count(!(Tw > 0.0f)) == 256) break;
     const int n = min(CHUNK, total - base);
     uint32_t my_mask = 0;
     if (tid < n) {
@@ -117,7 +151,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
     }
     sE[tid].mask = my_mask;
     __syncthreads();
-    if (__ballot(Tw != 0.0f) == 0ull) continue;  // this wave's quadrant is finished; keep voting
+    if (__ballot(Tw > 0.0f) == 0ull) continue;  // this wave's quadrant is finished; keep voting
     // compact this wave's entries (ascending list order is preserved)
     int cnt = 0;
 #pragma unroll
@@ -125,37 +159,39 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
       const int jj = k * 64 + lane;
       const bool rel = (sE[jj].mask >> w) & 1u;
       const uint64_t m = __ballot(rel);
-      if (rel) sIdx[w][cnt + __popcll(m & lt_mask)] = (uint16_t)jj;
+      if (rel)
+        sList[w][cnt + __popcll(m & lt_mask)] =
+            make_uint2((uint32_t)(jj * (int)sizeof(StagedEntry)), (uint32_t)(base + jj + 1));
       cnt += __popcll(m);
     }
+    // two pad slots so the pipeline below may read past the end (the values are never consumed)
+    if (lane < 2) sList[w][cnt + lane] = make_uint2(0u, 0u);
     __builtin_amdgcn_wave_barrier();
-    for (int i = 0; i < cnt; i++) {
-      const int j = sIdx[w][i];
-      const float4 qa = sE[j].a;
-      const float2 qc = sE[j].c;
-      const float4 qb = sE[j].b;
-      const float dx = qa.x - pixx, dy = qa.y - pixy;
-      const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
-      const bool in_range = !(power > 0.0f) && !(power < qc.y);
-      if (__ballot(in_range) == 0ull) continue;  // wave-uniform
-      // lanes outside [pmin, 0] may produce garbage here; every use below is behind a select
-      const float araw = __builtin_fminf(0.99f, qb.y * blend_exp<FAST_EXP>(power));
-      const bool valid = in_range && !(araw < 1.0f / 255.0f);
-      const float test_T = Tw * (1 - araw);
-      const bool use = valid && !(test_T < 0.0001f);
-      const float n0 = __builtin_fmaf(qb.z * araw, Tw, C0);
-      const float n1 = __builtin_fmaf(qb.w * araw, Tw, C1);
-      const float n2 = __builtin_fmaf(qc.x * araw, Tw, C2);
-      C0 = use ? n0 : C0;
-      C1 = use ? n1 : C1;
-      C2 = use ? n2 : C2;
-      Tout = use ? test_T : Tout;
-      last_contributor = use ? (uint32_t)(base + j + 1) : last_contributor;
-      Tw = use ? test_T : (valid ? 0.0f : Tw);
-      if (__ballot(Tw != 0.0f) == 0ull) break;
+    // Software pipeline, two entries per trip with ping-pong registers: while entry i blends,
+    // the record of entry i+1 and the list slot of entry i+2 are already in flight.
+    const uint2* lp = &sList[w][0];
+    float4 qa0, qb0, qa1, qb1;
+    float2 qc0, qc1;
+    uint2 e0 = lp[0], e1 = lp[1];
+    GCR_BLEND_LOAD(qa0, qb0, qc0, e0.x)
+    bool live = true;
+    for (int i = 0; i < cnt; i += 2, lp += 2) {
+      GCR_BLEND_LOAD(qa1, qb1, qc1, e1.x)
+      const uint32_t con0 = e0.y;
+      e0 = lp[2];
+      GCR_BLEND_STEP(qa0, qb0, qc0, con0)
+      if (!live || i + 1 >= cnt) break;
+      GCR_BLEND_LOAD(qa0, qb0, qc0, e0.x)
+      const uint32_t con1 = e1.y;
+      e1 = lp[3];
+      GCR_BLEND_STEP(qa1, qb1, qc1, con1)
+      if (!live) break;
     }
   }
+#undef GCR_BLEND_STEP
+#undef GCR_BLEND_LOAD
   if (inside) {
+    const float Tout = __builtin_fabsf(Tw);
     const size_t pix_id = (size_t)a.W * pyi + pxi;
     const size_t plane = (size_t)a.H * a.W;
     a.final_T[pix_id] = Tout;
