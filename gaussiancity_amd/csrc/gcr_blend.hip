@@ -79,7 +79,7 @@ GCR_DEV float blend_exp(float x) {
 //     (T*(1-a) < 1e-4 upstream): test_T = Tw*(1-a) is then 0 and the entry can never be `use`d;
 //     Tout keeps the value upstream leaves in T.
 template <bool FAST_EXP>
-__global__ __launch_bounds__(256, 8) void k_blend_fwd(const GcrBlendArgs a) {
+__global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[CHUNK];
   __shared__ uint2 sList[4][CHUNK + 2];  // per-wave compacted entries: {byte offset into sE,
                                          // contributor number = list position + 1}
