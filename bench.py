@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--fast-exp", action="store_true", help="non-parity v_exp_f32 variant (A/B only)")
+    ap.add_argument("--train-step", action="store_true",
+                    help="C4 training-step harness (fwd + loss + bwd + gradient all-reduce) instead of the frame loop")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the frame loop alternates over (frames are independent; 1 = serial)")
     args = ap.parse_args()
@@ -101,6 +103,22 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def copy_ceiling():
+        """On-box device-copy ceiling: 1 GiB -> 1 GiB D2D copies, read + write bytes."""
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+        b = torch.empty_like(a)
+        for _ in range(2):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(10):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        return 10 * 2 * a.numel() * 4 / 1e9 / (time.perf_counter() - tc)
+
+    if args.train_step:
+        return train_step_bench(args, torch, dist, N, synth, GaussianRasterizerWrapper, dev, world, rank, barrier)
 
     def load_scene(cfg_name, points=None):
         cfg, sc = synth.make_scene(cfg_name, points)
@@ -195,15 +213,24 @@ def main():
         achieved = ab[dom] / 1e9 / (dom_ms / 1e3) if dom_ms > 0 else 0.0
         blend_ms = stage["blend_fwd"]
         blend_ach = ab["blend_fwd"] / 1e9 / (blend_ms / 1e3) if blend_ms > 0 else 0.0
+        valu_frac = None
         traffic = None  # HBM bytes per launch from the committed rocprofv3 --pmc passes (C3 only)
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if args.config == "C3" and args.points is None and os.path.exists(tpath):
             tk = json.load(open(tpath))["kernels"].get(dom)
             if tk:  # gfx950: FETCH_SIZE counts half of a 16-B/lane read (MI355X_MICROARCH.md, HBM)
                 traffic = int((2 * tk["FETCH_SIZE_KB"] + tk["WRITE_SIZE_KB"]) * 1024)
+                if tk.get("SQ_INSTS_VALU") and dom_ms > 0:
+                    # the dominant kernel is instruction-bound: committed SQ_INSTS_VALU per launch against what
+                    # 256 CUs x 4 SIMDs can issue in the measured launch time (2 cycles per wave64 VALU
+                    # instruction, 2.4 GHz peak clock -- MI355X_MICROARCH.md "Wave scheduling")
+                    valu_frac = tk["SQ_INSTS_VALU"] * 2 / (1024 * 2.4e9 * dom_ms / 1e3)
+        ceiling = copy_ceiling()
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "copy_ceiling_GBps": round(ceiling, 1), "frac_of_copy_ceiling": round(achieved / ceiling, 4),
                     "launch_ms": round(dom_ms, 4), "alg_bytes_per_launch": int(ab[dom]),
+                    "valu_issue_frac": round(valu_frac, 3) if valu_frac else None,
                     "alpha_blend": {"kernel": "blend_fwd", "achieved": round(blend_ach, 1),
                                     "frac": round(blend_ach / HBM_PEAK_GBS, 4),
                                     "launch_ms": round(blend_ms, 4)}}
@@ -297,6 +324,68 @@ def main():
                                 "value": round(ms2, 4), "unit": "ms/frame", "higher_is_better": False,
                                 "stages_ms": {k: round(v, 4) for k, v in st2.items()}}
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, barrier):
+    """C4: the reference's G-step shape around the rasterizer -- N=16384 points with
+    precomputed colours, render 960x540, crop 640x448, L1 stand-in loss, backward, then the DDP
+    all-reduce(avg) of a 69,809,101-parameter fp32 stand-in gradient set (core/train.py:263-295,
+    78-87).  One frame per rank per step; the all-reduce is the path's only collective."""
+    from gaussiancity_amd.frames import TrainStepHarness, allreduce_gradients
+    cfg, sc = synth.make_scene("C4", args.points)
+    W, H = cfg["W"], cfg["H"]
+    cw, ch = cfg["crop"]
+    wr = Wrapper(synth.intrinsics(W, H), (W, H), device=dev)
+    # [N,14] = xyz, opacity, scale3, rot4 (x,y,z,w), rgb3  (dgr/__init__.py:404-409)
+    rot = sc["rotations"][:, [1, 2, 3, 0]]
+    pts_np = np.concatenate([sc["means3D"], sc["opacities"], sc["scales"], rot, sc["colors_precomp"]], axis=1)
+    points = torch.from_numpy(pts_np.astype(np.float32)).to(dev).requires_grad_(True)
+    target = torch.zeros((3, ch, cw), dtype=torch.float32, device=dev)
+    h = TrainStepHarness(wr, crop=((W - cw) // 2, (H - ch) // 2, cw, ch), device=dev)
+    poses = synth.orbit_poses()
+
+    def step(i):
+        pos, quat = poses[(rank + i * world) % len(poses)]
+        points.grad = None
+        return h.step(points, pos, quat, target)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # the collective alone, same message sizes
+    n_ar = 5
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(n_ar):
+        allreduce_gradients([h.param_grad])
+    barrier()
+    ar_ms = 1e3 * (time.perf_counter() - t1) / n_ar
+    if world > 1:
+        tt = torch.tensor([elapsed, ar_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, ar_ms = float(tt[0].item()), float(tt[1].item())
+    if rank == 0:
+        nbytes = h.param_grad.numel() * 4
+        bus = (2.0 * (world - 1) / world) * nbytes / 1e9 / (ar_ms / 1e3) if world > 1 else None
+        print(json.dumps({
+            "metric": "training steps/sec (C4 harness: fwd + L1 + bwd + grad all-reduce)",
+            "value": round(args.steps * world / elapsed, 3), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (gcity-synth-v1 %s, seed %d)" % (cfg["scene"], cfg["seed"]),
+            "config": {"workload": "C4: %d points, precomputed colours, %dx%d render, %dx%d crop, "
+                                   "69,809,101 fp32 stand-in gradients" % (cfg["P"], W, H, cw, ch),
+                       "parallelism": "DDP shape: one frame per rank per step, bucketed all-reduce(avg) over RCCL"},
+            "allreduce_ms": round(ar_ms, 4) if world > 1 else None, "allreduce_bytes": nbytes,
+            "allreduce_bus_GBps": round(bus, 1) if bus else None}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""profiles/<tag>_traffic.json from the FETCH_SIZE / WRITE_SIZE rocpd databases of
+tools/collect_profiles.sh: per bench.py stage, the per-launch averages of the stage's kernels summed.
+
+usage: make_traffic.py <fetch.db> <write.db> <out.json> [<sq.db>]
+"""
+import json
+import re
+import sqlite3
+import sys
+
+# bench.py stage -> substrings of the kernel names launched inside that stage timer (gcr_api.hip)
+STAGES = {
+    "preprocess": ("k_preprocess_cull", "k_preprocess_project"),
+    "scan": ("k_tile_table<false>", "k_tile_table<0>", "k_tile_tableILb0", "k_table_colscan"),
+    "emit": ("k_tile_table<true>", "k_tile_table<1>", "k_tile_tableILb1"),
+    "sort": ("k_tile_sort",),
+    "blend_fwd": ("k_blend_fwd",),
+}
+
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+    kcol = "kernel_name" if "kernel_name" in cols else "name"
+    rows = c.execute("select %s, avg(value), count(*) from counters_collection where counter_name=? group by %s"
+                     % (kcol, kcol), (counter,)).fetchall()
+    return {k: (v, n) for k, v, n in rows}
+
+
+def main(fetch_db, write_db, out, sq_db=None):
+    f = per_kernel(fetch_db, "FETCH_SIZE")
+    w = per_kernel(write_db, "WRITE_SIZE")
+    valu = per_kernel(sq_db, "SQ_INSTS_VALU") if sq_db else {}
+    kernels = {}
+    for stage, pats in STAGES.items():
+        fs = sum(v for k, (v, _) in f.items() if any(p in k for p in pats))
+        ws = sum(v for k, (v, _) in w.items() if any(p in k for p in pats))
+        names = sorted(set(re.search(r"k_\w+(<\w+>)?", k).group(0) for k in f if any(p in k for p in pats)))
+        kernels[stage] = {"FETCH_SIZE_KB": round(fs, 1), "WRITE_SIZE_KB": round(ws, 1), "kernels": names}
+        if valu:
+            kernels[stage]["SQ_INSTS_VALU"] = round(sum(v for k, (v, _) in valu.items() if any(p in k for p in pats)))
+    doc = {
+        "workload": "C3 (5M S-city, 1920x1080, SH3, forward)",
+        "unit": "KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE per-dispatch averages, summed over the stage's kernels)",
+        "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: MI355X_MICROARCH.md says FETCH_SIZE reports half the "
+                "bytes of 16-B/lane reads on gfx950; raw values kept here",
+        "kernels": kernels,
+    }
+    json.dump(doc, open(out, "w"), indent=1)
+    print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])
