@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--fast-exp", action="store_true", help="non-parity v_exp_f32 variant (A/B only)")
     ap.add_argument("--train-step", action="store_true",
                     help="C4 training-step harness (fwd + loss + bwd + gradient all-reduce) instead of the frame loop")
+    ap.add_argument("--host-threads", type=int, default=1,
+                    help="host threads driving the frame loop, one stream each (frames are independent)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the frame loop alternates over (frames are independent; 1 = serial)")
     args = ap.parse_args()
@@ -150,12 +152,32 @@ def main():
     # Frames are independent units, so consecutive frames go to alternating HIP streams: frame
     # f+1's preprocess/binning (latency-bound, low occupancy) overlaps frame f's blend.  Every
     # step is still one complete forward; each call still blocks the host until it knows R.
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams, args.host_threads))]
 
     def run_frames(lo, hi):
-        for i in range(lo, hi):
-            with torch.cuda.stream(streams[i % len(streams)]):
-                fwd(poses[i])
+        if args.host_threads <= 1:
+            for i in range(lo, hi):
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    fwd(poses[i])
+            return
+        # One host thread per stream.  The reference API returns num_rendered as a Python int, so every
+        # call blocks its caller until the frame's scan has run; with a single host thread that wait
+        # (plus the enqueue) is the frame period.  The library is re-entrant (per-thread read-back
+        # slot, no global state) and ctypes drops the GIL during the call, so thread t renders frames
+        # lo+t, lo+t+n, ... on its own stream while the others are blocked in their waits.
+        import threading
+
+        def worker(t):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[t % len(streams)]):
+                for i in range(lo + t, hi, args.host_threads):
+                    fwd(poses[i])
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(args.host_threads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
 
     # ---- warm-up, then the timed region: K frames, barrier + synchronize on both sides ------
     run_frames(0, args.warmup)
