@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
 template <bool FAST_EXP>
 __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[CHUNK];
-  __shared__ uint16_t sIdx[4][CHUNK];  // per-wave compacted slots
+  __shared__ uint2 sList[4][CHUNK + 2];   // per-wave compacted slots: {byte offset into sE, list entry}
+  __shared__ uint16_t sAcc4[4][CHUNK + 2];  // ... and byte offset of the slot's column in sAcc
   __shared__ float sAcc[9][CHUNK];
   __shared__ uint32_t sMax[4];
 
@@ -258,6 +259,9 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
   if (total == 0) return;
 
   float T = T_final;
+  const float neg_T_final = -T_final;
+  const char* const sEb = reinterpret_cast<const char*>(sE);
+  char* const acc_base = reinterpret_cast<char*>(&sAcc[acc_slot >= 0 ? acc_slot : 0][0]);
   float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;  // accum_rec
   float last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;
 
@@ -287,66 +291,111 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int jj = k * 64 + lane;
-      const uint32_t entry_l = (uint32_t)(total - 1 - (base + jj));
+      const uint32_t entry_l = (uint32_t)(total - 1 - (base + jj));  // == `contributor` upstream
       const bool rel = jj < n && ((sE[jj].mask >> w) & 1u) && entry_l < wave_max;
       const uint64_t m = __ballot(rel);
-      if (rel) sIdx[w][cnt + __popcll(m & lt_mask)] = (uint16_t)jj;
+      if (rel) {
+        const int slot = cnt + __popcll(m & lt_mask);
+        sList[w][slot] = make_uint2((uint32_t)(jj * (int)sizeof(StagedEntry)), entry_l);
+        sAcc4[w][slot] = (uint16_t)(jj * 4);
+      }
       cnt += __popcll(m);
     }
-    __builtin_amdgcn_wave_barrier();
-    for (int i = 0; i < cnt; i++) {
-      const int j = sIdx[w][i];
-      const uint32_t entry = (uint32_t)(total - 1 - (base + j));  // == `contributor` upstream
-      const float4 qa = sE[j].a;
-      const float2 qc = sE[j].c;
-      const float4 qb = sE[j].b;
-      const float dx = qa.x - pixx, dy = qa.y - pixy;
-      const float power = gcr_power(qa.z, qa.w, qb.x, dx, dy);
-      const bool in_range = entry < last_contributor && !(power > 0.0f) && !(power < qc.y);
-      if (__ballot(in_range) == 0ull) continue;  // whole wave skips this Gaussian
-      // Branch-free body: lanes that upstream would `continue` keep their state via selects
-      // and contribute exact zeros to the wave reduction (see K6: scalar-unit pressure).
-      const float G = blend_exp<FAST_EXP>(power);
-      const float alpha = __builtin_fminf(0.99f, qb.y * G);
-      const bool use = in_range && !(alpha < 1.0f / 255.0f);
-      const float Tn = T / (1.f - alpha);
-      const float dchannel_dcolor = alpha * Tn;
-      const float a0 = __builtin_fmaf(last_alpha, lc0, (1.f - last_alpha) * acc0);
-      const float a1 = __builtin_fmaf(last_alpha, lc1, (1.f - last_alpha) * acc1);
-      const float a2 = __builtin_fmaf(last_alpha, lc2, (1.f - last_alpha) * acc2);
-      float dL_dalpha = 0.0f;
-      dL_dalpha = __builtin_fmaf(qb.z - a0, dLp0, dL_dalpha);
-      dL_dalpha = __builtin_fmaf(qb.w - a1, dLp1, dL_dalpha);
-      dL_dalpha = __builtin_fmaf(qc.x - a2, dLp2, dL_dalpha);
-      dL_dalpha *= Tn;
-      dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-      const float dL_dG = qb.y * dL_dalpha;
-      const float gdx = G * dx, gdy = G * dy;
-      const float dG_ddelx = -gdx * qa.z - gdy * qa.w;
-      const float dG_ddely = -gdy * qb.x - gdx * qa.w;
-      float v[9];
-      v[0] = use ? dchannel_dcolor * dLp0 : 0.0f;
-      v[1] = use ? dchannel_dcolor * dLp1 : 0.0f;
-      v[2] = use ? dchannel_dcolor * dLp2 : 0.0f;
-      v[3] = use ? dL_dG * dG_ddelx * ddelx_dx : 0.0f;
-      v[4] = use ? dL_dG * dG_ddely * ddely_dy : 0.0f;
-      v[5] = use ? -0.5f * gdx * dx * dL_dG : 0.0f;
-      v[6] = use ? -0.5f * gdx * dy * dL_dG : 0.0f;
-      v[7] = use ? -0.5f * gdy * dy * dL_dG : 0.0f;
-      v[8] = use ? G * dL_dalpha : 0.0f;
-      T = use ? Tn : T;
-      acc0 = use ? a0 : acc0;
-      acc1 = use ? a1 : acc1;
-      acc2 = use ? a2 : acc2;
-      lc0 = use ? qb.z : lc0;
-      lc1 = use ? qb.w : lc1;
-      lc2 = use ? qc.x : lc2;
-      last_alpha = use ? alpha : last_alpha;
-      // reduce-scatter over each 16-lane row, then ONE ds_add_f32: lanes 0..8 of the four rows
-      // add their row's sum of term (lane & 15) into the chunk accumulator
-      const float rsum = gcr_row_reduce_scatter9(v, lane);
-      if (acc_slot >= 0) atomicAdd(&sAcc[acc_slot][j], rsum);
+    // two pad slots so the pipeline below may read past the end (the values are never consumed)
+    if (lane < 2) {
+      sList[w][cnt + lane] = make_uint2(0u, 0u);
+      sAcc4[w][cnt + lane] = 0;
     }
+    __builtin_amdgcn_wave_barrier();
+
+// One list entry against this lane's pixel (cr/backward.cu:505-580).  Branch-free body: lanes
+// that upstream would `continue` keep their state via selects and contribute exact zeros to the
+// wave reduction (see K6: scalar-unit pressure).  `power` is forced to 0 on those lanes so that
+// every intermediate stays finite and the three masked factors (dchannel_dcolor, dL_dalpha) zero
+// all nine terms.  The two quotients share the divisor 1-alpha: one v_rcp_f32 + one Newton step
+// (<= 1 ulp) instead of two IEEE division expansions -- the only place the HIP path leaves
+// gcr-fp32-v1; K7's sums are order-dependent (atomics) and tolerance-checked anyway.
+#define GCR_BWD_STEP(QA, QB, QC, ENTRY, ACC4)                                                  \
+  {                                                                                            \
+    const float dx = QA.x - pixx, dy = QA.y - pixy;                                            \
+    const float power_raw = gcr_power(QA.z, QA.w, QB.x, dx, dy);                               \
+    const bool in_range = (ENTRY) < last_contributor && !(power_raw > 0.0f) && !(power_raw < QC.y); \
+    if (__ballot(in_range) != 0ull) { /* else the whole wave skips this Gaussian */            \
+      const float power = in_range ? power_raw : 0.0f;                                         \
+      const float G = blend_exp<FAST_EXP>(power);                                              \
+      const float alpha = __builtin_fminf(0.99f, QB.y * G);                                    \
+      const bool use = in_range && !(alpha < 1.0f / 255.0f);                                   \
+      const float om = 1.f - alpha;                                                            \
+      const float r0 = __builtin_amdgcn_rcpf(om);                                              \
+      const float rcp = __builtin_fmaf(r0, __builtin_fmaf(-om, r0, 1.0f), r0);                 \
+      const float Tn = T * rcp;                                                                \
+      const float dchannel_dcolor = use ? alpha * Tn : 0.0f;                                   \
+      const float a0 = __builtin_fmaf(last_alpha, lc0, (1.f - last_alpha) * acc0);            \
+      const float a1 = __builtin_fmaf(last_alpha, lc1, (1.f - last_alpha) * acc1);            \
+      const float a2 = __builtin_fmaf(last_alpha, lc2, (1.f - last_alpha) * acc2);            \
+      float dL_dalpha = 0.0f;                                                                  \
+      dL_dalpha = __builtin_fmaf(QB.z - a0, dLp0, dL_dalpha);                                  \
+      dL_dalpha = __builtin_fmaf(QB.w - a1, dLp1, dL_dalpha);                                  \
+      dL_dalpha = __builtin_fmaf(QC.x - a2, dLp2, dL_dalpha);                                  \
+      dL_dalpha *= Tn;                                                                         \
+      dL_dalpha += (neg_T_final * rcp) * bg_dot_dpixel;                                        \
+      dL_dalpha = use ? dL_dalpha : 0.0f;                                                      \
+      const float dL_dG = QB.y * dL_dalpha;                                                    \
+      const float gdx = G * dx, gdy = G * dy;                                                  \
+      const float dG_ddelx = -gdx * QA.z - gdy * QA.w;                                         \
+      const float dG_ddely = -gdy * QB.x - gdx * QA.w;                                         \
+      float v[9];                                                                              \
+      v[0] = dchannel_dcolor * dLp0;                                                           \
+      v[1] = dchannel_dcolor * dLp1;                                                           \
+      v[2] = dchannel_dcolor * dLp2;                                                           \
+      v[3] = dL_dG * dG_ddelx * ddelx_dx;                                                      \
+      v[4] = dL_dG * dG_ddely * ddely_dy;                                                      \
+      v[5] = -0.5f * gdx * dx * dL_dG;                                                         \
+      v[6] = -0.5f * gdx * dy * dL_dG;                                                         \
+      v[7] = -0.5f * gdy * dy * dL_dG;                                                         \
+      v[8] = G * dL_dalpha;                                                                    \
+      T = use ? Tn : T;                                                                        \
+      acc0 = use ? a0 : acc0;                                                                  \
+      acc1 = use ? a1 : acc1;                                                                  \
+      acc2 = use ? a2 : acc2;                                                                  \
+      lc0 = use ? QB.z : lc0;                                                                  \
+      lc1 = use ? QB.w : lc1;                                                                  \
+      lc2 = use ? QC.x : lc2;                                                                  \
+      last_alpha = use ? alpha : last_alpha;                                                   \
+      /* reduce-scatter over each 16-lane row, then ONE ds_add_f32: lanes 0..8 of the four */  \
+      /* rows add their row's sum of term (lane & 15) into the chunk accumulator */            \
+      const float rsum = gcr_row_reduce_scatter9(v, lane);                                     \
+      if (acc_slot >= 0) atomicAdd(reinterpret_cast<float*>(acc_base + (ACC4)), rsum);         \
+    }                                                                                          \
+  }
+#define GCR_BWD_LOAD(QA, QB, QC, OFF)                              \
+  QA = *reinterpret_cast<const float4*>(sEb + (OFF));             \
+  QB = *reinterpret_cast<const float4*>(sEb + (OFF) + 16);         \
+  QC = *reinterpret_cast<const float2*>(sEb + (OFF) + 32);
+
+    // software pipeline, two entries per trip (see K6)
+    const uint2* lp = &sList[w][0];
+    const uint16_t* ap = &sAcc4[w][0];
+    float4 qa0, qb0, qa1, qb1;
+    float2 qc0, qc1;
+    uint2 e0 = lp[0], e1 = lp[1];
+    uint32_t c0 = ap[0], c1 = ap[1];
+    GCR_BWD_LOAD(qa0, qb0, qc0, e0.x)
+    for (int i = 0; i < cnt; i += 2, lp += 2, ap += 2) {
+      GCR_BWD_LOAD(qa1, qb1, qc1, e1.x)
+      const uint32_t en0 = e0.y, ac0 = c0;
+      e0 = lp[2];
+      c0 = ap[2];
+      GCR_BWD_STEP(qa0, qb0, qc0, en0, ac0)
+      if (i + 1 >= cnt) break;
+      GCR_BWD_LOAD(qa0, qb0, qc0, e0.x)
+      const uint32_t en1 = e1.y, ac1 = c1;
+      e1 = lp[3];
+      c1 = ap[3];
+      GCR_BWD_STEP(qa1, qb1, qc1, en1, ac1)
+    }
+#undef GCR_BWD_STEP
+#undef GCR_BWD_LOAD
     __syncthreads();
     if (tid < n) {
       const uint32_t id = sE[tid].id;
