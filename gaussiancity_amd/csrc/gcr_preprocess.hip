@@ -261,6 +261,11 @@ GCR_DEV bool phase_a1_exact(const GcrPreprocessArgs& a, const float (&vm)[16], c
   const int maxx = (int)__builtin_fminf(__builtin_fmaxf((px + rf + 16.0f - 1.0f) / 16.0f, 0.0f), gxf);
   const int maxy = (int)__builtin_fminf(__builtin_fmaxf((py + rf + 16.0f - 1.0f) / 16.0f, 0.0f), gyf);
   if ((uint32_t)(maxx - minx) * (uint32_t)(maxy - miny) == 0) return false;
+  // Deliberate deviation shared with the oracle: a radius that converts to an int <= 0 (NaN scale /
+  // covariance, or lambda <= 0 for an indefinite supplied covariance) is not rendered.  Upstream
+  // counts such a Gaussian in num_rendered but never emits its keys (radii == 0), so its sort reads
+  // uninitialised slots (cr/forward.cu:228-232 vs cr/rasterizer_impl.cu:78).
+  if (ri <= 0) return false;
   radius_out = ri;
   out.px = px; out.py = py; out.conx = conx; out.cony = cony; out.conz = conz; out.depth = p_view.z;
   out.rect_x = (uint32_t)minx | ((uint32_t)maxx << 16);
