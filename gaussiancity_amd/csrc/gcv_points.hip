@@ -1,0 +1,595 @@
+// gcv_points.hip -- MI355X (gfx950) kernels + C ABI (include/gcv.h) of the point-generation /
+// visibility path: footprint extruder (K15), points -> volume (K14), ray/voxel traversal (K12).
+// Reference behaviour: extensions/footprint_extruder/footprint_extruder.cpp ("fe/"),
+// extensions/voxlib/{points_to_volume,ray_voxel_intersection}.cu, voxlib_common.h ("vox/").
+//
+// Everything here is integer / index work except K12's ray setup and crossing times, which follow
+// the reference's fp32 expression order with IEEE division and sqrt (the library is built with
+// -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt), so all outputs are bit-comparable
+// with oracle/gcv_oracle.c.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/gcv.h"
+
+namespace {
+
+thread_local std::string g_err;
+std::atomic<int> g_timing{0};
+
+int fail(int code, const char* msg) {
+  g_err = msg;
+  return code;
+}
+int fail_hip(hipError_t e, const char* where) {
+  g_err = std::string(where) + ": " + hipGetErrorString(e);
+  return GCV_ERR_HIP;
+}
+#define HIP_TRY(expr, where)                          \
+  do {                                                \
+    hipError_t e_ = (expr);                           \
+    if (e_ != hipSuccess) return fail_hip(e_, where); \
+  } while (0)
+
+// ---- stage timers (non-blocking; resolved lazily) ---------------------------------------------
+enum Stage { ST_COUNT = 0, ST_EMIT, ST_CLEAR, ST_SCATTER, ST_OCC, ST_TRAVERSE, ST_N };
+struct StageSlot {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool pending = false;
+  double ms = 0.0;
+  int n = 0;
+};
+StageSlot g_slots[ST_N];
+void stage_resolve(StageSlot& s) {
+  if (!s.pending) return;
+  if (hipEventSynchronize(s.b) == hipSuccess) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      s.ms += ms;
+      s.n++;
+    }
+  }
+  s.pending = false;
+}
+struct StageTimer {
+  hipStream_t s;
+  StageSlot* sl = nullptr;
+  StageTimer(hipStream_t s_, int stage) : s(s_) {
+    if (g_timing.load() == 0) return;
+    sl = &g_slots[stage];
+    if (!sl->a) {
+      (void)hipEventCreate(&sl->a);
+      (void)hipEventCreate(&sl->b);
+    }
+    stage_resolve(*sl);
+    (void)hipEventRecord(sl->a, s);
+  }
+  ~StageTimer() {
+    if (!sl) return;
+    (void)hipEventRecord(sl->b, s);
+    sl->pending = true;
+  }
+};
+
+// =============================================================================================== K15
+// fe/:143-213 is a serial triple loop on the host.  Here:
+//   * whether a column is a border column does not depend on z (fe/:128-141: only the first test
+//     does), so the number of points a pixel emits is closed-form: every k for a border column,
+//     else the top k (z > td - scale) plus the bottom k (z == bu) when bottom points are included;
+//   * count pass (one thread per pixel, block sums) -> one-block scan of the block sums -> emit pass
+//     that recomputes the count, scans inside the block and writes the pixel's points at its global
+//     offset: upstream's output order (row-major pixels, z ascending) without any sort.
+constexpr int EX_BLOCK = 256;
+
+struct ExtrudeArgs {
+  int inc_btm, H, W;
+  const int16_t* lut;
+  gcv_seg_ins m;
+  const int16_t *seg, *td, *bu;
+  const uint8_t* pts;
+};
+
+__device__ __forceinline__ int ex_semantic(int ins, const gcv_seg_ins& m) {  // fe/:90-100
+  if (ins < m.bldg_ins_min_id) return ins;
+  if (ins >= m.car_ins_min_id) return m.car_semantic_id;
+  return m.bldg_facade_semantic_id;
+}
+
+__device__ __forceinline__ bool ex_nbr_same(const int16_t* __restrict__ map, int x, int y, int W, int s) {  // fe/:102-126
+  const int16_t c = map[(size_t)y * W + x];
+  const int16_t* up = map + (size_t)(y - s) * W + x;
+  const int16_t* mid = map + (size_t)y * W + x;
+  const int16_t* dn = map + (size_t)(y + s) * W + x;
+  return c == up[-s] && c == up[0] && c == up[s] && c == mid[-s] && c == mid[s] && c == dn[-s] && c == dn[0] &&
+         c == dn[s];
+}
+
+// What pixel (i, j) emits: nk = number of k values in [bu, td] step scale; full = border column.
+struct ExPixel {
+  int count, nk, scale, sem, ins, bu;
+  bool full;
+};
+
+__device__ __forceinline__ ExPixel ex_pixel(const ExtrudeArgs& a, int i, int j, unsigned long long* err) {
+  ExPixel p;
+  p.count = 0; p.nk = 0; p.scale = 1; p.sem = 0; p.ins = 0; p.bu = 0; p.full = false;
+  const size_t idx = (size_t)i * a.W + j;
+  if (!a.pts[idx]) return p;
+  p.ins = a.seg[idx];
+  p.sem = ex_semantic(p.ins, a.m);
+  const int scale = p.sem >= 0 ? a.lut[p.sem] : 0;
+  if (scale <= 0) {  // upstream: scale 0 from std::map::operator[] and an endless loop (fe/:186-189)
+    if (err != nullptr) atomicMin(err, (unsigned long long)idx);
+    return p;
+  }
+  p.scale = scale;
+  const int td = a.td[idx], bu = a.bu[idx];
+  p.bu = bu;
+  if (bu > td) return p;
+  p.nk = (td - bu) / scale + 1;
+  p.full = j < scale || j >= a.W - scale - 1 || i < scale || i >= a.H - scale - 1 ||  // fe/:135-137
+           !ex_nbr_same(a.seg, j, i, a.W, scale) || !ex_nbr_same(a.td, j, i, a.W, scale);
+  p.count = p.full ? p.nk : (p.nk == 1 ? 1 : 1 + (a.inc_btm ? 1 : 0));
+  return p;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+// exclusive scan over a 256-thread block; *total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds4, uint32_t* total) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t incl = wave_incl_scan(v, lane);
+  if (lane == 63) lds4[w] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < EX_BLOCK / 64; k++) {
+    const uint32_t s = lds4[k];
+    if (k < w) base += s;
+    tot += s;
+  }
+  *total = tot;
+  __syncthreads();
+  return base + incl - v;
+}
+
+// scratch layout: [0] u64 total, [1] u64 first bad pixel (~0 = none), then u64 block offsets
+__global__ __launch_bounds__(EX_BLOCK) void k_extrude_count(const ExtrudeArgs a, unsigned long long* scratch) {
+  __shared__ uint32_t lds4[4];
+  const long long pix = (long long)blockIdx.x * EX_BLOCK + threadIdx.x;
+  uint32_t c = 0;
+  if (pix < (long long)a.H * a.W) c = (uint32_t)ex_pixel(a, (int)(pix / a.W), (int)(pix % a.W), scratch + 1).count;
+  uint32_t total;
+  block_excl_scan(c, lds4, &total);
+  if (threadIdx.x == 0) scratch[2 + blockIdx.x] = total;
+}
+
+// in-place exclusive scan of the n block sums (one 1024-thread block; n = H*W/256 is small)
+__global__ __launch_bounds__(1024) void k_extrude_scan(unsigned long long* scratch, int n) {
+  __shared__ unsigned long long part[1024];
+  unsigned long long* sums = scratch + 2;
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int beg = min(n, tid * per), end = min(n, beg + per);
+  unsigned long long s = 0;
+  for (int i = beg; i < end; i++) s += sums[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned long long t = tid >= o ? part[tid - o] : 0ull;
+    __syncthreads();
+    part[tid] += t;
+    __syncthreads();
+  }
+  unsigned long long run = part[tid] - s;
+  for (int i = beg; i < end; i++) {
+    const unsigned long long t = sums[i];
+    sums[i] = run;
+    run += t;
+  }
+  if (tid == 1023) scratch[0] = part[1023];
+}
+
+__global__ __launch_bounds__(EX_BLOCK) void k_extrude_emit(const ExtrudeArgs a, const unsigned long long* scratch,
+                                                           int16_t* __restrict__ out, long long n_points) {
+  __shared__ uint32_t lds4[4];
+  const long long pix = (long long)blockIdx.x * EX_BLOCK + threadIdx.x;
+  ExPixel p;
+  p.count = 0;
+  int i = 0, j = 0;
+  if (pix < (long long)a.H * a.W) {
+    i = (int)(pix / a.W);
+    j = (int)(pix % a.W);
+    p = ex_pixel(a, i, j, nullptr);
+  }
+  uint32_t total;
+  const uint32_t local = block_excl_scan((uint32_t)p.count, lds4, &total);
+  if (p.count == 0) return;
+  long long o = (long long)scratch[2 + blockIdx.x] + local;
+  if (o + p.count > n_points) return;  // caller passed a stale count; never write out of bounds
+  const bool roof = p.sem == a.m.bldg_facade_semantic_id;
+  const int16_t roof_ins = (int16_t)(p.ins + a.m.roof_ins_offset);  // fe/:199-203
+  int16_t* w = out + 5 * o;
+  if (p.full) {
+    for (int m = 0; m < p.nk; m++, w += 5) {
+      const bool top = m == p.nk - 1;
+      w[0] = (int16_t)j; w[1] = (int16_t)i; w[2] = (int16_t)(p.bu + m * p.scale); w[3] = (int16_t)p.scale;
+      w[4] = top && roof ? roof_ins : (int16_t)p.ins;
+    }
+  } else {
+    if (p.count == 2) {  // bottom point
+      w[0] = (int16_t)j; w[1] = (int16_t)i; w[2] = (int16_t)p.bu; w[3] = (int16_t)p.scale; w[4] = (int16_t)p.ins;
+      w += 5;
+    }
+    w[0] = (int16_t)j; w[1] = (int16_t)i; w[2] = (int16_t)(p.bu + (p.nk - 1) * p.scale); w[3] = (int16_t)p.scale;
+    w[4] = roof ? roof_ins : (int16_t)p.ins;
+  }
+}
+
+// =============================================================================================== K14
+// vox/points_to_volume.cu:21-50.  One thread per point; atomicMax makes the overlap rule
+// deterministic (highest id wins = sequential order).  Bricks touched are flagged in the occupancy
+// bitmask (1 bit per 8x8x8 voxels) for the traversal.
+__device__ __forceinline__ void occ_set(uint32_t* occ, int kb, int jb, int lb, int wb, int db) {
+  const long long lin = ((long long)kb * wb + jb) * db + lb;
+  atomicOr(&occ[lin >> 5], 1u << (lin & 31));
+}
+
+__global__ __launch_bounds__(256) void k_points_to_volume(long long n, int h, int w, int d,
+                                                          const int16_t* __restrict__ points,
+                                                          const int32_t* __restrict__ pt_ids,
+                                                          const int16_t* __restrict__ scales,
+                                                          int32_t* __restrict__ volume, uint32_t* __restrict__ occ) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int pid = pt_ids[idx];
+  const int x = points[3 * idx], y = points[3 * idx + 1], z = points[3 * idx + 2];
+  const int sx = scales[3 * idx], sy = scales[3 * idx + 1], sz = scales[3 * idx + 2];
+  if (x >= w || y >= h || z >= d || x < 0 || y < 0 || z < 0) return;
+  const int xe = min(x + sx, w), ye = min(y + sy, h), ze = min(z + sz, d);
+  for (int j = x; j < xe; ++j)
+    for (int k = y; k < ye; ++k)
+      for (int l = z; l < ze; ++l) atomicMax(&volume[((long long)k * w + j) * d + l], pid);
+  if (occ != nullptr && xe > x && ye > y && ze > z) {
+    const int wb = (w + 7) >> 3, db = (d + 7) >> 3;
+    for (int kb = y >> 3; kb <= (ye - 1) >> 3; kb++)
+      for (int jb = x >> 3; jb <= (xe - 1) >> 3; jb++)
+        for (int lb = z >> 3; lb <= (ze - 1) >> 3; lb++) occ_set(occ, kb, jb, lb, wb, db);
+  }
+}
+
+// occupancy of an arbitrary dense volume: thread per (k, j, lb) ORs 8 contiguous voxels
+__global__ __launch_bounds__(256) void k_build_occ(const int32_t* __restrict__ volume, int h, int w, int d,
+                                                   uint32_t* __restrict__ occ) {
+  const int db = (d + 7) >> 3, wb = (w + 7) >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)h * w * db) return;
+  const int lb = (int)(t % db);
+  const long long kj = t / db;
+  const int j = (int)(kj % w), k = (int)(kj / w);
+  const int32_t* p = volume + ((long long)k * w + j) * d + 8 * lb;
+  const int nz = min(8, d - 8 * lb);
+  int32_t any = 0;
+  for (int l = 0; l < nz; l++) any |= p[l];
+  if (any != 0) occ_set(occ, k >> 3, j >> 3, lb, wb, db);
+}
+
+// =============================================================================================== K12
+// vox/ray_voxel_intersection.cu:54-216.  One wave = one 8x8 pixel tile (upstream's block shape, which
+// is exactly a wave64).  The crossing times are recomputed from the integer cell every step
+// (upstream's expression), so the walk is a pure function of the cell sequence and can be reproduced
+// bit for bit.  MI355X change: with the brick bitmask the volume is only read inside occupied bricks;
+// the bit is re-read only when the step crosses a brick face (cell & 7 wraps), so in empty space a
+// step is ALU only.
+struct RvipArgs {
+  int dims[3];
+  long long strides[3];
+  int max_samples;
+  int img[2];
+  float ori[3], fwd[3], side[3], up[3];
+  float c[2], f;
+  int wb, db;  // bricks along w and d (occupancy)
+};
+
+__device__ __forceinline__ void dev_normalize3(float* a) {  // vox/voxlib_common.h:56-68
+  float len = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 3; i++) len += a[i] * a[i];
+  len = __builtin_sqrtf(len);
+#pragma unroll
+  for (int i = 0; i < 3; i++) a[i] /= len;
+}
+
+#define GCV_STEP(AX)                                                        \
+  {                                                                         \
+    tnow = axis_t[AX];                                                      \
+    if (raydir[AX] > 0) {                                                   \
+      axis_int[AX] += 1;                                                    \
+      if (axis_int[AX] >= p.dims[AX]) quit = true;                          \
+      axis_t[AX] = ((float)(axis_int[AX] + 1) - p.ori[AX]) / raydir[AX];    \
+      crossed = (axis_int[AX] & 7) == 0;                                    \
+    } else {                                                                \
+      axis_int[AX] -= 1;                                                    \
+      if (axis_int[AX] < 0) quit = true;                                    \
+      axis_t[AX] = ((float)axis_int[AX] - p.ori[AX]) / raydir[AX];          \
+      crossed = (axis_int[AX] & 7) == 7;                                    \
+    }                                                                       \
+  }
+
+template <bool HAS_OCC>
+__global__ __launch_bounds__(64) void k_rvip(int32_t* __restrict__ out_voxel_id, float* __restrict__ out_depth,
+                                             float* __restrict__ out_raydirs, const int32_t* __restrict__ in_voxel,
+                                             const uint32_t* __restrict__ occ, const RvipArgs p) {
+  const int col = blockIdx.x * 8 + (threadIdx.x & 7);
+  const int row = blockIdx.y * 8 + (threadIdx.x >> 3);
+  if (row >= p.img[0] || col >= p.img[1]) return;
+  const long long pix = (long long)row * p.img[1] + col;
+  const long long npix = (long long)p.img[0] * p.img[1];
+
+  float raydir[3];
+  const float n0 = p.c[0] - (float)row;  // flip height
+  const float n1 = (float)col - p.c[1];
+#pragma unroll
+  for (int i = 0; i < 3; i++) raydir[i] = p.up[i] * n0 + p.side[i] * n1 + p.fwd[i] * p.f;
+  dev_normalize3(raydir);
+  out_raydirs[pix * 3] = raydir[0];
+  out_raydirs[pix * 3 + 1] = raydir[1];
+  out_raydirs[pix * 3 + 2] = raydir[2];
+
+  float axis_t[3];
+  int axis_int[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) axis_int[i] = (int)__builtin_floorf(p.ori[i]);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    if (raydir[i] > 0)
+      axis_t[i] = ((float)(axis_int[i] + 1) - p.ori[i]) / raydir[i];
+    else if (raydir[i] < 0)
+      axis_t[i] = ((float)axis_int[i] - p.ori[i]) / raydir[i];
+    else
+      axis_t[i] = HUGE_VALF;
+  }
+  const float qnan = __int_as_float(0x7fc00000);
+  bool quit = false;
+  bool occ_valid = false, occ_bit = true;
+  for (int plane = 0; plane < p.max_samples; plane++) {
+    float t = qnan, t2 = qnan;
+    int32_t blk_id = 0;
+    while (!quit) {
+      float tnow;
+      bool crossed;
+      if (axis_t[0] <= axis_t[1] && axis_t[0] <= axis_t[2])
+        GCV_STEP(0)
+      else if (axis_t[1] <= axis_t[2])
+        GCV_STEP(1)
+      else
+        GCV_STEP(2)
+      if (quit) break;
+      if (axis_int[0] < 0 || axis_int[0] >= p.dims[0] || axis_int[1] < 0 || axis_int[1] >= p.dims[1] ||
+          axis_int[2] < 0 || axis_int[2] >= p.dims[2]) {
+        occ_valid = false;
+        continue;  // still outside the grid
+      }
+      if (HAS_OCC) {
+        if (!occ_valid || crossed) {
+          const long long lin = ((long long)(axis_int[0] >> 3) * p.wb + (axis_int[1] >> 3)) * p.db + (axis_int[2] >> 3);
+          occ_bit = (occ[lin >> 5] >> (lin & 31)) & 1u;
+          occ_valid = true;
+        }
+        if (!occ_bit) continue;  // empty brick: the voxel is 0 without reading it
+      }
+      blk_id = in_voxel[(long long)axis_int[0] * p.strides[0] + (long long)axis_int[1] * p.strides[1] +
+                        (long long)axis_int[2] * p.strides[2]];
+      if (blk_id == 0) continue;
+      t = tnow;
+      if (axis_t[0] <= axis_t[1] && axis_t[0] <= axis_t[2])
+        t2 = axis_t[0];
+      else if (axis_t[1] <= axis_t[2])
+        t2 = axis_t[1];
+      else
+        t2 = axis_t[2];
+      break;
+    }
+    out_depth[pix * p.max_samples + plane] = t;
+    out_depth[npix * p.max_samples + pix * p.max_samples + plane] = t2;
+    out_voxel_id[pix * p.max_samples + plane] = blk_id;
+  }
+}
+
+// host half of vox/ray_voxel_intersection.cu:256-266 (same float operations, -ffp-contract=off)
+void host_normalize3(float* a) {
+  float len = 0.0f;
+  for (int i = 0; i < 3; i++) len += a[i] * a[i];
+  len = sqrtf(len);
+  for (int i = 0; i < 3; i++) a[i] /= len;
+}
+void host_cross3(float* r, const float* a, const float* b) {
+  r[0] = a[1] * b[2] - a[2] * b[1];
+  r[1] = a[2] * b[0] - a[0] * b[2];
+  r[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+int make_extrude_args(int inc_btm, const int16_t* lut, const gcv_seg_ins* m, int H, int W, const int16_t* seg,
+                      const int16_t* td, const int16_t* bu, const uint8_t* pts, size_t scratch_bytes, ExtrudeArgs* a) {
+  if (!lut || !m || !seg || !td || !bu || !pts) return fail(GCV_ERR_INVALID_ARGUMENT, "null map / table pointer");
+  if (H <= 0 || W <= 0 || H > 32767 || W > 32767)
+    return fail(GCV_ERR_INVALID_ARGUMENT, "map size must be in [1, 32767] (coordinates are int16, fe/:163-166)");
+  if (scratch_bytes < gcv_extrude_scratch_bytes(H, W)) return fail(GCV_ERR_BUFFER_TOO_SMALL, "extrude scratch too small");
+  a->inc_btm = inc_btm ? 1 : 0;
+  a->H = H; a->W = W; a->lut = lut; a->m = *m; a->seg = seg; a->td = td; a->bu = bu; a->pts = pts;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gcv_abi_version(void) { return GCV_ABI_VERSION; }
+const char* gcv_last_error(void) { return g_err.c_str(); }
+
+int gcv_set_option(const char* name, int value) {
+  if (!name) return -1;
+  if (!strcmp(name, "timing")) return g_timing.exchange(value);
+  return -1;
+}
+
+int gcv_get_stage_ms(float* out, int n) {
+  if (!out) return 0;
+  int k = 0;
+  for (; k < n && k < ST_N; k++) {
+    stage_resolve(g_slots[k]);
+    out[k] = g_slots[k].n ? (float)(g_slots[k].ms / g_slots[k].n) : 0.0f;
+    g_slots[k].ms = 0.0;
+    g_slots[k].n = 0;
+  }
+  return k;
+}
+
+size_t gcv_extrude_scratch_bytes(int32_t height, int32_t width) {
+  const size_t npix = (size_t)(height > 0 ? height : 0) * (size_t)(width > 0 ? width : 0);
+  return sizeof(unsigned long long) * (2 + (npix + EX_BLOCK - 1) / EX_BLOCK + 1);
+}
+
+int gcv_extrude_count(int32_t inc_btm, const int16_t* lut, const gcv_seg_ins* m, int32_t H, int32_t W,
+                      const int16_t* seg, const int16_t* td, const int16_t* bu, const uint8_t* pts, void* scratch,
+                      size_t scratch_bytes, int64_t* n_points_host, void* hip_stream) {
+  if (!n_points_host || !scratch) return fail(GCV_ERR_INVALID_ARGUMENT, "null scratch / n_points_host");
+  ExtrudeArgs a;
+  if (int rc = make_extrude_args(inc_btm, lut, m, H, W, seg, td, bu, pts, scratch_bytes, &a)) return rc;
+  hipStream_t s = (hipStream_t)hip_stream;
+  unsigned long long* sc = (unsigned long long*)scratch;
+  const int nblocks = (int)(((size_t)H * W + EX_BLOCK - 1) / EX_BLOCK);
+  const unsigned long long init[2] = {0ull, ~0ull};
+  HIP_TRY(hipMemcpyAsync(sc, init, sizeof(init), hipMemcpyHostToDevice, s), "extrude scratch init");
+  {
+    StageTimer t(s, ST_COUNT);
+    k_extrude_count<<<nblocks, EX_BLOCK, 0, s>>>(a, sc);
+    k_extrude_scan<<<1, 1024, 0, s>>>(sc, nblocks);
+  }
+  HIP_TRY(hipGetLastError(), "extrude count launch");
+  unsigned long long head[2];
+  HIP_TRY(hipMemcpyAsync(head, sc, sizeof(head), hipMemcpyDeviceToHost, s), "extrude count read-back");
+  HIP_TRY(hipStreamSynchronize(s), "extrude count sync");
+  if (head[1] != ~0ull) {
+    char msg[160];
+    snprintf(msg, sizeof(msg), "pixel %llu: semantic id without a positive scale (upstream would not terminate)", head[1]);
+    return fail(GCV_ERR_UNKNOWN_CLASS, msg);
+  }
+  *n_points_host = (int64_t)head[0];
+  return 0;
+}
+
+int gcv_extrude_emit(int32_t inc_btm, const int16_t* lut, const gcv_seg_ins* m, int32_t H, int32_t W,
+                     const int16_t* seg, const int16_t* td, const int16_t* bu, const uint8_t* pts, const void* scratch,
+                     size_t scratch_bytes, int16_t* points_out, int64_t n_points, void* hip_stream) {
+  if (!scratch) return fail(GCV_ERR_INVALID_ARGUMENT, "null scratch");
+  if (n_points < 0) return fail(GCV_ERR_INVALID_ARGUMENT, "n_points < 0");
+  if (n_points == 0) return 0;
+  if (!points_out) return fail(GCV_ERR_INVALID_ARGUMENT, "null points_out");
+  ExtrudeArgs a;
+  if (int rc = make_extrude_args(inc_btm, lut, m, H, W, seg, td, bu, pts, scratch_bytes, &a)) return rc;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int nblocks = (int)(((size_t)H * W + EX_BLOCK - 1) / EX_BLOCK);
+  {
+    StageTimer t(s, ST_EMIT);
+    k_extrude_emit<<<nblocks, EX_BLOCK, 0, s>>>(a, (const unsigned long long*)scratch, points_out, (long long)n_points);
+  }
+  HIP_TRY(hipGetLastError(), "extrude emit launch");
+  return 0;
+}
+
+size_t gcv_occupancy_bytes(int32_t h, int32_t w, int32_t d) {
+  if (h <= 0 || w <= 0 || d <= 0) return 0;
+  const size_t bricks = (size_t)((h + 7) >> 3) * (size_t)((w + 7) >> 3) * (size_t)((d + 7) >> 3);
+  return 4 * ((bricks + 31) / 32);
+}
+
+int gcv_points_to_volume(int64_t n, const int16_t* points, const int32_t* pt_ids, const int16_t* scales, int32_t h,
+                         int32_t w, int32_t d, int32_t* volume, uint32_t* occupancy, void* hip_stream) {
+  if (h <= 0 || w <= 0 || d <= 0) return fail(GCV_ERR_INVALID_ARGUMENT, "volume dimensions must be positive");
+  if (!volume) return fail(GCV_ERR_INVALID_ARGUMENT, "null volume");
+  if (n < 0 || (n > 0 && (!points || !pt_ids || !scales))) return fail(GCV_ERR_INVALID_ARGUMENT, "null point arrays");
+  hipStream_t s = (hipStream_t)hip_stream;
+  {
+    StageTimer t(s, ST_CLEAR);
+    HIP_TRY(hipMemsetAsync(volume, 0, sizeof(int32_t) * (size_t)h * w * d, s), "volume clear");
+    if (occupancy) HIP_TRY(hipMemsetAsync(occupancy, 0, gcv_occupancy_bytes(h, w, d), s), "occupancy clear");
+  }
+  if (n > 0) {
+    StageTimer t(s, ST_SCATTER);
+    k_points_to_volume<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((long long)n, h, w, d, points, pt_ids, scales, volume,
+                                                                  occupancy);
+    HIP_TRY(hipGetLastError(), "points_to_volume launch");
+  }
+  return 0;
+}
+
+int gcv_build_occupancy(const int32_t* volume, int32_t h, int32_t w, int32_t d, uint32_t* occupancy, void* hip_stream) {
+  if (h <= 0 || w <= 0 || d <= 0) return fail(GCV_ERR_INVALID_ARGUMENT, "volume dimensions must be positive");
+  if (!volume || !occupancy) return fail(GCV_ERR_INVALID_ARGUMENT, "null volume / occupancy");
+  hipStream_t s = (hipStream_t)hip_stream;
+  StageTimer t(s, ST_OCC);
+  HIP_TRY(hipMemsetAsync(occupancy, 0, gcv_occupancy_bytes(h, w, d), s), "occupancy clear");
+  const long long threads = (long long)h * w * ((d + 7) >> 3);
+  k_build_occ<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(volume, h, w, d, occupancy);
+  HIP_TRY(hipGetLastError(), "build occupancy launch");
+  return 0;
+}
+
+int gcv_ray_voxel_intersection(const int32_t* volume, const int32_t dims[3], const int64_t strides[3],
+                               const uint32_t* occupancy, const float cam_ori[3], const float cam_dir[3],
+                               const float cam_up[3], float cam_f, const float cam_c[2], const int32_t img_dims[2],
+                               int32_t max_samples, int32_t* out_voxel_id, float* out_depth, float* out_raydirs,
+                               void* hip_stream) {
+  if (!volume || !dims || !strides || !cam_ori || !cam_dir || !cam_up || !cam_c || !img_dims)
+    return fail(GCV_ERR_INVALID_ARGUMENT, "null argument");
+  if (!out_voxel_id || !out_depth || !out_raydirs) return fail(GCV_ERR_INVALID_ARGUMENT, "null output");
+  if (dims[0] <= 0 || dims[1] <= 0 || dims[2] <= 0) return fail(GCV_ERR_INVALID_ARGUMENT, "volume dims must be positive");
+  if (img_dims[0] <= 0 || img_dims[1] <= 0 || max_samples <= 0)
+    return fail(GCV_ERR_INVALID_ARGUMENT, "image dims / max_samples must be positive");
+  if (occupancy && !(strides[2] == 1 && strides[1] == dims[2] && strides[0] == (int64_t)dims[1] * dims[2]))
+    return fail(GCV_ERR_INVALID_ARGUMENT, "occupancy requires a contiguous [h][w][d] volume");
+  RvipArgs p;
+  for (int i = 0; i < 3; i++) {
+    p.dims[i] = dims[i];
+    p.strides[i] = strides[i];
+    p.ori[i] = cam_ori[i];
+    p.fwd[i] = cam_dir[i];
+  }
+  host_normalize3(p.fwd);
+  host_cross3(p.side, p.fwd, cam_up);
+  host_normalize3(p.side);
+  host_cross3(p.up, p.side, p.fwd);
+  host_normalize3(p.up);
+  p.f = cam_f;
+  p.c[0] = cam_c[0]; p.c[1] = cam_c[1];
+  p.max_samples = max_samples;
+  p.img[0] = img_dims[0]; p.img[1] = img_dims[1];
+  p.wb = (dims[1] + 7) >> 3;
+  p.db = (dims[2] + 7) >> 3;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const dim3 grid((img_dims[1] + 7) / 8, (img_dims[0] + 7) / 8, 1);
+  {
+    StageTimer t(s, ST_TRAVERSE);
+    if (occupancy)
+      k_rvip<true><<<grid, 64, 0, s>>>(out_voxel_id, out_depth, out_raydirs, volume, occupancy, p);
+    else
+      k_rvip<false><<<grid, 64, 0, s>>>(out_voxel_id, out_depth, out_raydirs, volume, nullptr, p);
+  }
+  HIP_TRY(hipGetLastError(), "ray_voxel_intersection launch");
+  return 0;
+}
+
+}  // extern "C"

@@ -124,3 +124,87 @@ def make_scene(name, P=None):
     gen = s_rand if cfg["scene"] == "s_rand" else s_city
     scene = gen(cfg["P"], cfg["seed"], cfg["sh_degree"])
     return cfg, scene
+
+
+# ------------------------------------------------------------------------------------------------
+# gcity-layout-v1: synthetic BEV city layout for the point-generation / visibility path (SURVEY.md
+# section 8 row f2).  Shapes, dtypes, class ids, per-class scales and the instance-id conventions are
+# the GOOGLE_EARTH ones of the reference (scripts/dataset_generator.py:42-118, 984-1004: buildings
+# carry even instance ids from 100, roof = facade id + 1; `PTS` = per-class stride grid masked by the
+# class, :198-221); the content is seeded noise, not OSM data.
+LAYOUT_CLASSES = {"NULL": 0, "ROAD": 1, "BLDG_FACADE": 2, "GREEN_LANDS": 3, "CONSTRUCTION": 4, "WATER": 5,
+                  "ZONE": 6, "BLDG_ROOF": 7}
+LAYOUT_SCALES = {"ROAD": 2, "BLDG_FACADE": 1, "BLDG_ROOF": 1, "GREEN_LANDS": 2, "CONSTRUCTION": 1, "WATER": 4,
+                 "ZONE": 2}
+LAYOUT_SEG_INS = {"BLDG_INS_MIN_ID": 100, "ROOF_INS_OFFSET": 1, "BLDG_FACADE_SEMANTIC_ID": 2,
+                  "BLDG_ROOF_SEMANTIC_ID": 7, "CAR_INS_MIN_ID": 32767, "CAR_SEMANTIC_ID": 32767}
+
+
+def layout_point_map(seg_map, classes=LAYOUT_CLASSES, scales=LAYOUT_SCALES):
+    """scripts/dataset_generator.py:198-221 (_get_point_maps): stride-`scale` lattice per class."""
+    pts = np.zeros(seg_map.shape, bool)
+    inv = {v: k for k, v in classes.items()}
+    for c in np.unique(seg_map):
+        name = inv[int(c)]
+        if name == "NULL":
+            continue
+        s = scales[name]
+        lattice = np.zeros(seg_map.shape, bool)
+        lattice[::s, ::s] = True
+        pts |= lattice & (seg_map == c)
+    return pts
+
+
+def s_layout(size=2048, seed=2001, block=128, road=16, elevation=4, max_height=300):
+    """Returns dict(INS, SEG, TD_HF, BU_HF int16 [size,size]; PTS bool): a road grid, blocks of green
+    land / zone / water / construction, and rectangular buildings with heights up to `max_height`."""
+    rng = np.random.default_rng(seed)
+    S = int(size)
+    seg = np.full((S, S), LAYOUT_CLASSES["GREEN_LANDS"], np.int16)
+    ins = seg.copy()
+    td = np.full((S, S), elevation, np.int16)
+    nb = (S + block - 1) // block
+    base_choices = np.array([LAYOUT_CLASSES[k] for k in ("GREEN_LANDS", "ZONE", "WATER", "CONSTRUCTION")], np.int16)
+    next_ins = LAYOUT_SEG_INS["BLDG_INS_MIN_ID"]
+    for by in range(nb):
+        for bx in range(nb):
+            y0, x0 = by * block + road, bx * block + road
+            y1, x1 = min(S, (by + 1) * block), min(S, (bx + 1) * block)
+            if y0 >= y1 or x0 >= x1:
+                continue
+            base = base_choices[rng.choice(4, p=[0.45, 0.3, 0.1, 0.15])]
+            seg[y0:y1, x0:x1] = base
+            ins[y0:y1, x0:x1] = base
+            if base == LAYOUT_CLASSES["GREEN_LANDS"]:  # rough vegetation: height noise -> many border columns
+                td[y0:y1, x0:x1] = elevation + rng.integers(0, 4, (y1 - y0, x1 - x0))
+            elif base == LAYOUT_CLASSES["WATER"]:
+                td[y0:y1, x0:x1] = elevation - 1
+                continue
+            for _ in range(int(rng.integers(1, 5))):
+                bw, bh = int(rng.integers(12, 64)), int(rng.integers(12, 64))
+                yy = int(rng.integers(y0, max(y0 + 1, y1 - bh)))
+                xx = int(rng.integers(x0, max(x0 + 1, x1 - bw)))
+                ye, xe = min(y1, yy + bh), min(x1, xx + bw)
+                if next_ins + 2 >= 16384:
+                    break
+                height = int(elevation + rng.integers(8, max_height))
+                seg[yy:ye, xx:xe] = LAYOUT_CLASSES["BLDG_FACADE"]
+                ins[yy:ye, xx:xe] = next_ins
+                td[yy:ye, xx:xe] = height
+                next_ins += 2
+    # roads last so that they cut cleanly between blocks
+    for k in range(0, S, block):
+        seg[k:k + road, :] = LAYOUT_CLASSES["ROAD"]; ins[k:k + road, :] = LAYOUT_CLASSES["ROAD"]; td[k:k + road, :] = elevation
+        seg[:, k:k + road] = LAYOUT_CLASSES["ROAD"]; ins[:, k:k + road] = LAYOUT_CLASSES["ROAD"]; td[:, k:k + road] = elevation
+    bu = np.zeros((S, S), np.int16)
+    return dict(INS=ins, SEG=seg, TD_HF=td, BU_HF=bu, PTS=layout_point_map(seg))
+
+
+def layout_camera(size=2048, W=960, H=540, pose=3, n_poses=24):
+    """cam_rig / pose for get_visible_points on an s_layout map: the reference's intrinsics
+    (config.py:36-37) and inference orbit scaled to the map (scripts/inference.py:168-199)."""
+    K = intrinsics(W, H)
+    rig = {"intrinsics": [float(v) for v in K.reshape(-1)], "sensor_size": [W, H]}
+    c = size / 2.0
+    pos, quat = orbit_poses(n_poses, radius=size / 4.0, altitude=size * 0.3125, centre=(c, c))[pose]
+    return rig, np.asarray(pos, np.float64), np.asarray(quat, np.float64)

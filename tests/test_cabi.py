@@ -89,3 +89,34 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     assert R.num_rendered == 0 and R.max_tile_instances == 0
     assert lib.gcr_mark_visible(-1, None, None, None, None, None) == -1
     assert lib.gcr_set_option(b"no_such_option", 1) < 0
+
+
+def _gcv_header_functions():
+    src = open(os.path.join(ROOT, "include", "gcv.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gcv_[a-z_]+)\s*\(", src)))
+
+
+def test_gcv_library_exports_every_declared_symbol():
+    """libgcv_hip.so (point generation / visibility, include/gcv.h): loads without a GPU and exports
+    exactly what the header declares; argument errors come back without touching the device."""
+    from gaussiancity_amd import _native_v as V
+    lib = V.lib()
+    declared = _gcv_header_functions()
+    assert set(declared) == set(V.EXPORTED_SYMBOLS), (declared, V.EXPORTED_SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", V.LIB_PATH]).decode()
+    assert set(declared) <= set(re.findall(r" T (gcv_[a-z_]+)", out))
+    assert lib.gcv_abi_version() == V.ABI_VERSION == int(
+        re.search(r"#define GCV_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "gcv.h")).read()).group(1))
+    code = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", V.LIB_PATH]).decode() \
+        if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") else "gfx950"
+    assert "gfx950" in code
+    assert lib.gcv_extrude_scratch_bytes(2048, 2048) >= 8 * (2 + 2048 * 2048 // 256)
+    assert lib.gcv_occupancy_bytes(16, 16, 16) == 4 and lib.gcv_occupancy_bytes(0, 1, 1) == 0
+    n = C.c_int64(0)
+    m = V.SegIns(100, 32767, 32767, 2, 1)
+    assert lib.gcv_extrude_count(1, None, C.byref(m), 8, 8, None, None, None, None, None, 0, C.byref(n), None) < 0
+    assert b"null" in lib.gcv_last_error()
+    assert lib.gcv_points_to_volume(0, None, None, None, 0, 4, 4, None, None, None) < 0
+    assert lib.gcv_ray_voxel_intersection(None, None, None, None, None, None, None, 1.0, None, None, 1, None, None,
+                                          None, None) < 0

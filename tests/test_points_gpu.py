@@ -1,0 +1,200 @@
+"""-m gpu: the HIP point-generation / visibility path (gaussiancity_amd.points -> C ABI include/gcv.h ->
+gfx950 kernels) against the oracle and the reference-generated golden vectors.  Everything here is
+integer / index work or IEEE fp32 in a fixed order, so the bar is BIT-EXACT throughout."""
+import numpy as np
+import pytest
+import torch
+
+import points_util as U
+from gaussiancity_amd import points as P
+from gaussiancity_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import points_oracle as PO
+    PO.lib()
+    return PO
+
+
+@pytest.mark.parametrize("case", U.golden_cases(), ids=lambda c: c[0])
+def test_extruder_matches_reference_golden(cuda_device, case):
+    name, inv, scales, seg_ins, seg, td, bu, pts, want = case
+    for inc in (True, False):
+        got = P.get_points_from_projection(inc, inv, scales, seg_ins, seg, td, bu, pts)
+        if want[inc].shape[0] == 0:
+            assert got is None
+        else:
+            assert got.dtype == np.uint16 and got.shape == want[inc].shape
+            assert np.array_equal(got, want[inc])
+
+
+def test_extruder_matches_oracle_on_ragged_random_maps(cuda_device, po):
+    rng = np.random.default_rng(321)
+    inv = {v: k for k, v in synth.LAYOUT_CLASSES.items()}
+    for trial in range(8):
+        H, W = int(rng.integers(1, 300)), int(rng.integers(1, 300))  # incl. maps smaller than a scale
+        L = synth.s_layout(max(H, W, 16), 4000 + trial, block=int(rng.integers(16, 64)), road=int(rng.integers(2, 9)),
+                           max_height=int(rng.integers(10, 120)))
+        seg, td, pts = (np.ascontiguousarray(L[k][:H, :W]) for k in ("INS", "TD_HF", "PTS"))
+        bu = rng.integers(-1, 4, (H, W)).astype(np.int16)
+        for inc in (True, False):
+            a = po.extrude(inc, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, seg, td, bu, pts)
+            b = P.get_points_from_projection(inc, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, seg, td, bu, pts)
+            assert (a is None) == (b is None), (H, W, inc)
+            if a is not None:
+                assert np.array_equal(a, b), (H, W, inc)
+
+
+def test_extruder_argument_and_class_errors(cuda_device):
+    inv = {v: k for k, v in synth.LAYOUT_CLASSES.items()}
+    z = np.zeros((8, 8), np.int16)
+    ok = (True, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, z + 1, z + 3, z, np.ones((8, 8), bool))
+    assert P.get_points_from_projection(*ok) is not None
+    for k, bad in ((0, 1), (1, []), (2, None), (3, 7), (4, z.tolist()), (7, "x")):  # PyArg_ParseTuple O! checks
+        args = list(ok)
+        args[k] = bad
+        with pytest.raises(TypeError):
+            P.get_points_from_projection(*args)
+    with pytest.raises(RuntimeError, match="semantic id"):  # upstream would never terminate here
+        P.get_points_from_projection(True, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, z + 9, z + 3, z,
+                                     np.ones((8, 8), bool))
+    with pytest.raises(IndexError):  # std::map::at upstream
+        P.get_points_from_projection(True, inv, synth.LAYOUT_SCALES, {"BLDG_INS_MIN_ID": 100}, z + 1, z + 3, z,
+                                     np.ones((8, 8), bool))
+
+
+def test_points_to_volume_and_occupancy(cuda_device, po):
+    rng = np.random.default_rng(11)
+    for h, w, d, n in ((13, 17, 11, 500), (64, 40, 33, 6000), (8, 8, 8, 1), (5, 3, 70, 0)):
+        pts, ids, sc = U.random_points(rng, n, h, w, d)
+        want = po.points_to_volume(pts, ids, sc, h, w, d)
+        t = [torch.from_numpy(a).to(cuda_device) for a in (pts, ids, sc)]
+        vol, occ = P.points_to_volume(*t, h, w, d, return_occupancy=True)
+        assert vol.dtype == torch.int32 and tuple(vol.shape) == (h, w, d)
+        assert np.array_equal(vol.cpu().numpy(), want)
+        assert torch.equal(P.points_to_volume(*t, h, w, d), vol)
+        # occupancy: exactly the bricks holding a non-zero voxel... plus bricks a clipped cube touched
+        hb, wb, db = (h + 7) // 8, (w + 7) // 8, (d + 7) // 8
+        pad = np.zeros((hb * 8, wb * 8, db * 8), np.int32)
+        pad[:h, :w, :d] = want
+        brick_any = pad.reshape(hb, 8, wb, 8, db, 8).any(axis=(1, 3, 5)).reshape(-1)
+        bits = np.unpackbits(occ.cpu().numpy().view(np.uint8), bitorder="little")[:brick_any.size].astype(bool)
+        assert np.array_equal(bits, brick_any)
+        # the same bitmask from the dense volume alone
+        from gaussiancity_amd import _native_v as V
+        occ2 = torch.zeros_like(occ)
+        V.check(V.lib().gcv_build_occupancy(vol.data_ptr(), h, w, d, occ2.data_ptr(), None), "gcv_build_occupancy")
+        torch.cuda.synchronize()
+        assert torch.equal(occ2, occ)
+    with pytest.raises(RuntimeError):
+        P.points_to_volume(torch.zeros((1, 3), dtype=torch.int16), t[1], t[2], 4, 4, 4)  # CHECK_CUDA
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("use_occ", [False, True])
+def test_traversal_bit_exact(cuda_device, po, variant, use_occ):
+    rng = np.random.default_rng(70 + variant)
+    h, w, d = 72, 61, 37
+    vol = U.shell_volume(rng, h, w, d, 8)
+    rows, cols = 45, 83  # ragged: not multiples of the 8x8 tile
+    ori, dr, up, f, c, img = U.camera_for_volume(h, w, d, rows, cols, variant)
+    want = po.ray_voxel_intersection_perspective(vol, ori, dr, up, f, c, img, 2)
+    v = torch.from_numpy(vol).to(cuda_device)
+    occ = None
+    if use_occ:
+        from gaussiancity_amd import _native_v as V
+        occ = torch.zeros(max(1, V.lib().gcv_occupancy_bytes(h, w, d) // 4), dtype=torch.int32, device=cuda_device)
+        V.check(V.lib().gcv_build_occupancy(v.data_ptr(), h, w, d, occ.data_ptr(), None), "gcv_build_occupancy")
+    got = P.ray_voxel_intersection_perspective(v, torch.from_numpy(ori), torch.from_numpy(dr), torch.from_numpy(up),
+                                               f, c, img, 2, occupancy=occ)
+    assert [tuple(t.shape) for t in got] == [(rows, cols, 2, 1), (2, rows, cols, 2, 1), (rows, cols, 1, 3)]
+    assert np.array_equal(got[0].cpu().numpy(), want[0])
+    assert np.array_equal(got[1].cpu().numpy().view(np.uint32), want[1].view(np.uint32))  # incl. the NaN pattern
+    assert np.array_equal(got[2].cpu().numpy().view(np.uint32), want[2].view(np.uint32))
+    assert (want[0] != 0).mean() > 0.2
+
+
+def test_traversal_strided_volume_and_errors(cuda_device, po):
+    rng = np.random.default_rng(3)
+    h, w, d = 30, 26, 20
+    vol = U.shell_volume(rng, h, w, d, 5)
+    ori, dr, up, f, c, img = U.camera_for_volume(h, w, d, 24, 40, 0)
+    want = po.ray_voxel_intersection_perspective(vol, ori, dr, up, f, c, img, 1)
+    vT = torch.from_numpy(np.ascontiguousarray(vol.transpose(2, 0, 1))).to(cuda_device).permute(1, 2, 0)  # same values, other strides
+    assert not vT.is_contiguous()
+    cam = [torch.from_numpy(a) for a in (ori, dr, up)]
+    got = P.ray_voxel_intersection_perspective(vT, *cam, f, c, img, 1)
+    assert np.array_equal(got[0].cpu().numpy(), want[0])
+    assert np.array_equal(got[1].cpu().numpy().view(np.uint32), want[1].view(np.uint32))
+    with pytest.raises(RuntimeError):
+        P.ray_voxel_intersection_perspective(torch.from_numpy(vol), *cam, f, c, img, 1)  # CPU tensor
+    with pytest.raises(RuntimeError):
+        P.ray_voxel_intersection_perspective(vT.float(), *cam, f, c, img, 1)
+    with pytest.raises(RuntimeError):
+        P.ray_voxel_intersection_perspective(vT, cam[0].double(), cam[1], cam[2], f, c, img, 1)
+
+
+def _visible_points_oracle(po, points, scales, rig, cam_pos, cam_quat, null_id):
+    """scripts/dataset_generator.py:1414-1461 composed from the oracle's pieces (numpy)."""
+    pts = points[:, [0, 1, 2]].astype(np.int16)
+    mn, mx = pts.min(0), pts.max(0)
+    loc = pts.copy()
+    loc[:, 0] -= mn[0]; loc[:, 1] -= mn[1]; loc[:, 2] -= mn[2] - 1
+    w, h, d = int(mx[0]) - int(mn[0]) + 1, int(mx[1]) - int(mn[1]) + 1, int(mx[2]) - int(mn[2]) + 2
+    vol = po.points_to_volume(loc, np.arange(1, len(pts) + 1, dtype=np.int32), scales.astype(np.int16), h, w, d)
+    cam = np.array(cam_pos, np.float64) - mn.astype(np.int16)
+    look = P.get_camera_look_at(cam, cam_quat)
+    ori = np.array([cam[1], cam[0], cam[2]], np.float32)
+    view = np.array([look[1] - cam[1], look[0] - cam[0], look[2] - cam[2]], np.float32)
+    K, sensor = rig["intrinsics"], rig["sensor_size"]
+    vid, _, _ = po.ray_voxel_intersection_perspective(vol, ori, view, np.array([0, 0, 1], np.float32), K[0],
+                                                      [K[5], K[2]], [sensor[1], sensor[0]], 1)
+    vp = vid.squeeze().astype(np.int64) - 1
+    ins = points[:, 4][np.clip(vp, 0, None)].copy()
+    ins[vp == -1] = null_id
+    return vp, ins
+
+
+def test_get_visible_points_end_to_end(cuda_device, po):
+    """maps -> extruded points -> volume -> traversal, HIP vs oracle, on a 256 px layout."""
+    size = 256
+    L = synth.s_layout(size, 2201, block=64, road=8, max_height=70)
+    inv = {v: k for k, v in synth.LAYOUT_CLASSES.items()}
+    pts = P.get_points_from_projection(True, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, L["INS"], L["TD_HF"],
+                                       L["BU_HF"], L["PTS"])
+    want_pts = po.extrude(True, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, L["INS"], L["TD_HF"], L["BU_HF"], L["PTS"])
+    assert np.array_equal(pts, want_pts)
+    points = pts.astype(np.int16)
+    scales = np.repeat(points[:, [3]], 3, axis=1)  # utils/helpers.get_point_scales without special classes
+    rig, cam_pos, cam_quat = synth.layout_camera(size, W=240, H=136)
+    vp, ins = P.get_visible_points(points, scales, rig, cam_pos.copy(), cam_quat, null_class_id=0)
+    vp_o, ins_o = _visible_points_oracle(po, points, scales, rig, cam_pos, cam_quat, 0)
+    assert vp.shape == (136, 240) and np.array_equal(vp, vp_o) and np.array_equal(ins, ins_o)
+    assert (vp >= 0).mean() > 0.5
+    # reduce_mem (scale 1/3, :1428-1433) runs and sees the same scene
+    vp3, _ = P.get_visible_points(points, scales, rig, cam_pos.copy(), cam_quat, 0, reduce_mem=True)
+    assert vp3.shape == vp.shape and (vp3 >= 0).mean() > 0.5
+
+
+def test_full_size_extruder_properties(cuda_device):
+    """BASELINE-size map (2048 x 2048, ~17 M points): order, ranges and hollowness hold; two runs agree."""
+    L = synth.s_layout(2048, 2001)
+    inv = {v: k for k, v in synth.LAYOUT_CLASSES.items()}
+    t = [torch.from_numpy(L[k]).to(cuda_device) for k in ("INS", "TD_HF", "BU_HF", "PTS")]
+    out = P.extrude_points(True, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, *t)
+    out2 = P.extrude_points(True, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, *t)
+    assert torch.equal(out, out2) and out.shape[0] > 10_000_000
+    x, y, z, s, ins = (out[:, k].long() for k in range(5))
+    key = ((y * 2048 + x) << 16) + (z + 1024)
+    assert bool((key[1:] > key[:-1]).all())  # row-major pixels, z ascending, no duplicates
+    seg, td, bu, pm = (v.long() for v in t)
+    assert bool(pm[y, x].all()) and bool((z <= td[y, x]).all()) and bool((z >= bu[y, x]).all())
+    assert bool(((z - bu[y, x]) % s == 0).all())
+    roof = ins != seg[y, x]
+    assert bool((ins[roof] == seg[y, x][roof] + 1).all()) and bool((z[roof] > td[y, x][roof] - s[roof]).all())
+    # every pixel of the point map contributes its top point exactly once
+    top = z > td[y, x] - s
+    assert int(top.sum()) == int(((td >= bu) & (pm > 0)).sum())
