@@ -70,6 +70,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--fast-exp", action="store_true", help="non-parity v_exp_f32 variant (A/B only)")
+    ap.add_argument("--path", default="raster", choices=["raster", "visibility"],
+                    help="raster (default): the rasterizer hot path; visibility: SURVEY 8 row f2, BEV maps -> points -> "
+                         "volume -> per-pixel first hit (one step = one camera pose)")
+    ap.add_argument("--layout-size", type=int, default=2048, help="--path visibility: BEV map edge in pixels")
+    ap.add_argument("--jumps", type=int, default=0,
+                    help="--path visibility: empty-space jumps in the traversal (A/B knob; same outputs)")
     ap.add_argument("--train-step", action="store_true",
                     help="C4 training-step harness (fwd + loss + bwd + gradient all-reduce) instead of the frame loop")
     ap.add_argument("--host-threads", type=int, default=1,
@@ -119,6 +125,8 @@ def main():
         torch.cuda.synchronize()
         return 10 * 2 * a.numel() * 4 / 1e9 / (time.perf_counter() - tc)
 
+    if args.path == "visibility":
+        return visibility_bench(args, torch, dist, synth, dev, world, rank, barrier, copy_ceiling)
     if args.train_step:
         return train_step_bench(args, torch, dist, N, synth, GaussianRasterizerWrapper, dev, world, rank, barrier)
 
@@ -349,6 +357,134 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def visibility_bench(args, torch, dist, synth, dev, world, rank, barrier, copy_ceiling):
+    """Row f2 (scripts/dataset_generator.py:1251-1461 as called per frame by scripts/inference.py:296-333):
+    BEV maps -> footprint extruder -> point-id volume -> perspective traversal -> vp_map / ins_map, everything
+    resident in HBM.  One step = one pose of the 24-pose orbit over the same 2048 x 2048 layout (upstream
+    re-extrudes and re-voxelises per frame too); frames are independent, so rank r takes poses r, r+N, ...
+    (weak scaling, no collective)."""
+    from gaussiancity_amd import _native_v as V
+    from gaussiancity_amd import points as PT
+    size = args.layout_size
+    L = synth.s_layout(size, 2001)
+    inv = {v: k for k, v in synth.LAYOUT_CLASSES.items()}
+    maps = [torch.from_numpy(L[k]).to(dev) for k in ("INS", "TD_HF", "BU_HF", "PTS")]
+    Wimg, Himg = 960, 540
+    rig = synth.layout_camera(size, Wimg, Himg)[0]
+    poses = [synth.layout_camera(size, Wimg, Himg, pose=i)[1:] for i in range(24)]
+    V.lib()
+
+    def frame(i):
+        cam_pos, cam_quat = poses[i % len(poses)]
+        rows = PT.extrude_points(True, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, *maps)
+        vp, ins = PT.visible_point_map(rows, rig, cam_pos, cam_quat, 0, use_jumps=bool(args.jumps))
+        return rows, vp, ins
+
+    for i in range(args.warmup):
+        frame(rank + i * world)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        frame(rank + i * world)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    V.set_option("timing", 1)
+    V.stage_ms()
+    for i in range(min(args.steps, 12)):
+        rows, vp, ins = frame(rank + i * world)
+    torch.cuda.synchronize()
+    st = V.stage_ms()
+    V.set_option("timing", 0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        n_pts = int(rows.shape[0])
+        mn, mx = rows[:, :3].min(dim=0).values.cpu().numpy(), rows[:, :3].max(dim=0).values.cpu().numpy()
+        w, h, d = int(mx[0]) - int(mn[0]) + 1, int(mx[1]) - int(mn[1]) + 1, int(mx[2]) - int(mn[2]) + 2
+        npix_map = size * size
+        # algorithmic bytes per stage (DESIGN.md section 11): maps 7 B/pixel per pass (count, emit) + 10 B/point
+        # written; volume clear 4 B/voxel; scatter 10 B/point read + 4 B per written voxel; traversal: outputs
+        # only (24 B/pixel) -- what it reads depends on the scene, so it is reported as time, not GB/s
+        voxels_written = int((rows[:, 3].long() ** 3).sum().item())
+        ab = {"extrude_count": 7 * npix_map, "extrude_emit": 7 * npix_map + 10 * n_pts,
+              "volume_clear": 4 * h * w * d, "volume_scatter": 10 * n_pts + 4 * voxels_written,
+              "traversal": 24 * Himg * Wimg}
+        stages = {k: {"ms": round(st[k], 4), "alg_MB": round(ab[k] / 1e6, 2),
+                      "alg_GBps": round(ab[k] / 1e9 / (st[k] / 1e3), 1) if st.get(k, 0) > 0 and k != "traversal" else None}
+                  for k in ab}
+        dom = max(ab, key=lambda k: st.get(k, 0.0))
+        hbm_dom = max((k for k in ab if k != "traversal"), key=lambda k: st.get(k, 0.0))
+        ceiling = copy_ceiling()
+        ach = ab[hbm_dom] / 1e9 / (st[hbm_dom] / 1e3)
+        out = {
+            "metric": "visibility frames/sec (BEV maps -> points -> volume -> first-hit map) @ %dx%d layout, %dx%d image"
+                      % (size, size, Wimg, Himg),
+            "value": round(args.steps * world / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int16/int32 (+ f32 ray setup)",
+            "data": "synthetic (gcity-layout-v1, seed 2001)",
+            "config": {"workload": "V1: %dx%d BEV layout, %d extruded points, %dx%dx%d int32 volume (%.2f GB), %dx%d rays, "
+                                   "24-pose orbit" % (size, size, n_pts, h, w, d, 4 * h * w * d / 1e9, Wimg, Himg),
+                       "parallelism": "frames sharded round-robin, one frame per GPU, no data-path collective",
+                       "empty_space_jumps": bool(args.jumps)},
+            "frame_stats": {"points": n_pts, "voxels_written": voxels_written,
+                            "hit_fraction": round(float((vp >= 0).float().mean().item()), 4)},
+            "stages_ms": stages, "longest_stage": dom,
+            "roofline": {"kernel": hbm_dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "copy_ceiling_GBps": round(ceiling, 1),
+                         "frac_of_copy_ceiling": round(ach / ceiling, 4), "launch_ms": round(st[hbm_dom], 4),
+                         "alg_bytes_per_launch": int(ab[hbm_dom]),
+                         "note": "the traversal is latency-bound pointer chasing through the volume (no byte model): "
+                                 "reported as time; the roofline object describes the slowest streaming stage"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = visibility_cpu_baseline(L, inv, synth, rows, (h, w, d), mn, poses[0], rig, vp)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def visibility_cpu_baseline(L, inv, synth, rows_gpu, dims, mn, pose, rig, vp_gpu_last):
+    """CPU side of one frame of the same workload: the REFERENCE's own extruder (oracle/_ref, compiled from the
+    reference source, single-threaded as upstream) when present -- kind "reference" -- else the oracle port;
+    volume + traversal = oracle port (the reference has no CPU path for them; traversal on all cores)."""
+    from gaussiancity_amd import points as PT
+    from oracle import points_oracle as PO
+    PO.lib()
+    ref = PO.reference_extruder()
+    a = (True, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, L["INS"], L["TD_HF"], L["BU_HF"], L["PTS"])
+    tc = time.perf_counter()
+    cpu_pts = ref.get_points_from_projection(*a) if ref is not None else PO.extrude(*a)
+    t_ext = time.perf_counter() - tc
+    same_pts = bool(np.array_equal(cpu_pts, rows_gpu.cpu().numpy().view(np.uint16)))
+    p16 = cpu_pts.astype(np.int16)
+    loc = p16[:, :3] - np.array([mn[0], mn[1], mn[2] - 1], np.int16)
+    h, w, d = dims
+    tc = time.perf_counter()
+    vol = PO.points_to_volume(loc, np.arange(1, len(loc) + 1, dtype=np.int32), np.repeat(p16[:, [3]], 3, axis=1), h, w, d)
+    t_vol = time.perf_counter() - tc
+    cp = np.array(pose[0], np.float64) - np.array(mn, np.float64)
+    look = PT.get_camera_look_at(cp, pose[1])
+    K, sensor = rig["intrinsics"], rig["sensor_size"]
+    tc = time.perf_counter()
+    vid, _, _ = PO.ray_voxel_intersection_perspective(
+        vol, np.array([cp[1], cp[0], cp[2]], np.float32),
+        np.array([look[1] - cp[1], look[0] - cp[0], look[2] - cp[2]], np.float32), np.array([0, 0, 1], np.float32),
+        K[0], [K[5], K[2]], [sensor[1], sensor[0]], 1)
+    t_rv = time.perf_counter() - tc
+    vp0, _ = PT.visible_point_map(rows_gpu, rig, pose[0], pose[1], 0)
+    same_vp = bool(np.array_equal(vp0.cpu().numpy(), vid.squeeze().astype(np.int64) - 1))
+    total = t_ext + t_vol + t_rv
+    return {"value": round(1.0 / total, 4), "unit": "frames/s", "cores": 1, "kind": "reference" if ref is not None else "port",
+            "sample": "1 frame of the same workload: extruder %.2f s (%s), volume %.2f s + traversal %.2f s (oracle port, "
+                      "traversal on all cores)" % (t_ext, "the reference's footprint_extruder.cpp" if ref is not None
+                                                   else "oracle port", t_vol, t_rv),
+            "gpu_points_bit_exact_vs_cpu": same_pts, "gpu_first_hit_map_bit_exact_vs_cpu": same_vp}
 
 
 def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, barrier):

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -240,11 +241,35 @@ __global__ __launch_bounds__(EX_BLOCK) void k_extrude_emit(const ExtrudeArgs a, 
 
 // =============================================================================================== K14
 // vox/points_to_volume.cu:21-50.  One thread per point; atomicMax makes the overlap rule
-// deterministic (highest id wins = sequential order).  Bricks touched are flagged in the occupancy
-// bitmask (1 bit per 8x8x8 voxels) for the traversal.
-__device__ __forceinline__ void occ_set(uint32_t* occ, int kb, int jb, int lb, int wb, int db) {
-  const long long lin = ((long long)kb * wb + jb) * db + lb;
-  atomicOr(&occ[lin >> 5], 1u << (lin & 31));
+// deterministic (highest id wins = sequential order).
+//
+// Occupancy = 1 bit per 16x16x16 macro cell, for the traversal's empty-space jumps.  Millions of
+// points share a few thousand bitmask words and device-scope atomics to one address serialise at the
+// memory side (a per-point atomicOr took 2.4 ms of a 2.9 ms scatter; testing the bit first does not
+// help because the per-XCD L2s are not coherent).  Consecutive points are spatial neighbours, so each
+// wave first merges the bits of lanes that target the same word and issues ONE atomicOr per distinct
+// word; only cubes straddling a macro-cell face add individual atomics.
+constexpr int MC_SHIFT = 4;  // macro cell = 16^3 voxels
+
+__device__ __forceinline__ long long mc_linear(int kb, int jb, int lb, int wb, int db) {
+  return ((long long)kb * wb + jb) * db + lb;
+}
+
+__device__ __forceinline__ void occ_set_wave(uint32_t* occ, bool valid, long long lin) {
+  uint32_t word = valid ? (uint32_t)(lin >> 5) : 0xffffffffu;
+  const uint32_t bit = valid ? 1u << (lin & 31) : 0u;
+  while (true) {
+    const unsigned long long todo = __ballot(word != 0xffffffffu);
+    if (todo == 0ull) break;
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t w0 = (uint32_t)__shfl((int)word, leader, 64);
+    const bool mine = word == w0;
+    uint32_t bits = mine ? bit : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bits |= (uint32_t)__shfl_xor((int)bits, o, 64);
+    if ((int)(threadIdx.x & 63) == leader) atomicOr(&occ[w0], bits);
+    if (mine) word = 0xffffffffu;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_points_to_volume(long long n, int h, int w, int d,
@@ -253,46 +278,143 @@ __global__ __launch_bounds__(256) void k_points_to_volume(long long n, int h, in
                                                           const int16_t* __restrict__ scales,
                                                           int32_t* __restrict__ volume, uint32_t* __restrict__ occ) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  const int pid = pt_ids[idx];
-  const int x = points[3 * idx], y = points[3 * idx + 1], z = points[3 * idx + 2];
-  const int sx = scales[3 * idx], sy = scales[3 * idx + 1], sz = scales[3 * idx + 2];
-  if (x >= w || y >= h || z >= d || x < 0 || y < 0 || z < 0) return;
-  const int xe = min(x + sx, w), ye = min(y + sy, h), ze = min(z + sz, d);
-  for (int j = x; j < xe; ++j)
-    for (int k = y; k < ye; ++k)
-      for (int l = z; l < ze; ++l) atomicMax(&volume[((long long)k * w + j) * d + l], pid);
-  if (occ != nullptr && xe > x && ye > y && ze > z) {
-    const int wb = (w + 7) >> 3, db = (d + 7) >> 3;
-    for (int kb = y >> 3; kb <= (ye - 1) >> 3; kb++)
-      for (int jb = x >> 3; jb <= (xe - 1) >> 3; jb++)
-        for (int lb = z >> 3; lb <= (ze - 1) >> 3; lb++) occ_set(occ, kb, jb, lb, wb, db);
+  bool valid = idx < n;
+  int pid = 0, x = 0, y = 0, z = 0, xe = 0, ye = 0, ze = 0;
+  if (valid) {
+    pid = pt_ids[idx];
+    x = points[3 * idx]; y = points[3 * idx + 1]; z = points[3 * idx + 2];
+    const int sx = scales[3 * idx], sy = scales[3 * idx + 1], sz = scales[3 * idx + 2];
+    valid = !(x >= w || y >= h || z >= d || x < 0 || y < 0 || z < 0);
+    xe = min(x + sx, w); ye = min(y + sy, h); ze = min(z + sz, d);
+    valid = valid && xe > x && ye > y && ze > z;
+  }
+  if (valid) {
+    for (int j = x; j < xe; ++j)
+      for (int k = y; k < ye; ++k)
+        for (int l = z; l < ze; ++l) atomicMax(&volume[((long long)k * w + j) * d + l], pid);
+  }
+  if (occ != nullptr) {  // wave-uniform
+    const int wb = (w + 15) >> MC_SHIFT, db = (d + 15) >> MC_SHIFT;
+    occ_set_wave(occ, valid, mc_linear(y >> MC_SHIFT, x >> MC_SHIFT, z >> MC_SHIFT, wb, db));
+    if (valid && (((ye - 1) >> MC_SHIFT) != (y >> MC_SHIFT) || ((xe - 1) >> MC_SHIFT) != (x >> MC_SHIFT) ||
+                  ((ze - 1) >> MC_SHIFT) != (z >> MC_SHIFT))) {  // cube straddles a macro-cell face
+      for (int kb = y >> MC_SHIFT; kb <= (ye - 1) >> MC_SHIFT; kb++)
+        for (int jb = x >> MC_SHIFT; jb <= (xe - 1) >> MC_SHIFT; jb++)
+          for (int lb = z >> MC_SHIFT; lb <= (ze - 1) >> MC_SHIFT; lb++) {
+            const long long lin = mc_linear(kb, jb, lb, wb, db);
+            atomicOr(&occ[lin >> 5], 1u << (lin & 31));
+          }
+    }
   }
 }
 
-// occupancy of an arbitrary dense volume: thread per (k, j, lb) ORs 8 contiguous voxels
+// Fused-pipeline variants (scripts/dataset_generator.py:1366-1388, _get_volume, without the host
+// round trips): bounds of the extruded rows, then rows [n][5] = (x, y, z, scale, instance) straight
+// into the volume with the localisation offsets applied in flight, id = row index + 1 and a cube of
+// `scale` voxels per side (utils/helpers.get_point_scales with no special classes).
+__global__ __launch_bounds__(256) void k_rows_bounds(long long n, const int16_t* __restrict__ rows, int stride,
+                                                     int* __restrict__ mnmx) {
+  int mn[3] = {32767, 32767, 32767}, mx[3] = {-32768, -32768, -32768};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const int v = rows[i * stride + a];
+      mn[a] = min(mn[a], v);
+      mx[a] = max(mx[a], v);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64));
+      mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&mnmx[a], mn[a]);
+      atomicMax(&mnmx[3 + a], mx[a]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rows_to_volume(long long n, int h, int w, int d, const int16_t* __restrict__ rows,
+                                                        int ox, int oy, int oz, int32_t* __restrict__ volume,
+                                                        uint32_t* __restrict__ occ) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = idx < n;
+  int x = 0, y = 0, z = 0, xe = 0, ye = 0, ze = 0;
+  if (valid) {
+    const int16_t* r = rows + 5 * idx;
+    // int16 arithmetic as the reference's tensor ops (points[:, k] -= offset wraps in int16)
+    x = (int16_t)(r[0] - ox); y = (int16_t)(r[1] - oy); z = (int16_t)(r[2] - oz);
+    const int s = r[3];
+    valid = !(x >= w || y >= h || z >= d || x < 0 || y < 0 || z < 0);
+    xe = min(x + s, w); ye = min(y + s, h); ze = min(z + s, d);
+    valid = valid && xe > x && ye > y && ze > z;
+  }
+  if (valid) {
+    const int pid = (int)(idx + 1);
+    for (int j = x; j < xe; ++j)
+      for (int k = y; k < ye; ++k)
+        for (int l = z; l < ze; ++l) atomicMax(&volume[((long long)k * w + j) * d + l], pid);
+  }
+  if (occ != nullptr) {
+    const int wb = (w + 15) >> MC_SHIFT, db = (d + 15) >> MC_SHIFT;
+    occ_set_wave(occ, valid, mc_linear(y >> MC_SHIFT, x >> MC_SHIFT, z >> MC_SHIFT, wb, db));
+    if (valid && (((ye - 1) >> MC_SHIFT) != (y >> MC_SHIFT) || ((xe - 1) >> MC_SHIFT) != (x >> MC_SHIFT) ||
+                  ((ze - 1) >> MC_SHIFT) != (z >> MC_SHIFT))) {
+      for (int kb = y >> MC_SHIFT; kb <= (ye - 1) >> MC_SHIFT; kb++)
+        for (int jb = x >> MC_SHIFT; jb <= (xe - 1) >> MC_SHIFT; jb++)
+          for (int lb = z >> MC_SHIFT; lb <= (ze - 1) >> MC_SHIFT; lb++) {
+            const long long lin = mc_linear(kb, jb, lb, wb, db);
+            atomicOr(&occ[lin >> 5], 1u << (lin & 31));
+          }
+    }
+  }
+}
+
+// occupancy of an arbitrary dense volume: one thread per (k, j, 16-voxel run along d); the wave merges
+// its bits (64 consecutive runs = at most a few words) before touching memory
 __global__ __launch_bounds__(256) void k_build_occ(const int32_t* __restrict__ volume, int h, int w, int d,
                                                    uint32_t* __restrict__ occ) {
-  const int db = (d + 7) >> 3, wb = (w + 7) >> 3;
+  const int db = (d + 15) >> MC_SHIFT, wb = (w + 15) >> MC_SHIFT;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)h * w * db) return;
-  const int lb = (int)(t % db);
-  const long long kj = t / db;
-  const int j = (int)(kj % w), k = (int)(kj / w);
-  const int32_t* p = volume + ((long long)k * w + j) * d + 8 * lb;
-  const int nz = min(8, d - 8 * lb);
-  int32_t any = 0;
-  for (int l = 0; l < nz; l++) any |= p[l];
-  if (any != 0) occ_set(occ, k >> 3, j >> 3, lb, wb, db);
+  bool any = false;
+  long long lin = 0;
+  if (t < (long long)h * w * db) {
+    const int lb = (int)(t % db);
+    const long long kj = t / db;
+    const int j = (int)(kj % w), k = (int)(kj / w);
+    const int32_t* p = volume + ((long long)k * w + j) * d + 16 * lb;
+    const int nz = min(16, d - 16 * lb);
+    int32_t acc = 0;
+    for (int l = 0; l < nz; l++) acc |= p[l];
+    any = acc != 0;
+    lin = mc_linear(k >> MC_SHIFT, j >> MC_SHIFT, lb, wb, db);
+  }
+  occ_set_wave(occ, any, lin);
 }
 
 // =============================================================================================== K12
 // vox/ray_voxel_intersection.cu:54-216.  One wave = one 8x8 pixel tile (upstream's block shape, which
-// is exactly a wave64).  The crossing times are recomputed from the integer cell every step
-// (upstream's expression), so the walk is a pure function of the cell sequence and can be reproduced
-// bit for bit.  MI355X change: with the brick bitmask the volume is only read inside occupied bricks;
-// the bit is re-read only when the step crosses a brick face (cell & 7 wraps), so in empty space a
-// step is ALU only.
+// is exactly a wave64).  Every crossing time is recomputed from the integer cell (upstream's
+// expression, IEEE division), so the walk is a pure function of the cell sequence.
+//
+// MI355X change (HAS_OCC): upstream tests one voxel per step -- a dependent, cache-missing load per
+// cell, ~700 per ray.  With the macro-cell bitmask a ray standing in an EMPTY 16^3 cell jumps to the
+// cell it leaves through, in one move that reproduces the reference walk exactly:
+//   * upstream's loop is a 3-way merge of the per-axis crossing sequences, ordered by (time, axis)
+//     with its "<=" chain as the tie rule; crossing times along one axis never decrease;
+//   * the exit event E is the first, in that order, of the three "leave the macro cell" crossings;
+//   * every other axis has by then performed exactly the crossings that precede E in that order --
+//     counted with the same fp32 expression (estimate from ori + T*dir, then corrected with the exact
+//     predicate, so the count is the reference's whatever the estimate was);
+//   * cells, times and the quit flag after the jump are what stepping would have left.
+// Voxels are only read inside occupied macro cells.  Outputs are bit-identical with and without the
+// bitmask (tests/test_points_gpu.py).
 struct RvipArgs {
   int dims[3];
   long long strides[3];
@@ -300,7 +422,7 @@ struct RvipArgs {
   int img[2];
   float ori[3], fwd[3], side[3], up[3];
   float c[2], f;
-  int wb, db;  // bricks along w and d (occupancy)
+  int wb, db;  // macro cells along w and d (occupancy)
 };
 
 __device__ __forceinline__ void dev_normalize3(float* a) {  // vox/voxlib_common.h:56-68
@@ -312,20 +434,48 @@ __device__ __forceinline__ void dev_normalize3(float* a) {  // vox/voxlib_common
   for (int i = 0; i < 3; i++) a[i] /= len;
 }
 
-#define GCV_STEP(AX)                                                        \
-  {                                                                         \
-    tnow = axis_t[AX];                                                      \
-    if (raydir[AX] > 0) {                                                   \
-      axis_int[AX] += 1;                                                    \
-      if (axis_int[AX] >= p.dims[AX]) quit = true;                          \
-      axis_t[AX] = ((float)(axis_int[AX] + 1) - p.ori[AX]) / raydir[AX];    \
-      crossed = (axis_int[AX] & 7) == 0;                                    \
-    } else {                                                                \
-      axis_int[AX] -= 1;                                                    \
-      if (axis_int[AX] < 0) quit = true;                                    \
-      axis_t[AX] = ((float)axis_int[AX] - p.ori[AX]) / raydir[AX];          \
-      crossed = (axis_int[AX] & 7) == 7;                                    \
-    }                                                                       \
+// time of the crossing through integer boundary N on axis AX: upstream's axis_t expression
+#define GCV_TCROSS(AX, N) (((float)(N)-p.ori[AX]) / raydir[AX])
+
+#define GCV_STEP(AX)                                  \
+  {                                                   \
+    tnow = axis_t[AX];                                \
+    if (raydir[AX] > 0) {                             \
+      axis_int[AX] += 1;                              \
+      if (axis_int[AX] >= p.dims[AX]) quit = true;    \
+      axis_t[AX] = GCV_TCROSS(AX, axis_int[AX] + 1);  \
+    } else {                                          \
+      axis_int[AX] -= 1;                              \
+      if (axis_int[AX] < 0) quit = true;              \
+      axis_t[AX] = GCV_TCROSS(AX, axis_int[AX]);      \
+    }                                                 \
+  }
+
+// Cell of axis AX after the crossings it performs before event (TE, E).  Its boundaries are cur+1,
+// cur+2, ... for a positive direction and cur, cur-1, ... for a negative one; crossing N precedes the
+// event iff (t(N), AX) < (TE, E).  MAXN = crossings that keep the axis inside the macro cell.
+#define GCV_PRED(AX, N, TE, E) ((GCV_TCROSS(AX, N) < (TE)) || (GCV_TCROSS(AX, N) == (TE) && (AX) < (E)))
+#define GCV_COUNT(AX, TE, E, MAXN, OUT)                                              \
+  {                                                                                  \
+    int cnt = 0;                                                                     \
+    const int maxn = (MAXN);                                                         \
+    if (raydir[AX] > 0) {                                                            \
+      const float pos = p.ori[AX] + (TE)*raydir[AX];                                 \
+      cnt = (int)__builtin_floorf(pos) - axis_int[AX];                               \
+      cnt = max(0, min(cnt, maxn));                                                  \
+      while (cnt > 0 && !GCV_PRED(AX, axis_int[AX] + cnt, TE, E)) cnt--;             \
+      while (cnt < maxn && GCV_PRED(AX, axis_int[AX] + cnt + 1, TE, E)) cnt++;       \
+      OUT = axis_int[AX] + cnt;                                                      \
+    } else if (raydir[AX] < 0) {                                                     \
+      const float pos = p.ori[AX] + (TE)*raydir[AX];                                 \
+      cnt = axis_int[AX] - (int)__builtin_ceilf(pos) + 1;                            \
+      cnt = max(0, min(cnt, maxn));                                                  \
+      while (cnt > 0 && !GCV_PRED(AX, axis_int[AX] - cnt + 1, TE, E)) cnt--;         \
+      while (cnt < maxn && GCV_PRED(AX, axis_int[AX] - cnt, TE, E)) cnt++;           \
+      OUT = axis_int[AX] - cnt;                                                      \
+    } else {                                                                         \
+      OUT = axis_int[AX];                                                            \
+    }                                                                                \
   }
 
 template <bool HAS_OCC>
@@ -355,22 +505,74 @@ __global__ __launch_bounds__(64) void k_rvip(int32_t* __restrict__ out_voxel_id,
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     if (raydir[i] > 0)
-      axis_t[i] = ((float)(axis_int[i] + 1) - p.ori[i]) / raydir[i];
+      axis_t[i] = GCV_TCROSS(i, axis_int[i] + 1);
     else if (raydir[i] < 0)
-      axis_t[i] = ((float)axis_int[i] - p.ori[i]) / raydir[i];
+      axis_t[i] = GCV_TCROSS(i, axis_int[i]);
     else
       axis_t[i] = HUGE_VALF;
   }
   const float qnan = __int_as_float(0x7fc00000);
   bool quit = false;
-  bool occ_valid = false, occ_bit = true;
+  long long mc_cached = -1;  // macro cell whose bit is in mc_bit
+  bool mc_bit = true;
   for (int plane = 0; plane < p.max_samples; plane++) {
     float t = qnan, t2 = qnan;
     int32_t blk_id = 0;
     while (!quit) {
       float tnow;
-      bool crossed;
-      if (axis_t[0] <= axis_t[1] && axis_t[0] <= axis_t[2])
+      bool jump = false;
+      if (HAS_OCC && axis_int[0] >= 0 && axis_int[0] < p.dims[0] && axis_int[1] >= 0 && axis_int[1] < p.dims[1] &&
+          axis_int[2] >= 0 && axis_int[2] < p.dims[2]) {
+        const long long lin =
+            mc_linear(axis_int[0] >> MC_SHIFT, axis_int[1] >> MC_SHIFT, axis_int[2] >> MC_SHIFT, p.wb, p.db);
+        if (lin != mc_cached) {
+          mc_cached = lin;
+          mc_bit = (occ[lin >> 5] >> (lin & 31)) & 1u;
+        }
+        jump = !mc_bit;
+      }
+      if (jump) {
+        // leave-the-macro-cell crossing of every axis (boundary coordinate and time)
+        int lo[3], hi[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          lo[a] = (axis_int[a] >> MC_SHIFT) << MC_SHIFT;
+          hi[a] = min(lo[a] + 15, p.dims[a] - 1);
+        }
+        const float T0 = raydir[0] > 0 ? GCV_TCROSS(0, hi[0] + 1) : (raydir[0] < 0 ? GCV_TCROSS(0, lo[0]) : HUGE_VALF);
+        const float T1 = raydir[1] > 0 ? GCV_TCROSS(1, hi[1] + 1) : (raydir[1] < 0 ? GCV_TCROSS(1, lo[1]) : HUGE_VALF);
+        const float T2 = raydir[2] > 0 ? GCV_TCROSS(2, hi[2] + 1) : (raydir[2] < 0 ? GCV_TCROSS(2, lo[2]) : HUGE_VALF);
+        int n0c = axis_int[0], n1c = axis_int[1], n2c = axis_int[2];
+        if (T0 <= T1 && T0 <= T2) {  // same "<=" chain as the step selection
+          tnow = T0;
+          GCV_COUNT(1, tnow, 0, raydir[1] > 0 ? hi[1] - axis_int[1] : axis_int[1] - lo[1], n1c)
+          GCV_COUNT(2, tnow, 0, raydir[2] > 0 ? hi[2] - axis_int[2] : axis_int[2] - lo[2], n2c)
+          n0c = raydir[0] > 0 ? hi[0] + 1 : lo[0] - 1;
+          if (n0c >= p.dims[0] || n0c < 0) quit = true;
+        } else if (T1 <= T2) {
+          tnow = T1;
+          GCV_COUNT(0, tnow, 1, raydir[0] > 0 ? hi[0] - axis_int[0] : axis_int[0] - lo[0], n0c)
+          GCV_COUNT(2, tnow, 1, raydir[2] > 0 ? hi[2] - axis_int[2] : axis_int[2] - lo[2], n2c)
+          n1c = raydir[1] > 0 ? hi[1] + 1 : lo[1] - 1;
+          if (n1c >= p.dims[1] || n1c < 0) quit = true;
+        } else {
+          tnow = T2;
+          GCV_COUNT(0, tnow, 2, raydir[0] > 0 ? hi[0] - axis_int[0] : axis_int[0] - lo[0], n0c)
+          GCV_COUNT(1, tnow, 2, raydir[1] > 0 ? hi[1] - axis_int[1] : axis_int[1] - lo[1], n1c)
+          n2c = raydir[2] > 0 ? hi[2] + 1 : lo[2] - 1;
+          if (n2c >= p.dims[2] || n2c < 0) quit = true;
+        }
+        axis_int[0] = n0c;
+        axis_int[1] = n1c;
+        axis_int[2] = n2c;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          if (raydir[a] > 0)
+            axis_t[a] = GCV_TCROSS(a, axis_int[a] + 1);
+          else if (raydir[a] < 0)
+            axis_t[a] = GCV_TCROSS(a, axis_int[a]);
+        }
+      } else if (axis_t[0] <= axis_t[1] && axis_t[0] <= axis_t[2])
         GCV_STEP(0)
       else if (axis_t[1] <= axis_t[2])
         GCV_STEP(1)
@@ -378,17 +580,16 @@ __global__ __launch_bounds__(64) void k_rvip(int32_t* __restrict__ out_voxel_id,
         GCV_STEP(2)
       if (quit) break;
       if (axis_int[0] < 0 || axis_int[0] >= p.dims[0] || axis_int[1] < 0 || axis_int[1] >= p.dims[1] ||
-          axis_int[2] < 0 || axis_int[2] >= p.dims[2]) {
-        occ_valid = false;
+          axis_int[2] < 0 || axis_int[2] >= p.dims[2])
         continue;  // still outside the grid
-      }
       if (HAS_OCC) {
-        if (!occ_valid || crossed) {
-          const long long lin = ((long long)(axis_int[0] >> 3) * p.wb + (axis_int[1] >> 3)) * p.db + (axis_int[2] >> 3);
-          occ_bit = (occ[lin >> 5] >> (lin & 31)) & 1u;
-          occ_valid = true;
+        const long long lin =
+            mc_linear(axis_int[0] >> MC_SHIFT, axis_int[1] >> MC_SHIFT, axis_int[2] >> MC_SHIFT, p.wb, p.db);
+        if (lin != mc_cached) {
+          mc_cached = lin;
+          mc_bit = (occ[lin >> 5] >> (lin & 31)) & 1u;
         }
-        if (!occ_bit) continue;  // empty brick: the voxel is 0 without reading it
+        if (!mc_bit) continue;  // empty macro cell: the voxel is 0 without reading it
       }
       blk_id = in_voxel[(long long)axis_int[0] * p.strides[0] + (long long)axis_int[1] * p.strides[1] +
                         (long long)axis_int[2] * p.strides[2]];
@@ -512,8 +713,8 @@ int gcv_extrude_emit(int32_t inc_btm, const int16_t* lut, const gcv_seg_ins* m, 
 
 size_t gcv_occupancy_bytes(int32_t h, int32_t w, int32_t d) {
   if (h <= 0 || w <= 0 || d <= 0) return 0;
-  const size_t bricks = (size_t)((h + 7) >> 3) * (size_t)((w + 7) >> 3) * (size_t)((d + 7) >> 3);
-  return 4 * ((bricks + 31) / 32);
+  const size_t cells = (size_t)((h + 15) >> 4) * (size_t)((w + 15) >> 4) * (size_t)((d + 15) >> 4);
+  return 4 * ((cells + 31) / 32);
 }
 
 int gcv_points_to_volume(int64_t n, const int16_t* points, const int32_t* pt_ids, const int16_t* scales, int32_t h,
@@ -536,13 +737,54 @@ int gcv_points_to_volume(int64_t n, const int16_t* points, const int32_t* pt_ids
   return 0;
 }
 
+int gcv_points_bounds(int64_t n, const int16_t* rows, int32_t row_stride, void* scratch24, int32_t min_host[3],
+                      int32_t max_host[3], void* hip_stream) {
+  if (n <= 0 || !rows || !scratch24 || !min_host || !max_host || row_stride < 3)
+    return fail(GCV_ERR_INVALID_ARGUMENT, "gcv_points_bounds: need n > 0, rows, 24-byte scratch, outputs, stride >= 3");
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int init[6] = {32767, 32767, 32767, -32768, -32768, -32768};
+  HIP_TRY(hipMemcpyAsync(scratch24, init, sizeof(init), hipMemcpyHostToDevice, s), "bounds init");
+  const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+  k_rows_bounds<<<blocks, 256, 0, s>>>((long long)n, rows, row_stride, (int*)scratch24);
+  HIP_TRY(hipGetLastError(), "bounds launch");
+  int out[6];
+  HIP_TRY(hipMemcpyAsync(out, scratch24, sizeof(out), hipMemcpyDeviceToHost, s), "bounds read-back");
+  HIP_TRY(hipStreamSynchronize(s), "bounds sync");
+  for (int a = 0; a < 3; a++) {
+    min_host[a] = out[a];
+    max_host[a] = out[3 + a];
+  }
+  return 0;
+}
+
+int gcv_rows_to_volume(int64_t n, const int16_t* rows, const int32_t offset[3], int32_t h, int32_t w, int32_t d,
+                       int32_t* volume, uint32_t* occupancy, void* hip_stream) {
+  if (h <= 0 || w <= 0 || d <= 0) return fail(GCV_ERR_INVALID_ARGUMENT, "volume dimensions must be positive");
+  if (!volume || !offset) return fail(GCV_ERR_INVALID_ARGUMENT, "null volume / offset");
+  if (n < 0 || (n > 0 && !rows)) return fail(GCV_ERR_INVALID_ARGUMENT, "null rows");
+  if (n >= 2147483647ll) return fail(GCV_ERR_INVALID_ARGUMENT, "more than 2^31-2 points (ids are int32, dataset_generator.py:1381)");
+  hipStream_t s = (hipStream_t)hip_stream;
+  {
+    StageTimer t(s, ST_CLEAR);
+    HIP_TRY(hipMemsetAsync(volume, 0, sizeof(int32_t) * (size_t)h * w * d, s), "volume clear");
+    if (occupancy) HIP_TRY(hipMemsetAsync(occupancy, 0, gcv_occupancy_bytes(h, w, d), s), "occupancy clear");
+  }
+  if (n > 0) {
+    StageTimer t(s, ST_SCATTER);
+    k_rows_to_volume<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((long long)n, h, w, d, rows, offset[0], offset[1],
+                                                                offset[2], volume, occupancy);
+    HIP_TRY(hipGetLastError(), "rows_to_volume launch");
+  }
+  return 0;
+}
+
 int gcv_build_occupancy(const int32_t* volume, int32_t h, int32_t w, int32_t d, uint32_t* occupancy, void* hip_stream) {
   if (h <= 0 || w <= 0 || d <= 0) return fail(GCV_ERR_INVALID_ARGUMENT, "volume dimensions must be positive");
   if (!volume || !occupancy) return fail(GCV_ERR_INVALID_ARGUMENT, "null volume / occupancy");
   hipStream_t s = (hipStream_t)hip_stream;
   StageTimer t(s, ST_OCC);
   HIP_TRY(hipMemsetAsync(occupancy, 0, gcv_occupancy_bytes(h, w, d), s), "occupancy clear");
-  const long long threads = (long long)h * w * ((d + 7) >> 3);
+  const long long threads = (long long)h * w * ((d + 15) >> 4);
   k_build_occ<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(volume, h, w, d, occupancy);
   HIP_TRY(hipGetLastError(), "build occupancy launch");
   return 0;
@@ -577,8 +819,8 @@ int gcv_ray_voxel_intersection(const int32_t* volume, const int32_t dims[3], con
   p.c[0] = cam_c[0]; p.c[1] = cam_c[1];
   p.max_samples = max_samples;
   p.img[0] = img_dims[0]; p.img[1] = img_dims[1];
-  p.wb = (dims[1] + 7) >> 3;
-  p.db = (dims[2] + 7) >> 3;
+  p.wb = (dims[1] + 15) >> 4;
+  p.db = (dims[2] + 15) >> 4;
   hipStream_t s = (hipStream_t)hip_stream;
   const dim3 grid((img_dims[1] + 7) / 8, (img_dims[0] + 7) / 8, 1);
   {

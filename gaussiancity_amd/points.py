@@ -126,8 +126,10 @@ def points_to_volume(points, pt_ids, scales, h, w, d, return_occupancy=False):
     return (volume, occ) if return_occupancy else volume
 
 
-# volumes at least this large get an occupancy bitmask built on the fly by the drop-in traversal
-OCCUPANCY_MIN_VOXELS = 1 << 24
+# The drop-in traversal builds a macro-cell bitmask on the fly for contiguous volumes with at least this
+# many voxels (None = never).  Off by default: on the dense city workload the jumps are slower than the
+# plain walk; they pay off on sparse volumes.
+OCCUPANCY_MIN_VOXELS = None
 
 
 def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples,
@@ -155,7 +157,8 @@ def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f
         rd = torch.empty((H, W, 1, 3), dtype=torch.float32, device=dev)
         dims = (C.c_int32 * 3)(*[int(v) for v in in_voxel.shape])
         strides = (C.c_int64 * 3)(*[int(v) for v in in_voxel.stride()])
-        if occupancy is None and in_voxel.is_contiguous() and in_voxel.numel() >= OCCUPANCY_MIN_VOXELS:
+        if (occupancy is None and OCCUPANCY_MIN_VOXELS is not None and in_voxel.is_contiguous()
+                and in_voxel.numel() >= OCCUPANCY_MIN_VOXELS):
             h, w, d = [int(v) for v in in_voxel.shape]
             occupancy = torch.empty(max(1, L.gcv_occupancy_bytes(h, w, d) // 4), dtype=torch.int32, device=dev)
             V.check(L.gcv_build_occupancy(in_voxel.data_ptr(), h, w, d, occupancy.data_ptr(), _stream()),
@@ -168,6 +171,43 @@ def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f
     return [vid, dep, rd]
 
 
+def visible_point_map(rows, cam_rig, cam_pos, cam_quat, null_class_id=0, use_jumps=False):
+    """Device-resident get_visible_points (scripts/dataset_generator.py:1414-1461) for rows as the extruder
+    writes them: int16 CUDA tensor [N,5] = (x, y, z, scale, instance) -> (vp_map int64 [H,W], ins_map [H,W]) on
+    the GPU.  Cube side = column 3 (get_point_scales without special classes); the only host round trip is
+    the bounding box.  Same outputs as get_visible_points on the same points."""
+    if not rows.is_cuda or rows.dtype != torch.int16 or rows.dim() != 2 or rows.shape[1] != 5:
+        raise RuntimeError("rows must be an int16 CUDA tensor [N,5]")
+    dev = rows.device
+    rows = rows.contiguous()
+    n = int(rows.shape[0])
+    L = V.lib()
+    with torch.cuda.device(dev):
+        scratch = torch.empty(6, dtype=torch.int32, device=dev)
+        mn, mx = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+        V.check(L.gcv_points_bounds(n, rows.data_ptr(), 5, scratch.data_ptr(), mn, mx, _stream()), "gcv_points_bounds")
+        w, h, d = mx[0] - mn[0] + 1, mx[1] - mn[1] + 1, mx[2] - mn[2] + 2  # :1376
+        off = (C.c_int32 * 3)(mn[0], mn[1], mn[2] - 1)                     # _get_localized_pt_cords, :1359-1363
+        volume = torch.empty((h, w, d), dtype=torch.int32, device=dev)
+        occ = None
+        if use_jumps:
+            occ = torch.empty(max(1, L.gcv_occupancy_bytes(h, w, d) // 4), dtype=torch.int32, device=dev)
+        V.check(L.gcv_rows_to_volume(n, rows.data_ptr(), off, h, w, d, volume.data_ptr(),
+                                     occ.data_ptr() if occ is not None else None, _stream()), "gcv_rows_to_volume")
+        cp = np.array(cam_pos, dtype=np.float64) - np.array([mn[0], mn[1], mn[2]], dtype=np.int16)  # :1440
+        look = get_camera_look_at(cp, cam_quat)
+        K, sensor = cam_rig["intrinsics"], cam_rig["sensor_size"]
+        vid = ray_voxel_intersection_perspective(
+            volume, torch.tensor([cp[1], cp[0], cp[2]], dtype=torch.float32),
+            torch.tensor([look[1] - cp[1], look[0] - cp[0], look[2] - cp[2]], dtype=torch.float32),
+            torch.tensor([0, 0, 1], dtype=torch.float32), K[0], [K[5], K[2]], [sensor[1], sensor[0]], 1,
+            occupancy=occ)[0]
+        vp_map = vid.view(sensor[1], sensor[0]).long() - 1
+        ins_map = rows[:, 4][vp_map.clamp(min=0)]
+        ins_map[vp_map == -1] = null_class_id
+    return vp_map, ins_map
+
+
 def get_camera_look_at(cam_position, cam_quaternion, step=1000):
     """utils/helpers.py:162-164."""
     mat3 = scipy.spatial.transform.Rotation.from_quat(cam_quaternion).as_matrix()
@@ -177,8 +217,8 @@ def get_camera_look_at(cam_position, cam_quaternion, step=1000):
 def get_visible_points(points, scales, cam_rig, cam_pos, cam_quat, null_class_id=0, reduce_mem=False):
     """scripts/dataset_generator.py:1414-1461: points int16 [N,5] (numpy), per-point scales [N,3] ->
     (vp_map [H,W] int: index of the point each pixel sees or -1, ins_map [H,W]: its instance id).
-    Same steps as upstream -- volume of point ids, perspective traversal, id - 1 -- with the volume's
-    brick occupancy handed to the traversal, and nothing but the two result maps leaving the GPU."""
+    Same steps as upstream -- volume of point ids, perspective traversal, id - 1 -- with nothing but the
+    two result maps leaving the GPU.  `visible_point_map` is the device-resident form."""
     dev = _need_gpu()
     cam_pos = np.array(cam_pos, dtype=np.float64)  # upstream mutates its argument; callers pass a copy (:329)
     pts_np = np.asarray(points)
@@ -201,7 +241,7 @@ def get_visible_points(points, scales, cam_rig, cam_pos, cam_quat, null_class_id
     w, h, d = int(mx[0]) - int(mn[0]) + 1, int(mx[1]) - int(mn[1]) + 1, int(mx[2]) - int(mn[2]) + 2
     assert loc.shape[0] < 2147483648
     pt_ids = torch.arange(1, loc.shape[0] + 1, dtype=torch.int32, device=dev).unsqueeze(1)
-    volume, occ = points_to_volume(loc, pt_ids, scales, h, w, d, return_occupancy=True)
+    volume = points_to_volume(loc, pt_ids, scales, h, w, d)
     # _get_ray_voxel_intersection, :1391-1411
     cam_pos = cam_pos - offsets
     look = get_camera_look_at(cam_pos, cam_quat)
@@ -209,7 +249,7 @@ def get_visible_points(points, scales, cam_rig, cam_pos, cam_quat, null_class_id
     view = torch.tensor([look[1] - cam_pos[1], look[0] - cam_pos[0], look[2] - cam_pos[2]], dtype=torch.float32)
     K, sensor = cam_rig["intrinsics"], cam_rig["sensor_size"]
     vid, _, _ = ray_voxel_intersection_perspective(volume, ori, view, torch.tensor([0, 0, 1], dtype=torch.float32),
-                                                   K[0], [K[5], K[2]], [sensor[1], sensor[0]], 1, occupancy=occ)
+                                                   K[0], [K[5], K[2]], [sensor[1], sensor[0]], 1)
     vp_map = vid.squeeze().long() - 1
     ins_map = instances[vp_map.clamp(min=0)]
     ins_map[vp_map == -1] = null_class_id

@@ -12,8 +12,9 @@
  *                                          (extensions/voxlib/points_to_volume.cu:21-81, bindings.cpp:36)
  *   gcv_ray_voxel_intersection             voxlib.ray_voxel_intersection_perspective
  *                                          (extensions/voxlib/ray_voxel_intersection.cu:54-332, bindings.cpp:33)
- *   gcv_build_occupancy                    (none upstream: 1 bit per 8x8x8 brick, lets the traversal
- *                                           skip the volume reads of empty bricks; results unchanged)
+ *   gcv_build_occupancy                    (none upstream: 1 bit per 16x16x16 macro cell; lets the traversal
+ *                                           jump across empty macro cells, reproducing the reference walk
+ *                                           exactly -- results unchanged)
  *
  * Plain C: device pointers + sizes + a HIP stream, no torch types.  Every function returns 0 on
  * success or a negative gcv_status; gcv_last_error() gives the message (per host thread).
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCV_ABI_VERSION 1
+#define GCV_ABI_VERSION 2
 
 enum gcv_status {
   GCV_OK = 0,
@@ -75,6 +76,17 @@ int gcv_points_to_volume(int64_t n_points, const int16_t* points, const int32_t*
                          int32_t h, int32_t w, int32_t d, int32_t* volume, uint32_t* occupancy, void* hip_stream);
 int gcv_build_occupancy(const int32_t* volume, int32_t h, int32_t w, int32_t d, uint32_t* occupancy, void* hip_stream);
 
+/* Fused form of scripts/dataset_generator.py:1366-1388 (_get_volume) for rows as the extruder writes them:
+ * gcv_points_bounds: per-axis min / max of columns 0..2 of int16 rows with `row_stride` elements (3 or 5);
+ *   waits for the result (upstream: six .item() calls).  scratch24: 24 device bytes.
+ * gcv_rows_to_volume: rows [n][5] = (x, y, z, scale, instance); voxel id = row index + 1, position =
+ *   (x, y, z) - offset in int16 arithmetic, cube of `scale` voxels per side -- what _get_volume + points_to_volume
+ *   produce for scales = get_point_scales(rows[:, 3]) (utils/helpers.py:197-222, no special classes). */
+int gcv_points_bounds(int64_t n_points, const int16_t* rows, int32_t row_stride, void* scratch24, int32_t min_host[3],
+                      int32_t max_host[3], void* hip_stream);
+int gcv_rows_to_volume(int64_t n_points, const int16_t* rows, const int32_t offset[3], int32_t h, int32_t w, int32_t d,
+                       int32_t* volume, uint32_t* occupancy, void* hip_stream);
+
 /* ---- K12: perspective ray / voxel traversal -----------------------------------------------------
  * volume int32 [dims0][dims1][dims2] with element strides (any layout torch can hand over);
  * cam_ori/cam_dir/cam_up are HOST float[3] (upstream copies them to the CPU, :256-266);
@@ -82,8 +94,8 @@ int gcv_build_occupancy(const int32_t* volume, int32_t h, int32_t w, int32_t d, 
  *   out_voxel_id int32 [rows][cols][max_samples]      0 = no hit
  *   out_depth    float [2][rows][cols][max_samples]   entry t and exit t2; quiet NaN 0x7fc00000 = no hit
  *   out_raydirs  float [rows][cols][3]
- * occupancy (nullable) must describe `volume` with contiguous [h][w][d] strides; it only removes
- * memory reads. */
+ * occupancy (nullable) must describe `volume` with contiguous [h][w][d] strides; it removes steps and
+ * memory reads, never changes an output. */
 int gcv_ray_voxel_intersection(const int32_t* volume, const int32_t dims[3], const int64_t strides[3],
                                const uint32_t* occupancy, const float cam_ori_host[3], const float cam_dir_host[3],
                                const float cam_up_host[3], float cam_f, const float cam_c[2],

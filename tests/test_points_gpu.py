@@ -76,11 +76,11 @@ def test_points_to_volume_and_occupancy(cuda_device, po):
         assert vol.dtype == torch.int32 and tuple(vol.shape) == (h, w, d)
         assert np.array_equal(vol.cpu().numpy(), want)
         assert torch.equal(P.points_to_volume(*t, h, w, d), vol)
-        # occupancy: exactly the bricks holding a non-zero voxel... plus bricks a clipped cube touched
-        hb, wb, db = (h + 7) // 8, (w + 7) // 8, (d + 7) // 8
-        pad = np.zeros((hb * 8, wb * 8, db * 8), np.int32)
+        # occupancy: exactly the 16^3 macro cells holding a non-zero voxel
+        hb, wb, db = (h + 15) // 16, (w + 15) // 16, (d + 15) // 16
+        pad = np.zeros((hb * 16, wb * 16, db * 16), np.int32)
         pad[:h, :w, :d] = want
-        brick_any = pad.reshape(hb, 8, wb, 8, db, 8).any(axis=(1, 3, 5)).reshape(-1)
+        brick_any = pad.reshape(hb, 16, wb, 16, db, 16).any(axis=(1, 3, 5)).reshape(-1)
         bits = np.unpackbits(occ.cpu().numpy().view(np.uint8), bitorder="little")[:brick_any.size].astype(bool)
         assert np.array_equal(bits, brick_any)
         # the same bitmask from the dense volume alone
@@ -115,6 +115,48 @@ def test_traversal_bit_exact(cuda_device, po, variant, use_occ):
     assert np.array_equal(got[1].cpu().numpy().view(np.uint32), want[1].view(np.uint32))  # incl. the NaN pattern
     assert np.array_equal(got[2].cpu().numpy().view(np.uint32), want[2].view(np.uint32))
     assert (want[0] != 0).mean() > 0.2
+
+
+def test_traversal_jumps_reproduce_the_reference_walk(cuda_device, po):
+    """The empty-space jump must land exactly where upstream's cell-by-cell walk would: sparse volumes
+    (long jumps), origins on integer coordinates and axis-parallel / diagonal view directions (crossing-time
+    ties between axes), origins inside, outside and far from the volume, several samples per ray."""
+    from gaussiancity_amd import _native_v as V
+    rng = np.random.default_rng(2024)
+    n_checked = 0
+    for trial in range(14):
+        h, w, d = (int(v) for v in rng.integers(17, 150, 3))
+        vol = np.zeros((h, w, d), np.int32)
+        nvox = int(rng.integers(1, 60))
+        vol[rng.integers(0, h, nvox), rng.integers(0, w, nvox), rng.integers(0, d, nvox)] = rng.integers(1, 1 << 30, nvox)
+        if trial % 3 == 0:
+            vol[:, :, 0] = 5  # a floor far below sparse clutter
+        rows, cols = int(rng.integers(9, 70)), int(rng.integers(9, 70))
+        centre = np.array([h, w, d], np.float32) * rng.uniform(0.2, 0.8, 3).astype(np.float32)
+        kind = trial % 5
+        if kind == 0:    # integer origin, view along -z: dx = dy = 0 for the centre ray, ties everywhere
+            ori = np.array([h // 2, w // 2, d + 40], np.float32); dr = np.array([0, 0, -1], np.float32); up = np.array([0, 1, 0], np.float32)
+        elif kind == 1:  # exact diagonal
+            ori = np.array([-8, -8, -8], np.float32); dr = np.array([1, 1, 1], np.float32); up = np.array([0, 0, 1], np.float32)
+        elif kind == 2:  # inside the volume, half-integer origin
+            ori = (np.floor(centre) + 0.5).astype(np.float32); dr = rng.normal(size=3).astype(np.float32); up = np.array([0, 0, 1], np.float32)
+        elif kind == 3:  # far outside, grazing
+            ori = np.array([-3.0 * h, 0.37 * w, 0.9 * d], np.float32); dr = (centre - ori).astype(np.float32); up = np.array([0, 0, 1], np.float32)
+        else:            # outside, looking away over an edge of the grid
+            ori = np.array([h + 5.25, w * 0.5, d * 0.5], np.float32); dr = np.array([-1.0, 0.2, -0.1], np.float32); up = np.array([0, 0, 1], np.float32)
+        f, c, img = float(rng.uniform(0.4, 2.0) * cols), [rows * 0.5, cols * 0.5], [rows, cols]
+        S = 3 if trial % 2 else 1
+        want = po.ray_voxel_intersection_perspective(vol, ori, dr, up, f, c, img, S)
+        v = torch.from_numpy(vol).to(cuda_device)
+        occ = torch.zeros(max(1, V.lib().gcv_occupancy_bytes(h, w, d) // 4), dtype=torch.int32, device=cuda_device)
+        V.check(V.lib().gcv_build_occupancy(v.data_ptr(), h, w, d, occ.data_ptr(), None), "gcv_build_occupancy")
+        cam = [torch.from_numpy(a) for a in (ori, dr, up)]
+        for o in (None, occ):
+            got = P.ray_voxel_intersection_perspective(v, *cam, f, c, img, S, occupancy=o)
+            assert np.array_equal(got[0].cpu().numpy(), want[0]), (trial, o is not None)
+            assert np.array_equal(got[1].cpu().numpy().view(np.uint32), want[1].view(np.uint32)), (trial, o is not None)
+        n_checked += int((want[0] != 0).sum())
+    assert n_checked > 200
 
 
 def test_traversal_strided_volume_and_errors(cuda_device, po):
@@ -174,6 +216,11 @@ def test_get_visible_points_end_to_end(cuda_device, po):
     vp_o, ins_o = _visible_points_oracle(po, points, scales, rig, cam_pos, cam_quat, 0)
     assert vp.shape == (136, 240) and np.array_equal(vp, vp_o) and np.array_equal(ins, ins_o)
     assert (vp >= 0).mean() > 0.5
+    # the device-resident form, plain walk and with empty-space jumps
+    rows = torch.from_numpy(points).to(cuda_device)
+    for jumps in (False, True):
+        vp_d, ins_d = P.visible_point_map(rows, rig, cam_pos.copy(), cam_quat, 0, use_jumps=jumps)
+        assert np.array_equal(vp_d.cpu().numpy(), vp_o) and np.array_equal(ins_d.cpu().numpy(), ins_o)
     # reduce_mem (scale 1/3, :1428-1433) runs and sees the same scene
     vp3, _ = P.get_visible_points(points, scales, rig, cam_pos.copy(), cam_quat, 0, reduce_mem=True)
     assert vp3.shape == vp.shape and (vp3 >= 0).mean() > 0.5
