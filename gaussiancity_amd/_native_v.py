@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_CSRC, "libgcv_hip.so")
 
 EXPORTED_SYMBOLS = (
     "gcv_abi_version", "gcv_last_error", "gcv_extrude_scratch_bytes", "gcv_extrude_count", "gcv_extrude_emit",
-    "gcv_occupancy_bytes", "gcv_points_to_volume", "gcv_build_occupancy", "gcv_points_bounds", "gcv_rows_to_volume",
+    "gcv_occupancy_bytes", "gcv_points_to_volume", "gcv_build_occupancy", "gcv_bounds_scratch_bytes", "gcv_points_bounds", "gcv_rows_to_volume",
     "gcv_ray_voxel_intersection",
     "gcv_set_option", "gcv_get_stage_ms",
 )
@@ -49,6 +49,8 @@ def lib():
     L.gcv_occupancy_bytes.argtypes = [i32, i32, i32]
     L.gcv_points_to_volume.restype = C.c_int
     L.gcv_points_to_volume.argtypes = [i64, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.gcv_bounds_scratch_bytes.restype = sz
+    L.gcv_bounds_scratch_bytes.argtypes = []
     L.gcv_points_bounds.restype = C.c_int
     L.gcv_points_bounds.argtypes = [i64, vp, i32, vp, C.POINTER(i32), C.POINTER(i32), vp]
     L.gcv_rows_to_volume.restype = C.c_int

@@ -312,8 +312,12 @@ __global__ __launch_bounds__(256) void k_points_to_volume(long long n, int h, in
 // round trips): bounds of the extruded rows, then rows [n][5] = (x, y, z, scale, instance) straight
 // into the volume with the localisation offsets applied in flight, id = row index + 1 and a cube of
 // `scale` voxels per side (utils/helpers.get_point_scales with no special classes).
+// Two stages, no atomics: six hot addresses would serialise every wave's result at the memory side
+// (measured 1.1 ms for 17 M rows with per-wave atomicMin/Max; 0.05 ms like this).
+constexpr int BOUNDS_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void k_rows_bounds(long long n, const int16_t* __restrict__ rows, int stride,
-                                                     int* __restrict__ mnmx) {
+                                                     int* __restrict__ partial) {
+  __shared__ int red[4][6];
   int mn[3] = {32767, 32767, 32767}, mx[3] = {-32768, -32768, -32768};
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
 #pragma unroll
@@ -334,9 +338,31 @@ __global__ __launch_bounds__(256) void k_rows_bounds(long long n, const int16_t*
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-      atomicMin(&mnmx[a], mn[a]);
-      atomicMax(&mnmx[3 + a], mx[a]);
+      red[threadIdx.x >> 6][a] = mn[a];
+      red[threadIdx.x >> 6][3 + a] = mx[a];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    int v = red[0][a];
+    for (int w = 1; w < 4; w++) v = a < 3 ? min(v, red[w][a]) : max(v, red[w][a]);
+    partial[6 * blockIdx.x + a] = v;
+  }
+}
+// partial[6*b + a] for b < nb  ->  partial[a]  (one block)
+__global__ __launch_bounds__(256) void k_bounds_final(int* __restrict__ partial, int nb) {
+  __shared__ int red[256][6];
+  int v[6] = {32767, 32767, 32767, -32768, -32768, -32768};
+  for (int b = threadIdx.x; b < nb; b += 256)
+    for (int a = 0; a < 6; a++) v[a] = a < 3 ? min(v[a], partial[6 * b + a]) : max(v[a], partial[6 * b + a]);
+  for (int a = 0; a < 6; a++) red[threadIdx.x][a] = v[a];
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    int r = red[0][a];
+    for (int t = 1; t < 256; t++) r = a < 3 ? min(r, red[t][a]) : max(r, red[t][a]);
+    partial[a] = r;
   }
 }
 
@@ -737,18 +763,19 @@ int gcv_points_to_volume(int64_t n, const int16_t* points, const int32_t* pt_ids
   return 0;
 }
 
-int gcv_points_bounds(int64_t n, const int16_t* rows, int32_t row_stride, void* scratch24, int32_t min_host[3],
+size_t gcv_bounds_scratch_bytes(void) { return sizeof(int) * 6 * BOUNDS_BLOCKS; }
+
+int gcv_points_bounds(int64_t n, const int16_t* rows, int32_t row_stride, void* scratch, int32_t min_host[3],
                       int32_t max_host[3], void* hip_stream) {
-  if (n <= 0 || !rows || !scratch24 || !min_host || !max_host || row_stride < 3)
-    return fail(GCV_ERR_INVALID_ARGUMENT, "gcv_points_bounds: need n > 0, rows, 24-byte scratch, outputs, stride >= 3");
+  if (n <= 0 || !rows || !scratch || !min_host || !max_host || row_stride < 3)
+    return fail(GCV_ERR_INVALID_ARGUMENT, "gcv_points_bounds: need n > 0, rows, scratch, outputs, stride >= 3");
   hipStream_t s = (hipStream_t)hip_stream;
-  const int init[6] = {32767, 32767, 32767, -32768, -32768, -32768};
-  HIP_TRY(hipMemcpyAsync(scratch24, init, sizeof(init), hipMemcpyHostToDevice, s), "bounds init");
-  const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
-  k_rows_bounds<<<blocks, 256, 0, s>>>((long long)n, rows, row_stride, (int*)scratch24);
+  const int blocks = (int)std::min<long long>((n + 255) / 256, BOUNDS_BLOCKS);
+  k_rows_bounds<<<blocks, 256, 0, s>>>((long long)n, rows, row_stride, (int*)scratch);
+  k_bounds_final<<<1, 256, 0, s>>>((int*)scratch, blocks);
   HIP_TRY(hipGetLastError(), "bounds launch");
   int out[6];
-  HIP_TRY(hipMemcpyAsync(out, scratch24, sizeof(out), hipMemcpyDeviceToHost, s), "bounds read-back");
+  HIP_TRY(hipMemcpyAsync(out, scratch, sizeof(out), hipMemcpyDeviceToHost, s), "bounds read-back");
   HIP_TRY(hipStreamSynchronize(s), "bounds sync");
   for (int a = 0; a < 3; a++) {
     min_host[a] = out[a];

@@ -183,7 +183,7 @@ def visible_point_map(rows, cam_rig, cam_pos, cam_quat, null_class_id=0, use_jum
     n = int(rows.shape[0])
     L = V.lib()
     with torch.cuda.device(dev):
-        scratch = torch.empty(6, dtype=torch.int32, device=dev)
+        scratch = torch.empty(L.gcv_bounds_scratch_bytes() // 4, dtype=torch.int32, device=dev)
         mn, mx = (C.c_int32 * 3)(), (C.c_int32 * 3)()
         V.check(L.gcv_points_bounds(n, rows.data_ptr(), 5, scratch.data_ptr(), mn, mx, _stream()), "gcv_points_bounds")
         w, h, d = mx[0] - mn[0] + 1, mx[1] - mn[1] + 1, mx[2] - mn[2] + 2  # :1376

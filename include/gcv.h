@@ -78,11 +78,12 @@ int gcv_build_occupancy(const int32_t* volume, int32_t h, int32_t w, int32_t d, 
 
 /* Fused form of scripts/dataset_generator.py:1366-1388 (_get_volume) for rows as the extruder writes them:
  * gcv_points_bounds: per-axis min / max of columns 0..2 of int16 rows with `row_stride` elements (3 or 5);
- *   waits for the result (upstream: six .item() calls).  scratch24: 24 device bytes.
+ *   waits for the result (upstream: six .item() calls).  scratch: gcv_bounds_scratch_bytes() device bytes.
  * gcv_rows_to_volume: rows [n][5] = (x, y, z, scale, instance); voxel id = row index + 1, position =
  *   (x, y, z) - offset in int16 arithmetic, cube of `scale` voxels per side -- what _get_volume + points_to_volume
  *   produce for scales = get_point_scales(rows[:, 3]) (utils/helpers.py:197-222, no special classes). */
-int gcv_points_bounds(int64_t n_points, const int16_t* rows, int32_t row_stride, void* scratch24, int32_t min_host[3],
+size_t gcv_bounds_scratch_bytes(void);
+int gcv_points_bounds(int64_t n_points, const int16_t* rows, int32_t row_stride, void* scratch, int32_t min_host[3],
                       int32_t max_host[3], void* hip_stream);
 int gcv_rows_to_volume(int64_t n_points, const int16_t* rows, const int32_t offset[3], int32_t h, int32_t w, int32_t d,
                        int32_t* volume, uint32_t* occupancy, void* hip_stream);
