@@ -98,12 +98,14 @@ class TrainStepHarness:
     (plain torch modules); `n_param` fp32 values stand in for their gradients so the RCCL
     message sizes match the real training step (BG generator: 69,809,101 parameters)."""
 
-    def __init__(self, rasterizer_wrapper, n_param=69_809_101, crop=None, device=None, group=None):
+    def __init__(self, rasterizer_wrapper, n_param=69_809_101, crop=None, device=None, group=None, lr=None):
         self.rw = rasterizer_wrapper
         self.crop = crop
         self.group = group
         self.device = device if device is not None else rasterizer_wrapper.device
         self.param_grad = torch.zeros(n_param, dtype=torch.float32, device=self.device)
+        self.lr = lr          # with a learning rate, step() also applies Adam to `points`
+        self._opt = None      # (the reference steps its generator's optimizer, core/train.py:293-295)
 
     def step(self, points, cam_pos, cam_quat, target=None):
         """points: [N,14] leaf tensor requiring grad.  Returns (loss, image)."""
@@ -116,4 +118,73 @@ class TrainStepHarness:
         # stand-in for "the generator's gradients depend on d(loss)/d(points)"
         self.param_grad.fill_(points.grad.abs().mean())
         n_buckets = allreduce_gradients([self.param_grad], group=self.group)
+        if self.lr is not None:
+            # data-parallel update: every rank applies the rank-averaged gradient, so replicas stay equal
+            allreduce_gradients([points.grad], group=self.group)
+            if self._opt is None or self._opt.param_groups[0]["params"][0] is not points:
+                self._opt = torch.optim.Adam([points], lr=self.lr, betas=(0.0, 0.999), eps=1e-7)  # cfg.TRAIN.GAUSSIAN
+            self._opt.step()
         return loss.detach(), img.detach(), n_buckets
+
+
+class InferenceLoop:
+    """Shape of the reference's render loop (scripts/inference.py:655-667) around the rasterizer only: for
+    every pose, points [N,14] -> image -> uint8 HWC frame on the host.  The reference does this on the
+    legacy default stream with a blocking `tensor_to_image(...).cpu()` per frame; here frames alternate
+    over two side streams and land in two pinned host buffers, so frame f's device->host copy and the
+    host-side consumer overlap frame f+1's render.  `render_fn(points, cam_pos, cam_quat) -> [3,H,W]`
+    is the rasterizer wrapper (or any stand-in on CPU, which degrades to a plain loop)."""
+
+    def __init__(self, render_fn, device=None):
+        self.render_fn = render_fn
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.cuda = self.device.type == "cuda"
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(2)] if self.cuda else [None, None]
+        self._pinned = [None, None]
+        self._events = [None, None]
+
+    @staticmethod
+    def to_uint8_hwc(img):
+        """utils/helpers.tensor_to_image(img, "RGB") * 255 -> uint8 (scripts/inference.py:665): [3,H,W] in
+        [-1,1] -> [H,W,3] in [0,255]."""
+        return ((img.clamp(-1, 1) / 2 + 0.5) * 255).permute(1, 2, 0).to(torch.uint8)
+
+    def run(self, points, poses, consume=None):
+        """Renders every (cam_pos, cam_quat) of `poses`; returns the list of uint8 [H,W,3] numpy frames, or
+        calls `consume(index, frame)` per frame (the frame buffer is reused two frames later)."""
+        out = []
+        pending = [None, None]  # (index, event) per slot
+
+        def drain(slot):
+            if pending[slot] is None:
+                return
+            idx, ev = pending[slot]
+            if ev is not None:
+                ev.synchronize()
+            frame = self._pinned[slot].numpy()
+            if consume is not None:
+                consume(idx, frame)
+            else:
+                out.append((idx, frame.copy()))
+            pending[slot] = None
+
+        for i, (cam_pos, cam_quat) in enumerate(poses):
+            slot = i & 1
+            drain(slot)  # the buffer this frame will land in must have been consumed
+            if self.cuda:
+                with torch.cuda.stream(self.streams[slot]):
+                    frame = self.to_uint8_hwc(self.render_fn(points, cam_pos, cam_quat))
+                    if self._pinned[slot] is None or self._pinned[slot].shape != frame.shape:
+                        self._pinned[slot] = torch.empty(frame.shape, dtype=torch.uint8, pin_memory=True)
+                    self._pinned[slot].copy_(frame, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.streams[slot])
+                pending[slot] = (i, ev)
+            else:
+                frame = self.to_uint8_hwc(self.render_fn(points, cam_pos, cam_quat))
+                self._pinned[slot] = frame.contiguous()
+                pending[slot] = (i, None)
+        n = len(poses)
+        for slot in ((n & 1), 1 - (n & 1)):  # oldest first
+            drain(slot)
+        return [f for _, f in sorted(out, key=lambda t: t[0])] if consume is None else None

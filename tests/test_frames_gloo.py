@@ -70,3 +70,36 @@ def test_single_process_paths():
     out = frames.render_sharded(_fake_frame, 3, rank=0, world=1)
     assert sorted(out) == [0, 1, 2]
     assert frames.allreduce_gradients([torch.ones(3)]) == 0
+
+
+class _FakeWrapper:
+    """Differentiable stand-in for GaussianRasterizerWrapper on CPU: image = f(points, pose)."""
+    device = torch.device("cpu")
+
+    def __call__(self, points, cam_pos, cam_quat):
+        base = points[:, :3].mean() + points[:, 11:14].mean(dim=0).view(3, 1, 1)
+        ramp = torch.linspace(0, 1, 12).view(1, 3, 4) * float(np.sum(cam_pos))
+        return (base + ramp).expand(3, 3, 4)
+
+
+def test_train_step_harness_optimizer_and_inference_loop():
+    pts = torch.randn(50, 14, requires_grad=True)
+    before = pts.detach().clone()
+    h = frames.TrainStepHarness(_FakeWrapper(), n_param=1000, crop=(0, 0, 4, 3), lr=1e-2)
+    target = torch.zeros(3, 3, 4)
+    losses = []
+    for i in range(5):
+        pts.grad = None
+        loss, img, _ = h.step(pts, np.array([1.0, 2.0, 3.0]), np.array([0, 0, 0, 1.0]), target)
+        losses.append(float(loss))
+    assert not torch.equal(pts.detach(), before) and losses[-1] < losses[0]      # Adam moved the points downhill
+    assert float(h.param_grad[0]) == float(h.param_grad[-1]) != 0.0
+    # inference loop: order, conversion and buffer reuse
+    poses = [(np.array([i, 0.0, 0.0]), np.array([0, 0, 0, 1.0])) for i in range(5)]
+    loop = frames.InferenceLoop(lambda p, cp, cq: torch.full((3, 2, 2), float(cp[0]) / 2 - 1.0))
+    got = loop.run(None, poses)
+    assert len(got) == 5 and got[0].shape == (2, 2, 3) and got[0].dtype == np.uint8
+    assert [int(f[0, 0, 0]) for f in got] == [0, 63, 127, 191, 255]
+    seen = []
+    loop.run(None, poses, consume=lambda i, f: seen.append((i, int(f[0, 0, 0]))))
+    assert seen == [(0, 0), (1, 63), (2, 127), (3, 191), (4, 255)]

@@ -356,3 +356,21 @@ def test_full_size_properties(cuda_device):
         assert float(np.abs(g2[n] - ref).max()) <= tol, n
     vis = (radii > 0).cpu().numpy()
     assert not np.any(g1["dL_dmean3D"][~vis]) and not np.any(g1["dL_dsh"][~vis])
+
+
+def test_inference_loop_matches_sequential_rendering(cuda_device):
+    """frames.InferenceLoop (two streams, pinned double buffer) returns exactly the frames a plain
+    sequential loop over the wrapper produces (scripts/inference.py:655-667)."""
+    from gaussiancity_amd import frames, synth
+    from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper
+    W, H = 160, 96
+    wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), device=cuda_device)
+    sc = scenes.blob_scene(3000, 91, 0)
+    rot_xyzw = sc["rotations"][:, [1, 2, 3, 0]]
+    pts = torch.from_numpy(np.concatenate([sc["means3D"], sc["opacities"], sc["scales"], rot_xyzw,
+                                           sc["colors_precomp"]], axis=1).astype(np.float32)).to(cuda_device)
+    poses = synth.orbit_poses(7, 60.0, 50.0)
+    want = [frames.InferenceLoop.to_uint8_hwc(wr(pts, p, q)).cpu().numpy() for p, q in poses]
+    got = frames.InferenceLoop(wr, device=cuda_device).run(pts, poses)
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert any(f.any() for f in got)
