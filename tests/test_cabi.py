@@ -120,3 +120,21 @@ def test_gcv_library_exports_every_declared_symbol():
     assert lib.gcv_points_to_volume(0, None, None, None, 0, 4, 4, None, None, None) < 0
     assert lib.gcv_ray_voxel_intersection(None, None, None, None, None, None, None, 1.0, None, None, 1, None, None,
                                           None, None) < 0
+
+
+def test_gce_library_exports_every_declared_symbol():
+    """libgce_hip.so (hash-grid encoder, include/gce.h)."""
+    from gaussiancity_amd import _native_e as E
+    lib = E.lib()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gce.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(gce_[a-z_]+)\s*\(", src)))
+    assert set(declared) == set(E.EXPORTED_SYMBOLS), (declared, E.EXPORTED_SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", E.LIB_PATH]).decode()
+    assert set(declared) <= set(re.findall(r" T (gce_[a-z_]+)", out))
+    assert lib.gce_abi_version() == E.ABI_VERSION == int(re.search(r"#define GCE_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "gce.h")).read()).group(1))
+    sc = (C.c_float * 4)()
+    assert lib.gce_level_scales(4, 1.0, 16, sc) == 0 and list(sc) == [15.0, 31.0, 63.0, 127.0]
+    assert lib.gce_forward(None, None, None, None, 8, 3, 3, 2, 1.0, 4, 0, None, 0, 0, None) < 0   # C = 3
+    assert b"C must be" in lib.gce_last_error()
+    assert lib.gce_forward(None, None, None, None, 8, 3, 2, 2, 1.0, 4, 0, None, 0, 0, None) < 0   # null tensors
+    assert lib.gce_backward(None, None, None, None, None, 8, 9, 2, 2, 1.0, 4, 0, None, None, 0, 0, None) < 0
