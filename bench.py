@@ -70,10 +70,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--fast-exp", action="store_true", help="non-parity v_exp_f32 variant (A/B only)")
-    ap.add_argument("--path", default="raster", choices=["raster", "visibility"],
+    ap.add_argument("--path", default="raster", choices=["raster", "visibility", "grid-encoder"],
                     help="raster (default): the rasterizer hot path; visibility: SURVEY 8 row f2, BEV maps -> points -> "
                          "volume -> per-pixel first hit (one step = one camera pose)")
     ap.add_argument("--layout-size", type=int, default=2048, help="--path visibility: BEV map edge in pixels")
+    ap.add_argument("--encoder-points", type=int, default=16384,
+                    help="--path grid-encoder: points per step (16384 = TRAIN_MAX_POINTS, config.py:34)")
     ap.add_argument("--jumps", type=int, default=0,
                     help="--path visibility: empty-space jumps in the traversal (A/B knob; same outputs)")
     ap.add_argument("--train-step", action="store_true",
@@ -125,6 +127,8 @@ def main():
         torch.cuda.synchronize()
         return 10 * 2 * a.numel() * 4 / 1e9 / (time.perf_counter() - tc)
 
+    if args.path == "grid-encoder":
+        return grid_encoder_bench(args, torch, dist, dev, world, rank, barrier, copy_ceiling)
     if args.path == "visibility":
         return visibility_bench(args, torch, dist, synth, dev, world, rank, barrier, copy_ceiling)
     if args.train_step:
@@ -353,6 +357,97 @@ def main():
             out["secondary"] = {"metric": "fwd+bwd ms/frame @ %d Gaussians, %dx%d, SH3" % (cfg2["P"], W2, H2),
                                 "value": round(ms2, 4), "unit": "ms/frame", "higher_is_better": False,
                                 "stages_ms": {k: round(v, 4) for k, v in st2.items()}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def grid_encoder_bench(args, torch, dist, dev, world, rank, barrier, copy_ceiling):
+    """Row f3: GaussianCity's positional encoder (models/generator.py:37-42): D=5 inputs, 16 levels x 8 channels,
+    2^19 rows per level (268 MB fp32 table).  One step = forward + backward (table gradient + input gradient)
+    over B points -- what one G-step does (core/train.py:263-295); every rank encodes its own B points against
+    its replica of the table (data parallel; the table gradient is part of the DDP all-reduce, not timed here)."""
+    import math
+    from gaussiancity_amd import _native_e as E
+    from gaussiancity_amd.grid_encoder import GridEncoder
+    B = args.encoder_points
+    enc = GridEncoder(in_channels=5, n_levels=16, lvl_channels=8, desired_resolution=2048).to(dev)
+    torch.manual_seed(1234 + rank)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    x = (torch.rand(B, 5, device=dev) * 2 - 1).requires_grad_(True)
+    g = torch.randn(B, 128, device=dev)
+
+    def step():
+        enc.embeddings.grad = None
+        x.grad = None
+        y = enc(x)
+        y.backward(g)
+        return y
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    E.set_option("timing", 1)
+    E.stage_ms()
+    for _ in range(min(args.steps, 20)):
+        y = step()
+    torch.cuda.synchronize()
+    st = E.stage_ms()
+    E.set_option("timing", 0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        D, L, Cc = 5, 16, 8
+        # algorithmic bytes per point and level: forward gathers 2^D rows of 4*C B, reads D*4 B of input, writes
+        # 4*C B and (with input gradients) D*C*4 B of dy_dx; backward adds 2^D rows (read-modify-write = 2 x 4*C B)
+        ab = {"forward": B * L * ((1 << D) * 4 * Cc + 4 * D + 4 * Cc + 4 * D * Cc),
+              "backward_embeddings": B * L * ((1 << D) * 8 * Cc + 4 * D + 4 * Cc),
+              "backward_inputs": B * L * (4 * D * Cc + 4 * Cc) + 4 * B * D}
+        stages = {k: {"ms": round(st[k], 4), "alg_MB": round(ab[k] / 1e6, 2),
+                      "alg_GBps": round(ab[k] / 1e9 / (st[k] / 1e3), 1) if st[k] > 0 else None} for k in ab}
+        dom = max(ab, key=lambda k: st[k])
+        ceiling = copy_ceiling()
+        ach = ab[dom] / 1e9 / (st[dom] / 1e3)
+        out = {"metric": "hash-grid encoder points/sec (forward + backward) @ D=5, 16 levels x 8 ch, 2^19 rows/level",
+               "value": round(B * args.steps * world / elapsed, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (uniform points, uniform table)",
+               "config": {"workload": "E1: %d points x 16 levels, 268 MB table, forward + table gradient + input gradient" % B,
+                          "parallelism": "data parallel: every rank encodes its own points against its replica of the table"},
+               "stages_ms": stages,
+               "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "copy_ceiling_GBps": round(ceiling, 1),
+                            "frac_of_copy_ceiling": round(ach / ceiling, 4), "launch_ms": round(st[dom], 4),
+                            "alg_bytes_per_launch": int(ab[dom])}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import grid_oracle as GO
+            GO.lib()
+            xn = ((x.detach() + 1) / 2).cpu().numpy()
+            emb = enc.embeddings.detach().cpu().numpy()
+            off = enc.offsets.cpu().numpy()
+            S, H = math.log2(enc.per_level_scale), enc.base_resolution
+            grad_lbc = np.ascontiguousarray(g.view(B, 16, 8).permute(1, 0, 2).cpu().numpy())
+            GO.forward(xn[:256], emb, off, S, H, True)  # warm-up (OpenMP pool, page-in)
+            n_rep, tc = 0, time.perf_counter()
+            while time.perf_counter() - tc < 10.0:
+                out_o, dd_o = GO.forward(xn, emb, off, S, H, True)
+                GO.backward(grad_lbc, xn, emb.shape, off, S, H, dd_o)
+                n_rep += 1
+            cpu_s = time.perf_counter() - tc
+            same = bool(np.array_equal(torch.from_numpy(out_o).permute(1, 0, 2).reshape(B, 128).numpy().view(np.uint32),
+                                       y.detach().cpu().numpy().view(np.uint32)))
+            out["cpu_baseline"] = {"value": round(B * n_rep / cpu_s, 1), "unit": "points/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "%d forward+backward passes over the same %d points in %.1f s (oracle/, OpenMP)"
+                                             % (n_rep, B, cpu_s), "gpu_encoding_bit_exact_vs_cpu": same}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
