@@ -12,7 +12,6 @@ library.  float32 only (upstream also dispatches half/double; GaussianCity keeps
 import ctypes as C
 import math
 
-import numpy as np
 import torch
 
 from . import _native_e as E
@@ -61,94 +60,106 @@ def ext_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C_, L
                                      int(gridtype), int(bool(align_corners)), _stream()), "gce_backward")
 
 
+class _Geometry:
+    """Static description of one encode call; what the native side needs besides the tensors."""
+    __slots__ = ("n_points", "in_dim", "channels", "levels", "log2_scale", "base", "grid_kind", "corners_aligned",
+                 "want_input_grad")
+
+    def __init__(self, points, table, level_rows, per_level_scale, base_resolution, want_input_grad, grid_kind,
+                 corners_aligned):
+        self.n_points, self.in_dim = points.shape
+        self.channels = table.shape[1]
+        self.levels = level_rows.shape[0] - 1
+        self.log2_scale = math.log2(per_level_scale)  # the kernels take log2 of the growth factor
+        self.base = base_resolution
+        self.grid_kind = grid_kind
+        self.corners_aligned = corners_aligned
+        self.want_input_grad = bool(want_input_grad)
+
+    def native(self):
+        return (self.n_points, self.in_dim, self.channels, self.levels, self.log2_scale, self.base)
+
+
 class GridEncoderFunction(torch.autograd.Function):
-    """inputs [B,D] in [0,1], embeddings [rows,C], offsets int32 [L+1] -> [B, L*C]."""
+    """Autograd node of the encoder.  Positional signature, saved state and returned gradients follow
+    extensions/grid_encoder/__init__.py:18-124: (inputs [B,D] in [0,1], embeddings [rows,C], offsets int32 [L+1],
+    per_level_scale, base_resolution, calc_grad_inputs, gridtype, align_corners) -> [B, L*C]."""
 
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
                 align_corners=False):
-        inputs = inputs.contiguous()
-        B, D = inputs.shape
-        L = offsets.shape[0] - 1
-        Cc = embeddings.shape[1]
-        S = math.log2(per_level_scale)  # the native side works with log2 of the scale (__init__.py:43-44)
-        H = base_resolution
-        outputs = torch.empty(L, B, Cc, device=inputs.device, dtype=embeddings.dtype)  # level-major, permuted below
-        if calc_grad_inputs:
-            dy_dx = torch.empty(B, L * D * Cc, device=inputs.device, dtype=embeddings.dtype)
-        else:
-            dy_dx = torch.empty(1, device=inputs.device, dtype=embeddings.dtype)
-        ext_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H, calc_grad_inputs, dy_dx, gridtype,
+        points = inputs.contiguous()
+        geo = _Geometry(points, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs, gridtype,
+                        align_corners)
+        B, D, Cc, L, S, H = geo.native()
+        # the native kernels write level-major [L, B, C]; callers see point-major [B, L*C]
+        level_major = embeddings.new_empty((L, B, Cc))
+        jacobian = embeddings.new_empty((B, L * D * Cc) if geo.want_input_grad else (1,))
+        ext_forward(points, embeddings, offsets, level_major, B, D, Cc, L, S, H, calc_grad_inputs, jacobian, gridtype,
                     align_corners)
-        outputs = outputs.permute(1, 0, 2).reshape(B, L * Cc)
-        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.save_for_backward(points, embeddings, offsets, jacobian)
         ctx.dims = [B, D, Cc, L, S, H, gridtype]
         ctx.calc_grad_inputs = calc_grad_inputs
         ctx.align_corners = align_corners
-        return outputs
+        return level_major.transpose(0, 1).reshape(B, L * Cc)
 
     @staticmethod
     def backward(ctx, grad):
-        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        points, table, level_rows, jacobian = ctx.saved_tensors
         B, D, Cc, L, S, H, gridtype = ctx.dims
-        grad = grad.view(B, L, Cc).permute(1, 0, 2).contiguous()  # [B, L*C] -> [L, B, C]
-        grad_embeddings = torch.zeros_like(embeddings)
-        if ctx.calc_grad_inputs:
-            grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype)
-        else:
-            grad_inputs = torch.zeros(1, device=inputs.device, dtype=embeddings.dtype)
-        ext_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, Cc, L, S, H, ctx.calc_grad_inputs, dy_dx,
-                     grad_inputs, gridtype, ctx.align_corners)
-        if ctx.calc_grad_inputs:
-            return grad_inputs.to(inputs.dtype), grad_embeddings, None, None, None, None, None, None
-        return None, grad_embeddings, None, None, None, None, None, None
+        wants_inputs = ctx.calc_grad_inputs
+        upstream = grad.reshape(B, L, Cc).transpose(0, 1).contiguous()      # back to level-major
+        d_table = torch.zeros_like(table)                                   # the kernel accumulates with atomics
+        d_points = table.new_zeros(points.shape if wants_inputs else (1,))
+        ext_backward(upstream, points, table, level_rows, d_table, B, D, Cc, L, S, H, wants_inputs, jacobian, d_points,
+                     gridtype, ctx.align_corners)
+        d_in = d_points.to(points.dtype) if wants_inputs else None
+        return d_in, d_table, None, None, None, None, None, None
 
 
 def level_offsets(in_channels, n_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners):
-    """Row offsets of the levels (__init__.py:158-172).  NOTE: like upstream, the resolution of level i uses the
-    constructor's `per_level_scale` ARGUMENT (default 2), not the value derived from desired_resolution that the
-    kernels use (self.per_level_scale) -- kept bug-for-bug, the table size depends on it."""
-    max_params = 2 ** log2_hashmap_size
-    offsets, offset = [], 0
-    for i in range(n_levels):
-        resolution = int(math.ceil(base_resolution * per_level_scale ** i))
-        params = min(max_params, (resolution if align_corners else resolution + 1) ** in_channels)
-        params = int(math.ceil(params / 8) * 8)
-        offsets.append(offset)
-        offset += params
-    offsets.append(offset)
-    return offsets
+    """First table row of every level, plus the total (extensions/grid_encoder/__init__.py:158-172): a level holds
+    min(2^log2_hashmap_size, side^in_channels) rows rounded up to a multiple of 8, side = resolution (+1 unless
+    align_corners).  NOTE: like upstream, the resolution of level i grows with the constructor's `per_level_scale`
+    ARGUMENT (default 2), not with the value derived from desired_resolution that the kernels use
+    (self.per_level_scale) -- kept bug-for-bug, the table size depends on it."""
+    cap = 1 << log2_hashmap_size
+    starts = [0]
+    for lvl in range(n_levels):
+        side = int(math.ceil(base_resolution * per_level_scale ** lvl)) + (0 if align_corners else 1)
+        rows = min(cap, side ** in_channels)
+        starts.append(starts[-1] + 8 * int(math.ceil(rows / 8)))
+    return starts
 
 
 class GridEncoder(torch.nn.Module):
+    """extensions.grid_encoder.GridEncoder (extensions/grid_encoder/__init__.py:127-193): same constructor
+    arguments, attributes, `offsets` buffer, `embeddings` parameter and U(-1e-4, 1e-4) initialisation."""
+
     def __init__(self, in_channels, n_levels, lvl_channels, desired_resolution, per_level_scale=2, base_resolution=16,
                  log2_hashmap_size=19, gridtype="hash", align_corners=False):
         super().__init__()
-        self.in_channels = in_channels
-        self.n_levels = n_levels
-        self.lvl_channels = lvl_channels
-        self.per_level_scale = 2 ** (math.log2(desired_resolution / base_resolution) / (n_levels - 1))
-        self.log2_hashmap_size = log2_hashmap_size
-        self.base_resolution = base_resolution
-        self.output_dim = n_levels * lvl_channels
-        self.gridtype = gridtype
-        self.gridtype_id = 0 if gridtype == "hash" else 1
+        growth = (desired_resolution / base_resolution) ** (1.0 / (n_levels - 1)) if n_levels > 1 else 1.0
+        self.in_channels, self.n_levels, self.lvl_channels = in_channels, n_levels, lvl_channels
+        self.base_resolution, self.log2_hashmap_size = base_resolution, log2_hashmap_size
+        self.per_level_scale = 2 ** (math.log2(desired_resolution / base_resolution) / (n_levels - 1)) if n_levels > 1 else growth
+        self.gridtype, self.gridtype_id = gridtype, (0 if gridtype == "hash" else 1)
         self.align_corners = align_corners
-        self.max_params = 2 ** log2_hashmap_size
-        offsets = level_offsets(in_channels, n_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners)
-        self.register_buffer("offsets", torch.from_numpy(np.array(offsets, dtype=np.int32)))
+        self.output_dim = n_levels * lvl_channels
+        self.max_params = 1 << log2_hashmap_size
+        starts = level_offsets(in_channels, n_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners)
+        self.register_buffer("offsets", torch.tensor(starts, dtype=torch.int32))
         self.n_params = self.offsets[-1] * lvl_channels
-        self.embeddings = torch.nn.Parameter(torch.empty(offsets[-1], lvl_channels))
+        self.embeddings = torch.nn.Parameter(torch.empty(starts[-1], lvl_channels))
         self._init_weights()
 
     def _init_weights(self):
-        self.embeddings.data.uniform_(-1e-4, 1e-4)
+        torch.nn.init.uniform_(self.embeddings, -1e-4, 1e-4)
 
     def forward(self, inputs, bound=1):
         """inputs [..., in_channels] in [-bound, bound] -> [..., n_levels * lvl_channels]."""
-        inputs = (inputs + bound) / (2 * bound)
-        prefix = list(inputs.shape[:-1])
-        inputs = inputs.view(-1, self.in_channels)
-        out = GridEncoderFunction.apply(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
-                                        inputs.requires_grad, self.gridtype_id, self.align_corners)
-        return out.view(prefix + [self.output_dim])
+        lead = inputs.shape[:-1]
+        unit = ((inputs + bound) / (2 * bound)).view(-1, self.in_channels)
+        code = GridEncoderFunction.apply(unit, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                                         unit.requires_grad, self.gridtype_id, self.align_corners)
+        return code.view(*lead, self.output_dim)
