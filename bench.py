@@ -272,6 +272,11 @@ def main():
                                     "launch_ms": round(blend_ms, 4)}}
         T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
         sort_passes = (32 + higher_msb(T_tiles) + 7) // 8
+        if dom == "blend_fwd":
+            roofline["note"] = ("the alpha blend is instruction-bound, not HBM-bound: R*256 pixel-Gaussian pairs at ~42 VALU "
+                                "instructions per 64 pairs (bit-exact exp polynomial included) -- `valu_issue_frac` is its "
+                                "fraction of the 2-cycle wave64 VALU issue peak; the HBM-bound kernel of the frame is the "
+                                "streaming cull inside `preprocess` (200 MB in 44 us = 4.5 TB/s, DESIGN.md section 5)")
         if dom == "sort":
             roofline["note"] = ("sort = %d radix passes x (histogram, scan, scatter); `achieved` uses the "
                                 "24*R one-pass lower bound of SURVEY.md 8d" % sort_passes)
