@@ -82,9 +82,12 @@ def main():
                     help="C4 training-step harness (fwd + loss + bwd + gradient all-reduce) instead of the frame loop")
     ap.add_argument("--host-threads", type=int, default=1,
                     help="host threads driving the frame loop, one stream each (frames are independent)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the frame loop alternates over (frames are independent; 1 = serial)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="HIP streams the frame loop alternates over (frames are independent; 1 = serial); "
+                         "default 2 for the rasterizer, 3 for --path visibility (measured optima)")
     args = ap.parse_args()
+    if args.streams is None:
+        args.streams = 3 if args.path == "visibility" else 2
 
     import torch
     import torch.distributed as dist
@@ -509,12 +512,20 @@ def visibility_bench(args, torch, dist, synth, dev, world, rank, barrier, copy_c
         vp, ins = PT.visible_point_map(rows, rig, cam_pos, cam_quat, 0, use_jumps=bool(args.jumps))
         return rows, vp, ins
 
-    for i in range(args.warmup):
-        frame(rank + i * world)
+    # frames are independent: consecutive frames alternate over HIP streams, so frame f+1's volume clear
+    # (HBM-bound) and scatter overlap frame f's traversal (instruction-bound); the two host round trips of a
+    # frame (point count, bounding box) only wait for their own stream
+    vstreams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+
+    def run(lo, hi):
+        for i in range(lo, hi):
+            with torch.cuda.stream(vstreams[i % len(vstreams)]):
+                frame(rank + i * world)
+
+    run(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        frame(rank + i * world)
+    run(args.warmup, args.warmup + args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     V.set_option("timing", 1)
@@ -556,7 +567,8 @@ def visibility_bench(args, torch, dist, synth, dev, world, rank, barrier, copy_c
             "data": "synthetic (gcity-layout-v1, seed 2001)",
             "config": {"workload": "V1: %dx%d BEV layout, %d extruded points, %dx%dx%d int32 volume (%.2f GB), %dx%d rays, "
                                    "24-pose orbit" % (size, size, n_pts, h, w, d, 4 * h * w * d / 1e9, Wimg, Himg),
-                       "parallelism": "frames sharded round-robin, one frame per GPU, no data-path collective",
+                       "parallelism": "frames sharded round-robin, one frame per GPU, no data-path collective; %d HIP "
+                                      "streams per GPU alternate over consecutive frames" % len(vstreams),
                        "empty_space_jumps": bool(args.jumps)},
             "frame_stats": {"points": n_pts, "voxels_written": voxels_written,
                             "hit_fraction": round(float((vp >= 0).float().mean().item()), 4)},
