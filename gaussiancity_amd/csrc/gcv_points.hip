@@ -23,6 +23,7 @@ namespace {
 
 thread_local std::string g_err;
 std::atomic<int> g_timing{0};
+std::atomic<int> g_entry_jump{1};  // option "entry_jump": closed-form walk from the camera to the grid (A/B knob)
 
 int fail(int code, const char* msg) {
   g_err = msg;
@@ -506,7 +507,7 @@ __device__ __forceinline__ void dev_normalize3(float* a) {  // vox/voxlib_common
     }                                                                                \
   }
 
-template <bool HAS_OCC>
+template <bool HAS_OCC, bool ENTRY_JUMP>
 __global__ __launch_bounds__(64) void k_rvip(int32_t* __restrict__ out_voxel_id, float* __restrict__ out_depth,
                                              float* __restrict__ out_raydirs, const int32_t* __restrict__ in_voxel,
                                              const uint32_t* __restrict__ occ, const RvipArgs p) {
@@ -543,12 +544,93 @@ __global__ __launch_bounds__(64) void k_rvip(int32_t* __restrict__ out_voxel_id,
   bool quit = false;
   long long mc_cached = -1;  // macro cell whose bit is in mc_bit
   bool mc_bit = true;
+
+  // Entry jump.  A camera above the city starts outside the grid and upstream walks ~500 cells before the
+  // first voxel test.  Nothing is tested on the way, so only the state at the moment the ray is inside for
+  // the first time matters -- and, the walk being a (time, axis)-ordered merge of per-axis crossings, that
+  // state is closed-form: the entering event E* is the LAST of the "enter the valid range" crossings of the
+  // axes that start out of range; every other axis has then performed the crossings that precede E*
+  // (GCV_COUNT, exact predicate); if one of them has thereby passed its far bound, or an out-of-range axis
+  // moves away / does not move, upstream ends in `quit` without ever testing a voxel.
+  bool pending_test = false;  // the cell reached by the entry jump is tested before any further step
+  float tnow_entry = 0.0f;
+  if (ENTRY_JUMP && !(((unsigned)axis_int[0] < (unsigned)p.dims[0]) & ((unsigned)axis_int[1] < (unsigned)p.dims[1]) &
+                      ((unsigned)axis_int[2] < (unsigned)p.dims[2]))) {
+    bool never = false;
+    int e = -1;
+    float TE = 0.0f;
+    int enter_cell[3] = {axis_int[0], axis_int[1], axis_int[2]};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      if ((unsigned)axis_int[a] < (unsigned)p.dims[a]) continue;
+      int boundary;
+      if (raydir[a] > 0 && axis_int[a] < 0) {
+        boundary = 0;
+        enter_cell[a] = 0;
+      } else if (raydir[a] < 0 && axis_int[a] >= p.dims[a]) {
+        boundary = p.dims[a];
+        enter_cell[a] = p.dims[a] - 1;
+      } else {
+        never = true;
+        boundary = 0;
+      }
+      const float Ta = GCV_TCROSS(a, boundary);
+      if (e < 0 || Ta >= TE) {  // ascending a: on equal times the higher axis comes later in upstream's order
+        TE = Ta;
+        e = a;
+      }
+    }
+    if (never) {
+      quit = true;
+    } else {
+      constexpr int FAR = 1 << 30;
+      int n0c = axis_int[0], n1c = axis_int[1], n2c = axis_int[2];
+      if (e == 0) {
+        GCV_COUNT(1, TE, 0, FAR, n1c)
+        GCV_COUNT(2, TE, 0, FAR, n2c)
+        n0c = enter_cell[0];
+      } else if (e == 1) {
+        GCV_COUNT(0, TE, 1, FAR, n0c)
+        GCV_COUNT(2, TE, 1, FAR, n2c)
+        n1c = enter_cell[1];
+      } else {
+        GCV_COUNT(0, TE, 2, FAR, n0c)
+        GCV_COUNT(1, TE, 2, FAR, n1c)
+        n2c = enter_cell[2];
+      }
+      axis_int[0] = n0c;
+      axis_int[1] = n1c;
+      axis_int[2] = n2c;
+      // an axis that walked past its far bound (or has not reached its range: impossible before E*, kept as
+      // a guard) means upstream hit `quit` on the way
+      if (!(((unsigned)n0c < (unsigned)p.dims[0]) & ((unsigned)n1c < (unsigned)p.dims[1]) &
+            ((unsigned)n2c < (unsigned)p.dims[2]))) {
+        quit = true;
+      } else {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          if (raydir[a] > 0)
+            axis_t[a] = GCV_TCROSS(a, axis_int[a] + 1);
+          else if (raydir[a] < 0)
+            axis_t[a] = GCV_TCROSS(a, axis_int[a]);
+        }
+        pending_test = true;
+        tnow_entry = TE;
+      }
+    }
+  }
+
   for (int plane = 0; plane < p.max_samples; plane++) {
     float t = qnan, t2 = qnan;
     int32_t blk_id = 0;
     while (!quit) {
       float tnow;
       bool jump = false;
+      if (pending_test) {
+        pending_test = false;
+        tnow = tnow_entry;
+        goto test_cell;
+      }
       if (HAS_OCC && axis_int[0] >= 0 && axis_int[0] < p.dims[0] && axis_int[1] >= 0 && axis_int[1] < p.dims[1] &&
           axis_int[2] >= 0 && axis_int[2] < p.dims[2]) {
         const long long lin =
@@ -623,6 +705,7 @@ __global__ __launch_bounds__(64) void k_rvip(int32_t* __restrict__ out_voxel_id,
         axis_t[2] = (s0 || s1) ? axis_t[2] : t_a;
       }
       if (quit) break;
+    test_cell:
       // one unsigned compare per axis, combined without short-circuit branches (the scalar unit is the
       // scarce resource in this loop, as in the blend kernels)
       const bool in_grid = ((unsigned)axis_int[0] < (unsigned)p.dims[0]) & ((unsigned)axis_int[1] < (unsigned)p.dims[1]) &
@@ -693,6 +776,7 @@ const char* gcv_last_error(void) { return g_err.c_str(); }
 int gcv_set_option(const char* name, int value) {
   if (!name) return -1;
   if (!strcmp(name, "timing")) return g_timing.exchange(value);
+  if (!strcmp(name, "entry_jump")) return g_entry_jump.exchange(value);
   return -1;
 }
 
@@ -878,10 +962,15 @@ int gcv_ray_voxel_intersection(const int32_t* volume, const int32_t dims[3], con
   const dim3 grid((img_dims[1] + 7) / 8, (img_dims[0] + 7) / 8, 1);
   {
     StageTimer t(s, ST_TRAVERSE);
-    if (occupancy)
-      k_rvip<true><<<grid, 64, 0, s>>>(out_voxel_id, out_depth, out_raydirs, volume, occupancy, p);
+    const bool entry = g_entry_jump.load() != 0;
+    if (occupancy && entry)
+      k_rvip<true, true><<<grid, 64, 0, s>>>(out_voxel_id, out_depth, out_raydirs, volume, occupancy, p);
+    else if (occupancy)
+      k_rvip<true, false><<<grid, 64, 0, s>>>(out_voxel_id, out_depth, out_raydirs, volume, occupancy, p);
+    else if (entry)
+      k_rvip<false, true><<<grid, 64, 0, s>>>(out_voxel_id, out_depth, out_raydirs, volume, nullptr, p);
     else
-      k_rvip<false><<<grid, 64, 0, s>>>(out_voxel_id, out_depth, out_raydirs, volume, nullptr, p);
+      k_rvip<false, false><<<grid, 64, 0, s>>>(out_voxel_id, out_depth, out_raydirs, volume, nullptr, p);
   }
   HIP_TRY(hipGetLastError(), "ray_voxel_intersection launch");
   return 0;

@@ -124,7 +124,7 @@ def test_traversal_jumps_reproduce_the_reference_walk(cuda_device, po):
     from gaussiancity_amd import _native_v as V
     rng = np.random.default_rng(2024)
     n_checked = 0
-    for trial in range(14):
+    for trial in range(20):
         h, w, d = (int(v) for v in rng.integers(17, 150, 3))
         vol = np.zeros((h, w, d), np.int32)
         nvox = int(rng.integers(1, 60))
@@ -144,6 +144,9 @@ def test_traversal_jumps_reproduce_the_reference_walk(cuda_device, po):
             ori = np.array([-3.0 * h, 0.37 * w, 0.9 * d], np.float32); dr = (centre - ori).astype(np.float32); up = np.array([0, 0, 1], np.float32)
         else:            # outside, looking away over an edge of the grid
             ori = np.array([h + 5.25, w * 0.5, d * 0.5], np.float32); dr = np.array([-1.0, 0.2, -0.1], np.float32); up = np.array([0, 0, 1], np.float32)
+        if trial >= 15:  # out of range on two or three axes at once, integer and fractional origins
+            ori = np.array([-7 - trial, w + 3.0 + 0.5 * (trial & 1), d + 11.25], np.float32)
+            dr = (centre - ori).astype(np.float32); up = np.array([0, 0, 1], np.float32)
         f, c, img = float(rng.uniform(0.4, 2.0) * cols), [rows * 0.5, cols * 0.5], [rows, cols]
         S = 3 if trial % 2 else 1
         want = po.ray_voxel_intersection_perspective(vol, ori, dr, up, f, c, img, S)
@@ -151,10 +154,13 @@ def test_traversal_jumps_reproduce_the_reference_walk(cuda_device, po):
         occ = torch.zeros(max(1, V.lib().gcv_occupancy_bytes(h, w, d) // 4), dtype=torch.int32, device=cuda_device)
         V.check(V.lib().gcv_build_occupancy(v.data_ptr(), h, w, d, occ.data_ptr(), None), "gcv_build_occupancy")
         cam = [torch.from_numpy(a) for a in (ori, dr, up)]
-        for o in (None, occ):
-            got = P.ray_voxel_intersection_perspective(v, *cam, f, c, img, S, occupancy=o)
-            assert np.array_equal(got[0].cpu().numpy(), want[0]), (trial, o is not None)
-            assert np.array_equal(got[1].cpu().numpy().view(np.uint32), want[1].view(np.uint32)), (trial, o is not None)
+        for entry in (1, 0):  # closed-form walk from the camera to the grid on / off
+            V.set_option("entry_jump", entry)
+            for o in (None, occ):
+                got = P.ray_voxel_intersection_perspective(v, *cam, f, c, img, S, occupancy=o)
+                assert np.array_equal(got[0].cpu().numpy(), want[0]), (trial, o is not None, entry)
+                assert np.array_equal(got[1].cpu().numpy().view(np.uint32), want[1].view(np.uint32)), (trial, o is not None, entry)
+        V.set_option("entry_jump", 1)
         n_checked += int((want[0] != 0).sum())
     assert n_checked > 200
 
