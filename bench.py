@@ -98,6 +98,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Debug aid for boxes with ONE GPU: GCR_BENCH_SHARE_GPU=1 lets every rank of a torchrun launch use cuda:0 and
+    # rendezvous over gloo, so the N>1 control flow (sharding, barriers, max-over-ranks reduction, rank-0 report)
+    # can be exercised where RCCL would refuse two ranks on one device.  Never set by the driver.
+    share_gpu = os.environ.get("GCR_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -107,7 +113,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
     N.lib()
     N.set_option("fast_exp", 1 if args.fast_exp else 0)
 
