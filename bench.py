@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--layout-size", type=int, default=2048, help="--path visibility: BEV map edge in pixels")
     ap.add_argument("--encoder-points", type=int, default=16384,
                     help="--path grid-encoder: points per step (16384 = TRAIN_MAX_POINTS, config.py:34)")
+    ap.add_argument("--resident-volume", type=int, default=1,
+                    help="--path visibility: keep the volume resident and erase only the written voxels (0 = clear it)")
     ap.add_argument("--jumps", type=int, default=0,
                     help="--path visibility: empty-space jumps in the traversal (A/B knob; same outputs)")
     ap.add_argument("--train-step", action="store_true",
@@ -515,10 +517,16 @@ def visibility_bench(args, torch, dist, synth, dev, world, rank, barrier, copy_c
     poses = [synth.layout_camera(size, Wimg, Himg, pose=i)[1:] for i in range(24)]
     V.lib()
 
+    workspaces = {}
+
     def frame(i):
         cam_pos, cam_quat = poses[i % len(poses)]
         rows = PT.extrude_points(True, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, *maps)
-        vp, ins = PT.visible_point_map(rows, rig, cam_pos, cam_quat, 0, use_jumps=bool(args.jumps))
+        ws = None
+        if args.resident_volume:  # one resident all-zero volume per stream (restored after every traversal)
+            key = torch.cuda.current_stream().cuda_stream
+            ws = workspaces.setdefault(key, PT.VolumeWorkspace(dev))
+        vp, ins = PT.visible_point_map(rows, rig, cam_pos, cam_quat, 0, use_jumps=bool(args.jumps), workspace=ws)
         return rows, vp, ins
 
     # frames are independent: consecutive frames alternate over HIP streams, so frame f+1's volume clear
@@ -558,7 +566,8 @@ def visibility_bench(args, torch, dist, synth, dev, world, rank, barrier, copy_c
         # only (24 B/pixel) -- what it reads depends on the scene, so it is reported as time, not GB/s
         voxels_written = int((rows[:, 3].long() ** 3).sum().item())
         ab = {"extrude_count": 7 * npix_map, "extrude_emit": 7 * npix_map + 10 * n_pts,
-              "volume_clear": 4 * h * w * d, "volume_scatter": 10 * n_pts + 4 * voxels_written,
+              "volume_clear": (10 * n_pts + 4 * voxels_written) if args.resident_volume else 4 * h * w * d,
+              "volume_scatter": 10 * n_pts + 4 * voxels_written,
               "traversal": 24 * Himg * Wimg}
         stages = {k: {"ms": round(st[k], 4), "alg_MB": round(ab[k] / 1e6, 2),
                       "alg_GBps": round(ab[k] / 1e9 / (st[k] / 1e3), 1) if st.get(k, 0) > 0 and k != "traversal" else None}
@@ -578,7 +587,7 @@ def visibility_bench(args, torch, dist, synth, dev, world, rank, barrier, copy_c
                                    "24-pose orbit" % (size, size, n_pts, h, w, d, 4 * h * w * d / 1e9, Wimg, Himg),
                        "parallelism": "frames sharded round-robin, one frame per GPU, no data-path collective; %d HIP "
                                       "streams per GPU alternate over consecutive frames" % len(vstreams),
-                       "empty_space_jumps": bool(args.jumps)},
+                       "empty_space_jumps": bool(args.jumps), "resident_volume": bool(args.resident_volume)},
             "frame_stats": {"points": n_pts, "voxels_written": voxels_written,
                             "hit_fraction": round(float((vp >= 0).float().mean().item()), 4)},
             "stages_ms": stages, "longest_stage": dom,

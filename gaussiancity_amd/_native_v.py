@@ -11,12 +11,12 @@ LIB_PATH = os.path.join(_CSRC, "libgcv_hip.so")
 
 EXPORTED_SYMBOLS = (
     "gcv_abi_version", "gcv_last_error", "gcv_extrude_scratch_bytes", "gcv_extrude_count", "gcv_extrude_emit",
-    "gcv_occupancy_bytes", "gcv_points_to_volume", "gcv_build_occupancy", "gcv_bounds_scratch_bytes", "gcv_points_bounds", "gcv_rows_to_volume",
+    "gcv_occupancy_bytes", "gcv_points_to_volume", "gcv_build_occupancy", "gcv_bounds_scratch_bytes", "gcv_points_bounds", "gcv_rows_to_volume", "gcv_rows_erase_volume",
     "gcv_ray_voxel_intersection",
     "gcv_set_option", "gcv_get_stage_ms",
 )
 STAGE_NAMES = ("extrude_count", "extrude_emit", "volume_clear", "volume_scatter", "occupancy", "traversal")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SegIns(C.Structure):
@@ -54,7 +54,9 @@ def lib():
     L.gcv_points_bounds.restype = C.c_int
     L.gcv_points_bounds.argtypes = [i64, vp, i32, vp, C.POINTER(i32), C.POINTER(i32), vp]
     L.gcv_rows_to_volume.restype = C.c_int
-    L.gcv_rows_to_volume.argtypes = [i64, vp, C.POINTER(i32), i32, i32, i32, vp, vp, vp]
+    L.gcv_rows_to_volume.argtypes = [i64, vp, C.POINTER(i32), i32, i32, i32, vp, vp, i32, vp]
+    L.gcv_rows_erase_volume.restype = C.c_int
+    L.gcv_rows_erase_volume.argtypes = [i64, vp, C.POINTER(i32), i32, i32, i32, vp, vp]
     L.gcv_build_occupancy.restype = C.c_int
     L.gcv_build_occupancy.argtypes = [vp, i32, i32, i32, vp, vp]
     L.gcv_ray_voxel_intersection.restype = C.c_int

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCV_ABI_VERSION 2
+#define GCV_ABI_VERSION 3
 
 enum gcv_status {
   GCV_OK = 0,
@@ -81,12 +81,17 @@ int gcv_build_occupancy(const int32_t* volume, int32_t h, int32_t w, int32_t d, 
  *   waits for the result (upstream: six .item() calls).  scratch: gcv_bounds_scratch_bytes() device bytes.
  * gcv_rows_to_volume: rows [n][5] = (x, y, z, scale, instance); voxel id = row index + 1, position =
  *   (x, y, z) - offset in int16 arithmetic, cube of `scale` voxels per side -- what _get_volume + points_to_volume
- *   produce for scales = get_point_scales(rows[:, 3]) (utils/helpers.py:197-222, no special classes). */
+ *   produce for scales = get_point_scales(rows[:, 3]) (utils/helpers.py:197-222, no special classes).
+ *   volume_is_zero != 0: the caller guarantees the h*w*d ints are already 0 (a resident workspace restored by
+ *   gcv_rows_erase_volume), so the clear -- the longest stage of a frame -- is skipped.
+ * gcv_rows_erase_volume: writes 0 over exactly the cubes gcv_rows_to_volume(rows, offset, ...) wrote. */
 size_t gcv_bounds_scratch_bytes(void);
 int gcv_points_bounds(int64_t n_points, const int16_t* rows, int32_t row_stride, void* scratch, int32_t min_host[3],
                       int32_t max_host[3], void* hip_stream);
 int gcv_rows_to_volume(int64_t n_points, const int16_t* rows, const int32_t offset[3], int32_t h, int32_t w, int32_t d,
-                       int32_t* volume, uint32_t* occupancy, void* hip_stream);
+                       int32_t* volume, uint32_t* occupancy, int32_t volume_is_zero, void* hip_stream);
+int gcv_rows_erase_volume(int64_t n_points, const int16_t* rows, const int32_t offset[3], int32_t h, int32_t w,
+                          int32_t d, int32_t* volume, void* hip_stream);
 
 /* ---- K12: perspective ray / voxel traversal -----------------------------------------------------
  * volume int32 [dims0][dims1][dims2] with element strides (any layout torch can hand over);

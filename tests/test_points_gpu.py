@@ -227,6 +227,14 @@ def test_get_visible_points_end_to_end(cuda_device, po):
     for jumps in (False, True):
         vp_d, ins_d = P.visible_point_map(rows, rig, cam_pos.copy(), cam_quat, 0, use_jumps=jumps)
         assert np.array_equal(vp_d.cpu().numpy(), vp_o) and np.array_equal(ins_d.cpu().numpy(), ins_o)
+    # resident workspace: same maps, and the buffer is all-zero again after every call (also after it grew)
+    ws = P.VolumeWorkspace(cuda_device)
+    for k in range(3):
+        sub = rows[: len(rows) // (3 - k)] if k < 2 else rows
+        want_vp, want_ins = P.visible_point_map(sub, rig, cam_pos.copy(), cam_quat, 0)
+        got_vp, got_ins = P.visible_point_map(sub, rig, cam_pos.copy(), cam_quat, 0, workspace=ws)
+        assert torch.equal(got_vp, want_vp) and torch.equal(got_ins, want_ins)
+        assert int(ws.buf.count_nonzero()) == 0
     # reduce_mem (scale 1/3, :1428-1433) runs and sees the same scene
     vp3, _ = P.get_visible_points(points, scales, rig, cam_pos.copy(), cam_quat, 0, reduce_mem=True)
     assert vp3.shape == vp.shape and (vp3 >= 0).mean() > 0.5
