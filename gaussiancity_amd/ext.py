@@ -33,7 +33,8 @@ def _dev_f32(t, name, device):
         raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
     if t.device != device:
         raise RuntimeError("%s must live on %s (got %s)" % (name, device, t.device))
-    t = t.contiguous()
+    if not t.is_contiguous():
+        t = t.contiguous()
     return t, t.data_ptr()
 
 
@@ -76,8 +77,33 @@ def _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations, cov3D
     return g, keep
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device):
+    # the raw getter skips the Stream object round trip (several microseconds per frame on the host)
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(device.index if device.index is not None else torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _on_device:
+    """`with torch.cuda.device(d)` only when d is not already current (the guard costs microseconds per frame)."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        idx = device.index
+        self.ctx = None if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*a)
+        return False
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
@@ -104,7 +130,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     # every pixel / every radius is written by the kernels, so no zero-fill launches are needed
     out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=device)
     radii = torch.empty((P,), dtype=torch.int32, device=device)
-    with torch.cuda.device(device):
+    with _on_device(device):
         cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
                               tan_fovy, H, W, scale_modifier, degree, prefiltered, debug)
         g, keep_g = _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations,
@@ -162,7 +188,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     (dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales,
      dL_drotations) = views
     if P != 0:
-        with torch.cuda.device(device):
+        with _on_device(device):
             cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
                                   tan_fovy, H, W, scale_modifier, degree, False, debug)
             # opacity is not an input of the backward (it is read from the geometry state)
