@@ -1,9 +1,5 @@
-"""Drop-in for the reference's `extensions.voxlib` package (extensions/voxlib/__init__.py:10-12):
-same two entry points the reference's Python calls (scripts/dataset_generator.py:1385,1403), backed
-by libgcv_hip.so.  `maps_to_volume` has no in-tree caller upstream and is
-not provided."""
-from gaussiancity_amd.points import points_to_volume, ray_voxel_intersection_perspective  # noqa: F401
-
-
-def maps_to_volume(*args, **kwargs):
-    raise NotImplementedError("voxlib.maps_to_volume has no caller in GaussianCity and is not part of this build")
+"""Drop-in for the reference's `extensions.voxlib` package (extensions/voxlib/__init__.py:10-12): the three
+functions of the native module `voxlib` (extensions/voxlib/bindings.cpp:32-40), backed by libgcv_hip.so.
+The reference's Python calls the first two (scripts/dataset_generator.py:1385,1403); `maps_to_volume` has no
+in-tree caller upstream and is provided for completeness of the module surface."""
+from gaussiancity_amd.points import maps_to_volume, points_to_volume, ray_voxel_intersection_perspective  # noqa: F401

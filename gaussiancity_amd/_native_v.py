@@ -11,12 +11,12 @@ LIB_PATH = os.path.join(_CSRC, "libgcv_hip.so")
 
 EXPORTED_SYMBOLS = (
     "gcv_abi_version", "gcv_last_error", "gcv_extrude_scratch_bytes", "gcv_extrude_count", "gcv_extrude_emit",
-    "gcv_occupancy_bytes", "gcv_points_to_volume", "gcv_build_occupancy", "gcv_bounds_scratch_bytes", "gcv_points_bounds", "gcv_rows_to_volume", "gcv_rows_erase_volume",
+    "gcv_maps_to_volume", "gcv_occupancy_bytes", "gcv_points_to_volume", "gcv_build_occupancy", "gcv_bounds_scratch_bytes", "gcv_points_bounds", "gcv_rows_to_volume", "gcv_rows_erase_volume",
     "gcv_ray_voxel_intersection",
     "gcv_set_option", "gcv_get_stage_ms",
 )
 STAGE_NAMES = ("extrude_count", "extrude_emit", "volume_clear", "volume_scatter", "occupancy", "traversal")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class SegIns(C.Structure):
@@ -45,6 +45,8 @@ def lib():
     L.gcv_extrude_count.argtypes = [i32, vp, C.POINTER(SegIns), i32, i32, vp, vp, vp, vp, vp, sz, C.POINTER(i64), vp]
     L.gcv_extrude_emit.restype = C.c_int
     L.gcv_extrude_emit.argtypes = [i32, vp, C.POINTER(SegIns), i32, i32, vp, vp, vp, vp, vp, sz, vp, i64, vp]
+    L.gcv_maps_to_volume.restype = C.c_int
+    L.gcv_maps_to_volume.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
     L.gcv_occupancy_bytes.restype = sz
     L.gcv_occupancy_bytes.argtypes = [i32, i32, i32]
     L.gcv_points_to_volume.restype = C.c_int

@@ -240,6 +240,37 @@ __global__ __launch_bounds__(EX_BLOCK) void k_extrude_emit(const ExtrudeArgs a, 
   }
 }
 
+// =============================================================================================== K13
+// vox/maps_to_volume.cu:21-101: BEV maps straight into an int16 instance volume [H][W][depth] (one voxel per k
+// of a border column).  Same closed-form border test as the extruder; thread per pixel.
+__global__ __launch_bounds__(256) void k_maps_to_volume(int H, int W, int depth, const int8_t* __restrict__ scales,
+                                                        int n_scales, const int16_t* __restrict__ inst_map,
+                                                        const int16_t* __restrict__ td, const int16_t* __restrict__ bu,
+                                                        const uint8_t* __restrict__ pts, int16_t* __restrict__ volume,
+                                                        unsigned long long* __restrict__ err) {
+  const long long px = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= (long long)H * W) return;
+  if (!pts[px]) return;
+  const int j = (int)(px / W), i = (int)(px % W);
+  const int hgt_up = td[px], hgt_lw = bu[px];
+  const int inst = inst_map[px];
+  const int sem = inst < 10 ? inst : 2;  // vox/maps_to_volume.cu:17-18,44
+  if (sem < 0 || sem >= n_scales || scales[sem] <= 0) {
+    atomicMin(err, (unsigned long long)px);
+    return;
+  }
+  const int scale = scales[sem];
+  bool border = i < scale || i >= W - scale - 1 || j < scale || j >= H - scale - 1;
+  if (!border) border = !ex_nbr_same(td, i, j, W, scale) || !ex_nbr_same(inst_map, i, j, W, scale);
+  int16_t* col = volume + px * depth;
+  for (int k = hgt_lw; k <= hgt_up; k += scale) {
+    const bool top = k > hgt_up - scale;
+    if (!top && !border) continue;
+    if (k < 0 || k >= depth) continue;  // upstream writes out of bounds here
+    col[k] = (int16_t)((top && sem == 2) ? inst + 1 : inst);
+  }
+}
+
 // =============================================================================================== K14
 // vox/points_to_volume.cu:21-50.  One thread per point; atomicMax makes the overlap rule
 // deterministic (highest id wins = sequential order).
@@ -851,6 +882,32 @@ int gcv_extrude_emit(int32_t inc_btm, const int16_t* lut, const gcv_seg_ins* m, 
     k_extrude_emit<<<nblocks, EX_BLOCK, 0, s>>>(a, (const unsigned long long*)scratch, points_out, (long long)n_points);
   }
   HIP_TRY(hipGetLastError(), "extrude emit launch");
+  return 0;
+}
+
+int gcv_maps_to_volume(const int16_t* inst_map, const int16_t* td_hf, const int16_t* bu_hf, const uint8_t* pts_map,
+                       const int8_t* scales, int32_t n_scales, int32_t height, int32_t width, int32_t depth,
+                       int16_t* volume, void* scratch8, void* hip_stream) {
+  if (!inst_map || !td_hf || !bu_hf || !pts_map || !scales || !volume || !scratch8)
+    return fail(GCV_ERR_INVALID_ARGUMENT, "gcv_maps_to_volume: null argument");
+  if (height <= 0 || width <= 0 || depth <= 0 || n_scales <= 0)
+    return fail(GCV_ERR_INVALID_ARGUMENT, "gcv_maps_to_volume: sizes must be positive");
+  hipStream_t s = (hipStream_t)hip_stream;
+  const unsigned long long none = ~0ull;
+  HIP_TRY(hipMemcpyAsync(scratch8, &none, 8, hipMemcpyHostToDevice, s), "maps_to_volume scratch init");
+  HIP_TRY(hipMemsetAsync(volume, 0, sizeof(int16_t) * (size_t)height * width * depth, s), "maps_to_volume clear");
+  const long long npx = (long long)height * width;
+  k_maps_to_volume<<<(unsigned)((npx + 255) / 256), 256, 0, s>>>(height, width, depth, scales, n_scales, inst_map, td_hf,
+                                                                bu_hf, pts_map, volume, (unsigned long long*)scratch8);
+  HIP_TRY(hipGetLastError(), "maps_to_volume launch");
+  unsigned long long bad = none;
+  HIP_TRY(hipMemcpyAsync(&bad, scratch8, 8, hipMemcpyDeviceToHost, s), "maps_to_volume read-back");
+  HIP_TRY(hipStreamSynchronize(s), "maps_to_volume sync");
+  if (bad != none) {
+    char msg[160];
+    snprintf(msg, sizeof(msg), "pixel %llu: class without a positive scale (upstream would not terminate)", bad);
+    return fail(GCV_ERR_UNKNOWN_CLASS, msg);
+  }
   return 0;
 }
 

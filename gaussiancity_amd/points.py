@@ -126,6 +126,31 @@ def points_to_volume(points, pt_ids, scales, h, w, d, return_occupancy=False):
     return (volume, occ) if return_occupancy else volume
 
 
+MAPS_TO_VOLUME_DEPTH = 504  # BLDG_MAX_HEIGHT, extensions/voxlib/maps_to_volume.cu:16
+
+
+def maps_to_volume(inst_map, td_hf, bu_hf, pts_map, scales, depth=MAPS_TO_VOLUME_DEPTH):
+    """voxlib.maps_to_volume (extensions/voxlib/maps_to_volume.cu:103-142): int16 CUDA maps [H,W], bool point map,
+    int8 per-class scales -> int16 instance volume [H, W, 504]."""
+    for t, n in ((inst_map, "inst_map"), (td_hf, "td_hf"), (bu_hf, "bu_hf"), (pts_map, "pts_map"), (scales, "scales")):
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % n)  # CHECK_CUDA, :108-112
+    if inst_map.dtype != torch.int16 or td_hf.dtype != torch.int16 or bu_hf.dtype != torch.int16:
+        raise RuntimeError("expected scalar type Short")
+    if pts_map.dtype not in (torch.bool, torch.uint8) or scales.dtype != torch.int8:
+        raise RuntimeError("expected pts_map Bool and scales Char")
+    dev = inst_map.device
+    H, W = int(inst_map.shape[0]), int(inst_map.shape[1])
+    with torch.cuda.device(dev):
+        volume = torch.empty((H, W, int(depth)), dtype=torch.int16, device=dev)
+        scratch = torch.empty(1, dtype=torch.int64, device=dev)
+        V.check(V.lib().gcv_maps_to_volume(inst_map.contiguous().data_ptr(), td_hf.contiguous().data_ptr(),
+                                           bu_hf.contiguous().data_ptr(), pts_map.contiguous().view(torch.uint8).data_ptr(),
+                                           scales.contiguous().data_ptr(), int(scales.numel()), H, W, int(depth),
+                                           volume.data_ptr(), scratch.data_ptr(), _stream()), "gcv_maps_to_volume")
+    return volume
+
+
 # The drop-in traversal builds a macro-cell bitmask on the fly for contiguous volumes with at least this
 # many voxels (None = never).  Off by default: on the dense city workload the jumps are slower than the
 # plain walk (DESIGN.md section 11); they pay off on sparse volumes.

@@ -10,6 +10,8 @@
  *                                           a CPU loop upstream, "the end-to-end bottleneck", README.md:101)
  *   gcv_points_to_volume                   voxlib.points_to_volume
  *                                          (extensions/voxlib/points_to_volume.cu:21-81, bindings.cpp:36)
+ *   gcv_maps_to_volume                     voxlib.maps_to_volume
+ *                                          (extensions/voxlib/maps_to_volume.cu:21-142, bindings.cpp:38; no in-tree caller)
  *   gcv_ray_voxel_intersection             voxlib.ray_voxel_intersection_perspective
  *                                          (extensions/voxlib/ray_voxel_intersection.cu:54-332, bindings.cpp:33)
  *   gcv_build_occupancy                    (none upstream: 1 bit per 16x16x16 macro cell; lets the traversal
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GCV_ABI_VERSION 3
+#define GCV_ABI_VERSION 4
 
 enum gcv_status {
   GCV_OK = 0,
@@ -64,6 +66,15 @@ int gcv_extrude_emit(int32_t include_bottom_points, const int16_t* scale_of_sema
                      int32_t height, int32_t width, const int16_t* seg_map, const int16_t* td_hf,
                      const int16_t* bu_hf, const uint8_t* pts_map, const void* scratch, size_t scratch_bytes,
                      int16_t* points_out, int64_t n_points, void* hip_stream);
+
+/* ---- K13: BEV maps -> instance volume (voxlib.maps_to_volume, extensions/voxlib/maps_to_volume.cu:21-142) ----
+ * inst_map/td_hf/bu_hf int16 [height][width], pts_map uint8, scales int8 [n_scales] indexed by semantic class
+ * (instance < 10 ? instance : 2, as upstream :16-19,44); volume int16 [height][width][depth] (upstream: depth 504)
+ * is zeroed and receives the instance id at every z of a border column (roof = instance + 1).  z outside
+ * [0, depth) is skipped (upstream writes out of bounds).  scratch8: 8 device bytes.  Waits for completion. */
+int gcv_maps_to_volume(const int16_t* inst_map, const int16_t* td_hf, const int16_t* bu_hf, const uint8_t* pts_map,
+                       const int8_t* scales, int32_t n_scales, int32_t height, int32_t width, int32_t depth,
+                       int16_t* volume, void* scratch8, void* hip_stream);
 
 /* ---- K14: points -> dense volume ------------------------------------------------------------
  * points [n][3] int16 (x, y, z), pt_ids [n] int32, scales [n][3] int16; volume int32 [h][w][d]

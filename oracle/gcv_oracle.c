@@ -113,6 +113,39 @@ void orv_points_to_volume(int64_t n_pts, int h, int w, int d, const int16_t *poi
   }
 }
 
+/* ------------------------------------------------------------------------------------ K13 */
+/* extensions/voxlib/maps_to_volume.cu:21-101 ("parity unpinned": CUDA only, and no caller in the reference's
+ * own Python).  Constants as upstream (:16-19): buildings start at instance 10 here (not 100), merge into
+ * semantic class 2, roof = instance + 1; depth is 504 upstream and a parameter here.  One int16 per voxel:
+ * the instance id at (y, x, k) for every k of a border column -- no cube, unlike points_to_volume.
+ * Upstream writes volume[.. + k] without looking at depth (out of bounds for k >= 504 or k < 0); here such k
+ * are skipped.  scales[sem] <= 0 or sem >= n_scales: error -2 - pixel (upstream: endless loop / OOB read). */
+int64_t orv_maps_to_volume(int height, int width, int depth, const int8_t *scales, int n_scales, const int16_t *inst_map,
+                           const int16_t *td_hf, const int16_t *bu_hf, const uint8_t *pts_map, int16_t *volume) {
+  memset(volume, 0, sizeof(int16_t) * (size_t)height * width * depth);
+  for (int j = 0; j < height; j++)
+    for (int i = 0; i < width; i++) {
+      const size_t px = (size_t)j * width + i;
+      if (!pts_map[px]) continue;
+      const int hgt_up = td_hf[px], hgt_lw = bu_hf[px];
+      const int16_t inst = inst_map[px];
+      const int sem = inst < 10 ? inst : 2;
+      if (sem < 0 || sem >= n_scales || scales[sem] <= 0) return -2 - (int64_t)px;
+      const int scale = scales[sem];
+      int16_t *col = volume + px * depth;
+      const int edge = (i < scale) || (i >= width - scale - 1) || (j < scale) || (j >= height - scale - 1);
+      int border = edge;
+      if (!edge) border = !nbr_same(td_hf, i, j, width, scale) || !nbr_same(inst_map, i, j, width, scale);
+      for (int k = hgt_lw; k <= hgt_up; k += scale) {
+        const int top = k > hgt_up - scale;
+        if (!top && !border) continue; /* hollow */
+        if (k < 0 || k >= depth) continue;
+        col[k] = (int16_t)((top && sem == 2) ? inst + 1 : inst);
+      }
+    }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------ K12 */
 /* voxlib_common.h:56-82 */
 static void normalize3(float *a) {

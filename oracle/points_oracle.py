@@ -40,6 +40,9 @@ def lib():
         L.orv_points_to_volume.restype = None
         L.orv_points_to_volume.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]
+        L.orv_maps_to_volume.restype = C.c_int64
+        L.orv_maps_to_volume.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
         L.orv_rvip.restype = None
         L.orv_rvip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -102,6 +105,19 @@ def points_to_volume(points, pt_ids, scales, h, w, d):
     scales = np.ascontiguousarray(scales, np.int16)
     vol = np.zeros((h, w, d), np.int32)
     lib().orv_points_to_volume(len(points), h, w, d, _p(points), _p(pt_ids), _p(scales), _p(vol))
+    return vol
+
+
+def maps_to_volume(inst_map, td_hf, bu_hf, pts_map, scales, depth=504):
+    inst = np.ascontiguousarray(inst_map, np.int16)
+    td, bu = np.ascontiguousarray(td_hf, np.int16), np.ascontiguousarray(bu_hf, np.int16)
+    pts = np.ascontiguousarray(pts_map).astype(np.uint8)
+    sc = np.ascontiguousarray(scales, np.int8)
+    H, W = inst.shape
+    vol = np.empty((H, W, depth), np.int16)
+    rc = lib().orv_maps_to_volume(H, W, depth, _p(sc), len(sc), _p(inst), _p(td), _p(bu), _p(pts), _p(vol))
+    if rc < 0:
+        raise RuntimeError("pixel %d: class without a positive scale" % (-2 - rc))
     return vol
 
 

@@ -259,3 +259,23 @@ def test_full_size_extruder_properties(cuda_device):
     # every pixel of the point map contributes its top point exactly once
     top = z > td[y, x] - s
     assert int(top.sum()) == int(((td >= bu) & (pm > 0)).sum())
+
+
+def test_maps_to_volume_bit_exact(cuda_device, po):
+    import extensions.voxlib as voxlib
+    rng = np.random.default_rng(78)
+    for H, W, depth in ((64, 48, 504), (33, 70, 61)):
+        L = synth.s_layout(max(H, W), 5000 + H, block=24, road=4, max_height=58)
+        inst = np.ascontiguousarray(np.where(L["INS"][:H, :W] >= 100, L["INS"][:H, :W] - 90, L["INS"][:H, :W])).astype(np.int16)
+        td, bu = np.ascontiguousarray(L["TD_HF"][:H, :W]), rng.integers(0, 3, (H, W)).astype(np.int16)
+        pts = np.ascontiguousarray(L["PTS"][:H, :W])
+        scales = np.array([1, 2, 1, 2, 1, 4, 2, 1, 1, 1], np.int8)
+        want = po.maps_to_volume(inst, td, bu, pts, scales, depth)
+        t = [torch.from_numpy(a).to(cuda_device) for a in (inst, td, bu, pts, scales)]
+        got = voxlib.maps_to_volume(*t) if depth == 504 else P.maps_to_volume(*t, depth=depth)
+        assert got.dtype == torch.int16 and tuple(got.shape) == (H, W, depth)
+        assert np.array_equal(got.cpu().numpy(), want) and (want != 0).sum() > 1000
+    with pytest.raises(RuntimeError, match="positive scale"):
+        P.maps_to_volume(t[0], t[1], t[2], t[3], torch.zeros(10, dtype=torch.int8, device=cuda_device))
+    with pytest.raises(RuntimeError, match="CUDA"):
+        P.maps_to_volume(t[0].cpu(), t[1], t[2], t[3], t[4])

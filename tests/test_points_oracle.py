@@ -139,3 +139,36 @@ def test_traversal_multiple_samples_and_strides(po):
     assert not volT.flags["C_CONTIGUOUS"]
     vT, dT, _ = po.ray_voxel_intersection_perspective(volT, ori, dr, up, f, c, img, 1)
     assert np.array_equal(vT, v1) and np.array_equal(dT.view(np.uint32), d1.view(np.uint32))
+
+
+def test_maps_to_volume_oracle_against_numpy(po):
+    """extensions/voxlib/maps_to_volume.cu:21-101 restated in numpy, pixel by pixel."""
+    rng = np.random.default_rng(77)
+    H, W, depth = 37, 41, 40
+    inst = rng.choice(np.array([1, 3, 4, 6, 12, 14], np.int16), size=(H, W))
+    inst[8:20, 10:30] = 12
+    td = rng.integers(0, 6, (H, W)).astype(np.int16)
+    td[8:20, 10:30] = 33
+    td[25:30, 5:12] = 47  # taller than the volume: those z are skipped, not written out of bounds
+    bu = rng.integers(0, 2, (H, W)).astype(np.int16)
+    pts = rng.random((H, W)) < 0.8
+    scales = np.array([1, 2, 1, 2, 1, 4, 2, 1, 1, 1], np.int8)
+    vol = po.maps_to_volume(inst, td, bu, pts, scales, depth)
+    want = np.zeros((H, W, depth), np.int16)
+    for j in range(H):
+        for i in range(W):
+            if not pts[j, i]:
+                continue
+            ins = int(inst[j, i]); sem = ins if ins < 10 else 2; s = int(scales[sem]); up = int(td[j, i])
+            edge = i < s or i >= W - s - 1 or j < s or j >= H - s - 1
+            border = edge
+            if not edge:
+                nb = [(j - s, i - s), (j - s, i), (j - s, i + s), (j, i - s), (j, i + s), (j + s, i - s), (j + s, i), (j + s, i + s)]
+                border = any(td[a, b] != up for a, b in nb) or any(inst[a, b] != ins for a, b in nb)
+            for k in range(int(bu[j, i]), up + 1, s):
+                top = k > up - s
+                if (top or border) and 0 <= k < depth:
+                    want[j, i, k] = ins + 1 if (top and sem == 2) else ins
+    assert np.array_equal(vol, want) and (vol == 13).any() and (vol != 0).sum() > 500
+    with pytest.raises(RuntimeError):
+        po.maps_to_volume(np.full((4, 4), 5, np.int16), td[:4, :4], bu[:4, :4], np.ones((4, 4), bool), scales[:5], depth)
