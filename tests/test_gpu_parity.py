@@ -374,3 +374,57 @@ def test_inference_loop_matches_sequential_rendering(cuda_device):
     got = frames.InferenceLoop(wr, device=cuda_device).run(pts, poses)
     assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
     assert any(f.any() for f in got)
+
+
+def test_callback_entry_point_matches_staged_path(oracle_mod, cuda_device):
+    """gcr_rasterize_forward: the reference's std::function<char*(size_t)> resize contract as C callbacks
+    (cr/rasterizer.h:25-27) -- the binding INTEGRATION.md section C shows.  Buffers are grown through the
+    callbacks; image, radii and R equal the oracle's, and the buffers drive gcr_backward."""
+    import ctypes as C
+    from gaussiancity_amd import _native as N
+    from gaussiancity_amd import ext
+    P, W, H = 3500, 176, 112
+    rs = scenes.camera(W, H, pose_index=9)._replace(sh_degree=2, bg=torch.tensor([0.1, 0.2, 0.3]))
+    sc = scenes.blob_scene(P, 61, 2)
+    fr = _frame(oracle_mod, rs, sc)
+    dev = cuda_device
+    t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items() if isinstance(v, np.ndarray)}
+    cam_t = [rs.bg.to(dev), rs.view_matrix.to(dev).contiguous(), rs.proj_matrix.to(dev).contiguous(), rs.campos.to(dev)]
+    cam = N.Camera(H, W, rs.tanfovx, rs.tanfovy, rs.scale_modifier, 2, 0, 0, *[x.data_ptr() for x in cam_t])
+    g = N.Gaussians(P, 9, t["means3D"].data_ptr(), t["opacities"].data_ptr(), t["shs"].data_ptr(), None,
+                    t["scales"].data_ptr(), t["rotations"].data_ptr(), None)
+    bufs, sizes = {}, {}
+
+    def make_cb(name):
+        def cb(user, nbytes):  # == resizeFunctional, dgr/rasterize_points.cu:27-33
+            bufs[name] = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+            sizes[name] = int(nbytes)
+            return bufs[name].data_ptr()
+        return N.RESIZE_FN(cb)
+
+    cbs = [make_cb(n) for n in ("geom", "binning", "img")]
+    out_color = torch.empty((3, H, W), device=dev)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)
+    L = N.lib()
+    R = L.gcr_rasterize_forward(cbs[0], None, cbs[1], None, cbs[2], None, C.byref(cam), C.byref(g), out_color.data_ptr(),
+                                radii.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert R == fr.R > 0, (R, N.lib().gcr_last_error())
+    assert sizes["geom"] == L.gcr_geometry_bytes(P) and sizes["img"] == L.gcr_image_bytes(W, H)
+    assert sizes["binning"] == L.gcr_binning_bytes(R, W, H)
+    np.testing.assert_array_equal(radii.cpu().numpy(), fr.radii)
+    assert np.array_equal(out_color.cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
+    # the callback-allocated buffers are what the backward consumes
+    dpix = np.random.default_rng(4).normal(size=(3, H, W)).astype(np.float32)
+    grads = ext.rasterize_gaussians_backward(cam_t[0], t["means3D"], radii, torch.Tensor([]), t["scales"], t["rotations"],
+                                             rs.scale_modifier, torch.Tensor([]), cam_t[1], cam_t[2], rs.tanfovx, rs.tanfovy,
+                                             torch.from_numpy(dpix).to(dev), t["shs"], 2, cam_t[3], bufs["geom"], R,
+                                             bufs["binning"], bufs["img"], False)
+    names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
+    _check_grads(fr.backward(dpix), {n: x.cpu().numpy() for n, x in zip(names, grads)},
+                 ["dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"])
+    # a callback that fails to allocate is reported, not dereferenced
+    null_cb = N.RESIZE_FN(lambda user, nbytes: None)
+    rc = L.gcr_rasterize_forward(null_cb, None, cbs[1], None, cbs[2], None, C.byref(cam), C.byref(g), out_color.data_ptr(),
+                                 radii.data_ptr(), None)
+    assert rc < 0 and b"callback" in L.gcr_last_error()
