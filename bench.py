@@ -63,7 +63,7 @@ def algorithmic_bytes(P, P_v, R, R_p, W, H, M, sh):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--points", type=int, default=None, help="override P (debug only)")
