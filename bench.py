@@ -409,6 +409,15 @@ def main():
         dist.destroy_process_group()
 
 
+def committed_traffic(tag, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_traffic_<tag>.json)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % tag)
+    if not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"].get(kernel)
+    return int((2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024) if k else None
+
+
 def grid_encoder_bench(args, torch, dist, dev, world, rank, barrier, copy_ceiling):
     """Row f3: GaussianCity's positional encoder (models/generator.py:37-42): D=5 inputs, 16 levels x 8 channels,
     2^19 rows per level (268 MB fp32 table).  One step = forward + backward (table gradient + input gradient)
@@ -471,7 +480,9 @@ def grid_encoder_bench(args, torch, dist, dev, world, rank, barrier, copy_ceilin
                           "parallelism": "data parallel: every rank encodes its own points against its replica of the table"},
                "stages_ms": stages,
                "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "copy_ceiling_GBps": round(ceiling, 1),
+                            "frac": round(ach / HBM_PEAK_GBS, 4),
+                            "traffic": committed_traffic("grid_encoder", dom) if B == 16384 else None,
+                            "copy_ceiling_GBps": round(ceiling, 1),
                             "frac_of_copy_ceiling": round(ach / ceiling, 4), "launch_ms": round(st[dom], 4),
                             "alg_bytes_per_launch": int(ab[dom])}}
         if world == 1 and not args.no_cpu_baseline:
@@ -592,7 +603,9 @@ def visibility_bench(args, torch, dist, synth, dev, world, rank, barrier, copy_c
                             "hit_fraction": round(float((vp >= 0).float().mean().item()), 4)},
             "stages_ms": stages, "longest_stage": dom,
             "roofline": {"kernel": hbm_dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "copy_ceiling_GBps": round(ceiling, 1),
+                         "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": committed_traffic("visibility", hbm_dom) if size == 2048 else None,
+                         "copy_ceiling_GBps": round(ceiling, 1),
                          "frac_of_copy_ceiling": round(ach / ceiling, 4), "launch_ms": round(st[hbm_dom], 4),
                          "alg_bytes_per_launch": int(ab[hbm_dom]),
                          "note": "the traversal is latency-bound pointer chasing through the volume (no byte model): "
