@@ -1,0 +1,44 @@
+"""The bench line contract (driver + judge): checked on the committed lines under profiles/, which bench.py
+produced on an MI355X, and on bench.py's argument surface (no GPU needed)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "steps": int, "warmup": int,
+            "ms_per_step": (int, float), "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict}
+
+
+def _check(line, with_cpu=True):
+    for k, t in REQUIRED.items():
+        assert k in line and isinstance(line[k], t), k
+    assert "vs_baseline" in line and line["vs_baseline"] is None          # BASELINE.md publishes no number
+    assert "workload" in line["config"] and "model" not in line["config"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    if with_cpu:
+        c = line["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c, k
+        assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+
+
+def test_committed_bench_lines_follow_the_contract():
+    for name, cpu in (("r01_bench_c3.json", True), ("r01_bench_visibility.json", True), ("r01_bench_grid_encoder.json", True),
+                      ("r01_bench_c5.json", False)):
+        line = json.load(open(os.path.join(ROOT, "profiles", name)))
+        _check(line, cpu)
+    c3 = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_c3.json")))
+    assert c3["unit"] == "frames/s" and "5000000 Gaussians, 1920x1080" in c3["metric"] and c3["scaling"] == "weak"
+    assert c3["cpu_baseline"]["gpu_image_bit_exact_vs_cpu"] is True
+    assert json.load(open(os.path.join(ROOT, "profiles", "r01_bench_visibility.json")))["cpu_baseline"]["kind"] == "reference"
+
+
+def test_bench_cli_surface():
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--help"]).decode()
+    for flag in ("--gpus", "--steps", "--warmup", "--config", "--path", "--train-step"):
+        assert flag in out
