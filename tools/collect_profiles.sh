@@ -1,17 +1,46 @@
 #!/bin/bash
-# Collects the round's rocprofv3 evidence on the GPU box (run through gpurun):
-#   kernel trace of the default bench command (C3 only, so per-kernel averages are comparable
-#   with bench.py's stage timers), then FETCH_SIZE / WRITE_SIZE / SQ counters in SEPARATE --pmc
-#   passes (TCC slots do not fit one pass; never combined with sys/hip traces).
-# Output: gpurun_out/<tag>_*/  -> summarise with tools/rocpd_stats.py / tools/rocpd_pmc.py
+# Collects the round's rocprofv3 evidence ON THE GPU BOX (run through gpurun) and writes only the text / JSON
+# summaries into gpurun_out/ (the rocpd databases stay in /tmp: gpurun_out/ is capped at 64 MiB):
+#   kernel trace of the default bench command, then FETCH_SIZE / WRITE_SIZE / SQ counters in SEPARATE --pmc passes
+#   (TCC slots do not fit one pass; never combined with sys/hip traces), for the three bench paths.
+# Afterwards copy gpurun_out/<tag>_* into profiles/ and commit.
+#   usage: gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
 set -u
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
+O=$R/gpurun_out
+mkdir -p $O
+
+# ---- rasterizer (headline path) ----------------------------------------------------------------------------
 B="python $R/bench.py --no-cpu-baseline --no-secondary"
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_kt -o k -- $B --steps 24 > $R/gpurun_out/${TAG}_kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/${TAG}_fetch -o p -- $B --steps 8 --warmup 2 > $R/gpurun_out/${TAG}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/${TAG}_write -o p -- $B --steps 8 --warmup 2 > $R/gpurun_out/${TAG}_write.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_kt -o k -- $B > /dev/null 2>&1
+python $R/tools/rocpd_stats.py /tmp/${TAG}_kt/k_results.db $O/${TAG}_kernel_trace_stats.txt > /dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_f -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_w -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
-  --kernel-trace -d $R/gpurun_out/${TAG}_sq -o p -- $B --steps 8 --warmup 2 > $R/gpurun_out/${TAG}_sq.log 2>&1
-echo collected $TAG
+  --kernel-trace -d /tmp/${TAG}_sq -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
+python $R/tools/rocpd_pmc.py /tmp/${TAG}_f/p_results.db $O/${TAG}_pmc_fetch.txt > /dev/null
+python $R/tools/rocpd_pmc.py /tmp/${TAG}_w/p_results.db $O/${TAG}_pmc_write.txt > /dev/null
+python $R/tools/rocpd_pmc.py /tmp/${TAG}_sq/p_results.db $O/${TAG}_pmc_sq.txt > /dev/null
+python $R/tools/make_traffic.py /tmp/${TAG}_f/p_results.db /tmp/${TAG}_w/p_results.db $O/${TAG}_traffic.json /tmp/${TAG}_sq/p_results.db > /dev/null
+
+# ---- visibility and hash-grid encoder ------------------------------------------------------------------------
+for P in visibility grid-encoder; do
+  N=${P/-/_}
+  B="python $R/bench.py --path $P --no-cpu-baseline"
+  rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_${N}_kt -o k -- $B --steps 24 --warmup 3 > /dev/null 2>&1
+  python $R/tools/rocpd_stats.py /tmp/${TAG}_${N}_kt/k_results.db $O/${TAG}_${N}_kernel_trace_stats.txt > /dev/null
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_${N}_f -o p -- $B --steps 6 --warmup 2 > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_${N}_w -o p -- $B --steps 6 --warmup 2 > /dev/null 2>&1
+  python $R/tools/rocpd_pmc.py /tmp/${TAG}_${N}_f/p_results.db $O/${TAG}_${N}_pmc_fetch.txt > /dev/null
+  python $R/tools/rocpd_pmc.py /tmp/${TAG}_${N}_w/p_results.db $O/${TAG}_${N}_pmc_write.txt > /dev/null
+done
+
+# ---- bench lines ---------------------------------------------------------------------------------------------------
+python $R/bench.py > $O/${TAG}_bench_c3.json 2>/dev/null
+python $R/bench.py --config C5 --steps 48 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_c5.json 2>/dev/null
+python $R/bench.py --path visibility > $O/${TAG}_bench_visibility.json 2>/dev/null
+python $R/bench.py --path grid-encoder > $O/${TAG}_bench_grid_encoder.json 2>/dev/null
+python $R/bench.py --train-step --steps 100 > $O/${TAG}_bench_c4_trainstep.json 2>/dev/null
+echo collected $TAG; ls $O | grep "^${TAG}_"
