@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured copy)
+NUMERICS = "gcr-fp32-v1"  # the numerics contract shared by oracle/ and the HIP kernels
 
 
 def higher_msb(n):
@@ -70,6 +71,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--fast-exp", action="store_true", help="non-parity v_exp_f32 variant (A/B only)")
+    ap.add_argument("--backward", action="store_true",
+                    help="one step = forward + backward of the frame (with --config C2: the BASELINE metric's fwd+bwd half "
+                         "as the main loop, e.g. under rocprofv3)")
     ap.add_argument("--path", default="raster", choices=["raster", "visibility", "grid-encoder"],
                     help="raster (default): the rasterizer hot path; visibility: SURVEY 8 row f2, BEV maps -> points -> "
                          "volume -> per-pixel first hit (one step = one camera pose)")
@@ -91,6 +95,19 @@ def main():
     if args.streams is None:
         args.streams = 3 if args.path == "visibility" else 2
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: re-launch this command as N ranks (one per GPU) under
+        # torch.distributed.run on this node; the children see WORLD_SIZE and take the normal path
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
     from gaussiancity_amd import _native as N
@@ -107,8 +124,7 @@ def main():
     if share_gpu:
         local_rank = 0
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -172,10 +188,57 @@ def main():
 
         return cfg, sc, cams, use_sh, fwd
 
+    def make_fwd_bwd(fwd_fn, dpix):
+        def fb(pose):
+            a, o = fwd_fn(pose)
+            (bg, m3, col, opa, scl, rot, smod, cov, view, proj, tfx, tfy, h, w, sh, deg, campos, _, _) = a
+            R, color, radii, geom, binning, img = o
+            g = ext.rasterize_gaussians_backward(bg, m3, radii, col, scl, rot, smod, cov, view, proj, tfx, tfy,
+                                                 dpix, sh, deg, campos, geom, R, binning, img, False)
+            return a, o, g
+        return fb
+
+    def frame_statistics(fwd_fn, pose_list, P, W, H):
+        """(R, R_p, P_v) means over the given poses (untimed): R_p = sum over tiles of the largest n_contrib."""
+        stats = []
+        for ps in pose_list:
+            _, o = fwd_fn(ps)
+            R, _, radii, _, _, img = o
+            L = N.get_layout(P, W, H, R)
+            nc = img[L.img_n_contrib:L.img_n_contrib + 4 * W * H].view(torch.int32).view(H, W)
+            Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+            pad = torch.zeros((Hp, Wp), dtype=torch.int32, device=dev)
+            pad[:H, :W] = nc
+            R_p = int(pad.view(Hp // 16, 16, Wp // 16, 16).amax(dim=(1, 3)).sum().item())
+            stats.append((R, R_p, int((radii > 0).sum().item())))
+        return tuple(float(np.mean([x[i] for x in stats])) for i in range(3))
+
+    def oracle_kwargs(rs, sc_np, use_sh_):
+        kw = dict(img_h=rs.img_h, img_w=rs.img_w, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy,
+                  bg=rs.bg.cpu().numpy(), scale_modifier=rs.scale_modifier,
+                  view_matrix=rs.view_matrix.cpu().numpy(), proj_matrix=rs.proj_matrix.cpu().numpy(),
+                  sh_degree=rs.sh_degree, campos=rs.campos.cpu().numpy(), means3D=sc_np["means3D"],
+                  opacities=sc_np["opacities"], scales=sc_np["scales"], rotations=sc_np["rotations"])
+        kw.update(dict(shs=sc_np["shs"]) if use_sh_ else dict(colors_precomp=sc_np["colors_precomp"]))
+        return kw
+
+    def traffic_doc(tag):
+        """Newest committed rocprofv3 --pmc summary profiles/rNN_traffic[_<tag>].json, or None."""
+        import glob
+        pat = "r[0-9][0-9]_traffic%s.json" % ("_" + tag if tag else "")
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+        return (json.load(open(files[-1])), os.path.basename(files[-1])) if files else (None, None)
+
+    VALU_PEAK_GINSTR = 1024 * 2.4 / 2.0  # 256 CUs x 4 SIMDs, 2.4 GHz, 2 cycles per wave64 VALU instruction
+
     cfg, sc, cams, use_sh, fwd = load_scene(args.config, args.points)
     P, W, H = cfg["P"], cfg["W"], cfg["H"]
     M = sc["shs"].shape[1] if use_sh else 0
     poses = [rank + i * world for i in range(args.warmup + args.steps)]
+    step_fn = fwd
+    if args.backward:  # one step = forward + backward of the same frame (BASELINE metric's second half)
+        dpix_main = torch.from_numpy(synth.grad_image(W, H, cfg["seed"])).to(dev)
+        step_fn = make_fwd_bwd(fwd, dpix_main)
 
     # Frames are independent units, so consecutive frames go to alternating HIP streams: frame
     # f+1's preprocess/binning (latency-bound, low occupancy) overlaps frame f's blend.  Every
@@ -193,7 +256,7 @@ def main():
         if args.host_threads <= 1:
             for i in range(lo, hi):
                 with torch.cuda.stream(streams[i % len(streams)]):
-                    fwd(poses[i])
+                    step_fn(poses[i])
             return
         # One host thread per stream.  The reference API returns num_rendered as a Python int, so every
         # call blocks its caller until the frame's scan has run; with a single host thread that wait
@@ -206,7 +269,7 @@ def main():
             torch.cuda.set_device(dev)
             with torch.cuda.stream(streams[t % len(streams)]):
                 for i in range(lo + t, hi, args.host_threads):
-                    fwd(poses[i])
+                    step_fn(poses[i])
 
         th = [threading.Thread(target=worker, args=(t,)) for t in range(args.host_threads)]
         for x in th:
@@ -220,26 +283,36 @@ def main():
     # rocprofv3 --kernel-trace of this command averages over; (2) one stream, every kernel alone on the GPU.
     # Running it before the timed region also means the clocks are up and the capacity hints are learnt whatever
     # W the caller chose (measured: with W = 5 and K = 20 straight after start-up a frame costs 0.29 ms, not 0.255).
-    poses_pre = [rank + i * world for i in range(4 + 96)]
-    for i in range(240):  # learn the capacity hints (first frames take the staged path) and bring the clocks up
+    # These untimed frames are reported as `pre_frames` next to `warmup`.
+    n_burn, n_inst, n_alone = 240, 96, 48
+    poses_pre = [rank + i * world for i in range(4 + n_inst)]
+    for i in range(n_burn):  # learn the capacity hints (first frames take the staged path) and bring the clocks up
         with torch.cuda.stream(streams[i % len(streams)]):
-            fwd(poses_pre[i % 24])
-    n_inst = 96
+            step_fn(poses_pre[i % 24])
     N.set_option("timing", 1)
     N.stage_ms()  # reset accumulators
     barrier()
     t1 = time.perf_counter()
     for i in range(4, 4 + n_inst):
         with torch.cuda.stream(streams[i % len(streams)]):
-            fwd(poses_pre[i])
+            step_fn(poses_pre[i])
     barrier()
     elapsed_instrumented = (time.perf_counter() - t1) * args.steps / n_inst
     stage = N.stage_ms()
-    for i in range(4, 4 + 48):
-        fwd(poses_pre[i])
+    for i in range(4, 4 + n_alone):
+        step_fn(poses_pre[i])
     barrier()
     stage_alone = N.stage_ms()
     N.set_option("timing", 0)
+    # one frame alone on the GPU, enqueue -> finished (what a caller that needs THIS frame waits for); the
+    # headline `value` is a throughput with len(streams) frames in flight
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(4, 4 + 24):
+        step_fn(poses_pre[i])
+        torch.cuda.synchronize()
+    frame_latency_ms = 1e3 * (time.perf_counter() - t1) / 24
+    pre_frames = n_burn + n_inst + n_alone + 24
 
     # ---- W untimed warm-up frames, then the timed region: EXACTLY K frames, barrier + synchronize on both sides
     run_frames(0, args.warmup)
@@ -258,79 +331,84 @@ def main():
     out = None
     if rank == 0:
         # ---- per-frame workload statistics over the same poses (untimed) --------------------
-        stats = []
-        for i in range(args.warmup, args.warmup + min(args.steps, len(cams))):  # poses repeat every orbit
-            _, o = fwd(poses[i])
-            R, _, radii, _, _, img = o
-            L = N.get_layout(P, W, H, R)
-            nc = img[L.img_n_contrib:L.img_n_contrib + 4 * W * H].view(torch.int32).view(H, W)
-            Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
-            pad = torch.zeros((Hp, Wp), dtype=torch.int32, device=dev)
-            pad[:H, :W] = nc
-            R_p = int(pad.view(Hp // 16, 16, Wp // 16, 16).amax(dim=(1, 3)).sum().item())
-            stats.append((R, R_p, int((radii > 0).sum().item())))
-        R_mean = float(np.mean([s[0] for s in stats]))
-        Rp_mean = float(np.mean([s[1] for s in stats]))
-        Pv_mean = float(np.mean([s[2] for s in stats]))
+        R_mean, Rp_mean, Pv_mean = frame_statistics(
+            fwd, [poses[i] for i in range(args.warmup, args.warmup + min(args.steps, len(cams)))], P, W, H)
         ab = algorithmic_bytes(P, Pv_mean, R_mean, Rp_mean, W, H, M, use_sh)
-        fwd_stages = ("preprocess", "scan", "emit", "sort", "ranges", "blend_fwd")
+        stage_names = ("preprocess", "scan", "emit", "sort", "ranges", "blend_fwd")
+        if args.backward:
+            stage_names += ("blend_bwd", "preprocess_bwd")
         stages = {}
-        for k in fwd_stages:
+        for k in stage_names:
             ms = stage.get(k, 0.0)
             stages[k] = {"ms": round(ms, 4), "ms_single_stream": round(stage_alone.get(k, 0.0), 4),
                          "alg_MB": round(ab[k] / 1e6, 3),
                          "alg_GBps": round(ab[k] / 1e9 / (ms / 1e3), 1) if ms > 0 else None}
-        dom = max(fwd_stages, key=lambda k: stage.get(k, 0.0))
+        dom = max(stage_names, key=lambda k: stage.get(k, 0.0))
         dom_ms = stage[dom]
+        dom_alone_ms = stage_alone.get(dom, 0.0) or dom_ms
         achieved = ab[dom] / 1e9 / (dom_ms / 1e3) if dom_ms > 0 else 0.0
         blend_ms = stage["blend_fwd"]
         blend_ach = ab["blend_fwd"] / 1e9 / (blend_ms / 1e3) if blend_ms > 0 else 0.0
-        valu_frac = None
-        traffic = None  # HBM bytes per launch from the committed rocprofv3 --pmc passes (C3 only)
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if args.config == "C3" and args.points is None and os.path.exists(tpath):
-            tk = json.load(open(tpath))["kernels"].get(dom)
-            if tk:  # gfx950: FETCH_SIZE counts half of a 16-B/lane read (MI355X_MICROARCH.md, HBM)
-                traffic = int((2 * tk["FETCH_SIZE_KB"] + tk["WRITE_SIZE_KB"]) * 1024)
-                if tk.get("SQ_INSTS_VALU") and dom_ms > 0:
-                    # the dominant kernel is instruction-bound: committed SQ_INSTS_VALU per launch against what
-                    # 256 CUs x 4 SIMDs can issue in the measured launch time (2 cycles per wave64 VALU
-                    # instruction, 2.4 GHz peak clock -- MI355X_MICROARCH.md "Wave scheduling")
-                    alone_ms = stage_alone.get(dom, 0.0) or dom_ms  # issue fraction of the kernel running alone
-                    valu_frac = tk["SQ_INSTS_VALU"] * 2 / (1024 * 2.4e9 * alone_ms / 1e3)
+        # HBM bytes / VALU instructions per launch from the committed rocprofv3 --pmc passes of this workload
+        tag = {"C3": "", "C2": "c2"}.get(args.config) if args.points is None else None
+        tdoc, tfile = traffic_doc(tag) if tag is not None else (None, None)
+        tk = tdoc["kernels"].get(dom) if tdoc else None
+        traffic = int((2 * tk["FETCH_SIZE_KB"] + tk["WRITE_SIZE_KB"]) * 1024) if tk else None  # gfx950: FETCH_SIZE
+        #                                   counts half of a 16-B/lane read (MI355X_MICROARCH.md, HBM)
+        valu_instr = tk.get("SQ_INSTS_VALU") if tk else None
         ceiling = copy_ceiling()
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "copy_ceiling_GBps": round(ceiling, 1), "frac_of_copy_ceiling": round(achieved / ceiling, 4),
-                    "launch_ms": round(dom_ms, 4), "launch_ms_single_stream": round(stage_alone.get(dom, 0.0), 4),
-                    "alg_bytes_per_launch": int(ab[dom]),
-                    "valu_issue_frac": round(valu_frac, 3) if valu_frac else None,
-                    "alpha_blend": {"kernel": "blend_fwd", "achieved": round(blend_ach, 1),
-                                    "frac": round(blend_ach / HBM_PEAK_GBS, 4),
-                                    "launch_ms": round(blend_ms, 4)}}
+        hbm = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+               "alg_bytes_per_launch": int(ab[dom]), "copy_ceiling_GBps": round(ceiling, 1),
+               "frac_of_copy_ceiling": round(achieved / ceiling, 4)}
+        valu = None
+        if valu_instr and dom_ms > 0:
+            # wave64 VALU instructions per launch (committed SQ_INSTS_VALU) over the live launch duration, against
+            # what 1024 SIMDs issue at 2 cycles per instruction and 2.4 GHz (MI355X_MICROARCH.md "Wave scheduling")
+            g = valu_instr / 1e9 / (dom_ms / 1e3)
+            valu = {"achieved": round(g, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+                    "frac": round(g / VALU_PEAK_GINSTR, 4), "instr_per_launch": int(valu_instr),
+                    "frac_single_stream": round(valu_instr / 1e9 / (dom_alone_ms / 1e3) / VALU_PEAK_GINSTR, 4),
+                    "source": "profiles/" + tfile}
+        blend_like = dom in ("blend_fwd", "blend_bwd")
+        if blend_like and valu:
+            # the alpha-blend kernels are bound by VALU issue, not by HBM: the roofline object prices the launch
+            # against the instruction roofline and carries the HBM accounting of SURVEY 8d beside it
+            roofline = {"kernel": dom, "bound": "valu", "achieved": valu["achieved"], "peak": valu["peak"],
+                        "unit": valu["unit"], "frac": valu["frac"], "traffic": traffic, "valu": valu, "hbm": hbm}
+        else:
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": hbm["frac"], "traffic": traffic, "valu": valu, "hbm": hbm}
+        roofline.update({"launch_ms": round(dom_ms, 4), "launch_ms_single_stream": round(stage_alone.get(dom, 0.0), 4),
+                         "alg_bytes_per_launch": int(ab[dom]),
+                         "alpha_blend": {"kernel": "blend_fwd", "hbm_achieved_GBps": round(blend_ach, 1),
+                                         "hbm_frac": round(blend_ach / HBM_PEAK_GBS, 4),
+                                         "launch_ms": round(blend_ms, 4)}})
         T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
         sort_passes = (32 + higher_msb(T_tiles) + 7) // 8
-        if dom == "blend_fwd":
-            roofline["note"] = ("the alpha blend is instruction-bound, not HBM-bound: R*256 pixel-Gaussian pairs at ~42 VALU "
-                                "instructions per 64 pairs (bit-exact exp polynomial included) -- `valu_issue_frac` is its "
-                                "fraction of the 2-cycle wave64 VALU issue peak; the HBM-bound kernel of the frame is the "
-                                "streaming cull inside `preprocess` (200 MB in 44 us = 4.5 TB/s, DESIGN.md section 5)")
-        if dom == "sort":
-            roofline["note"] = ("sort = %d radix passes x (histogram, scan, scatter); `achieved` uses the "
-                                "24*R one-pass lower bound of SURVEY.md 8d" % sort_passes)
+        if blend_like:
+            roofline["note"] = ("the alpha blend evaluates exp() for every (pixel, Gaussian) pair that survives culling: "
+                                "its limiter is VALU issue (`valu`), its HBM traffic (`hbm`, SURVEY 8d accounting) is a few "
+                                "percent of peak by construction; the HBM-bound kernel of the frame is the streaming cull "
+                                "inside `preprocess` (DESIGN.md section 5)")
 
+        mode = "forward+backward" if args.backward else "forward"
         out = {
-            "metric": "rendered frames/sec (fwd) @ %d Gaussians, %dx%d" % (P, W, H),
+            "metric": ("rendered frames/sec (fwd+bwd) @ %d Gaussians, %dx%d" if args.backward else
+                       "rendered frames/sec (fwd) @ %d Gaussians, %dx%d") % (P, W, H),
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "warmup": args.warmup, "pre_frames": pre_frames,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "ms_per_step_with_stage_events": round(1e3 * elapsed_instrumented / args.steps, 4),
+            "frame_latency_ms": round(frame_latency_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (gcity-synth-v1 %s, seed %d)" % (cfg["scene"], cfg["seed"]),
-            "config": {"workload": "%s: %s %d Gaussians, %dx%d, SH degree %d, forward, 24-pose orbit"
-                                   % (args.config, cfg["scene"], P, W, H, cfg["sh_degree"]),
+            "config": {"workload": "%s: %s %d Gaussians, %dx%d, SH degree %d, %s, 24-pose orbit"
+                                   % (args.config, cfg["scene"], P, W, H, cfg["sh_degree"], mode),
                        "parallelism": "frames sharded round-robin, one frame per GPU, no data-path collective; "
-                                      "%d HIP streams per GPU alternate over consecutive frames" % len(streams),
-                       "exp": "v_exp_f32 (non-parity)" if args.fast_exp else "gcr-fp32-v1 (bit-exact vs oracle)"},
+                                      "%d HIP streams per GPU alternate over consecutive frames (`value` is a throughput "
+                                      "with that many frames in flight; `frame_latency_ms` is one frame alone)" % len(streams),
+                       "exp": "v_exp_f32 (non-parity)" if args.fast_exp else "%s (bit-exact vs oracle)" % NUMERICS},
             "frame_stats": {"num_rendered": R_mean, "consumed_entries_Rp": Rp_mean, "visible": Pv_mean,
                             "tiles": T_tiles, "sort_passes": sort_passes},
             "stages_ms": stages,
@@ -340,13 +418,7 @@ def main():
         # ---- CPU baseline: the oracle on a bounded sample of the same workload --------------
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
-            rs = cams[0]
-            kw = dict(img_h=rs.img_h, img_w=rs.img_w, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy,
-                      bg=rs.bg.cpu().numpy(), scale_modifier=rs.scale_modifier,
-                      view_matrix=rs.view_matrix.cpu().numpy(), proj_matrix=rs.proj_matrix.cpu().numpy(),
-                      sh_degree=rs.sh_degree, campos=rs.campos.cpu().numpy(), means3D=sc["means3D"],
-                      opacities=sc["opacities"], scales=sc["scales"], rotations=sc["rotations"])
-            kw.update(dict(shs=sc["shs"]) if use_sh else dict(colors_precomp=sc["colors_precomp"]))
+            kw = oracle_kwargs(cams[0], sc, use_sh)
             O.lib()
             O.Frame(**kw)  # warm-up (page-in, OpenMP pool)
             n_cpu, cpu_s = 0, 0.0
@@ -356,6 +428,8 @@ def main():
                           campos=rs.campos.cpu().numpy())
                 tc = time.perf_counter()
                 fr = O.Frame(**kw)
+                if args.backward:
+                    fr.backward(dpix_main.cpu().numpy())
                 cpu_s += time.perf_counter() - tc
                 n_cpu += 1
             _, o = fwd(n_cpu - 1)
@@ -363,62 +437,100 @@ def main():
             threads = O.num_threads()
             O.set_num_threads(1)
             tc = time.perf_counter()
-            O.Frame(**kw)
+            fr1 = O.Frame(**kw)
+            if args.backward:
+                fr1.backward(dpix_main.cpu().numpy())
             one_s = time.perf_counter() - tc
             O.set_num_threads(threads)
             out["cpu_baseline"] = {"value": round(n_cpu / cpu_s, 4), "unit": "frames/s", "cores": threads,
                                    "kind": "port",
-                                   "sample": "%d orbit frames of the same workload in %.1f s (oracle/, OpenMP)" % (n_cpu, cpu_s),
+                                   "sample": "%d orbit frames (%s) of the same workload in %.1f s (oracle/, OpenMP)"
+                                             % (n_cpu, mode, cpu_s),
                                    "single_thread_frames_per_s": round(1.0 / one_s, 4),
                                    "host_cpus": os.cpu_count(), "gpu_image_bit_exact_vs_cpu": same}
+            if args.config != "C1":
+                out["cpu_baseline"]["C1"] = cpu_baseline_c1(O, synth, GaussianRasterizerWrapper, torch, oracle_kwargs)
 
         # ---- secondary metric: C2 forward+backward ms/frame ----------------------------------
-        if world == 1 and not args.no_secondary and args.config != "C2":
-            del fwd
+        if world == 1 and not args.no_secondary and args.config != "C2" and not args.backward:
+            del fwd, step_fn
             torch.cuda.empty_cache()
             cfg2, sc2, cams2, use_sh2, fwd2 = load_scene("C2", None if args.points is None else min(args.points, 500000))
-            W2, H2 = cfg2["W"], cfg2["H"]
+            W2, H2, P2 = cfg2["W"], cfg2["H"], cfg2["P"]
             dpix = torch.from_numpy(synth.grad_image(W2, H2, cfg2["seed"])).to(dev)
-
-            def fb(pose):
-                a, o = fwd2(pose)
-                (bg, m3, col, opa, scl, rot, smod, cov, view, proj, tfx, tfy, h, w, sh, deg, campos, _, _) = a
-                R, color, radii, geom, binning, img = o
-                ext.rasterize_gaussians_backward(bg, m3, radii, col, scl, rot, smod, cov, view, proj, tfx, tfy,
-                                                 dpix, sh, deg, campos, geom, R, binning, img, False)
+            fb = make_fwd_bwd(fwd2, dpix)
             for i in range(3):
                 fb(i)
             N.set_option("timing", 1)
             N.stage_ms()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            n2 = 12
+            n2 = 24
             for i in range(n2):
                 fb(3 + i)
             torch.cuda.synchronize()
             ms2 = 1e3 * (time.perf_counter() - t1) / n2
             st2 = N.stage_ms()
             N.set_option("timing", 0)
-            out["secondary"] = {"metric": "fwd+bwd ms/frame @ %d Gaussians, %dx%d, SH3" % (cfg2["P"], W2, H2),
+            R2, Rp2, Pv2 = frame_statistics(fwd2, list(range(3, 3 + n2)), P2, W2, H2)
+            ab2 = algorithmic_bytes(P2, Pv2, R2, Rp2, W2, H2, sc2["shs"].shape[1], True)
+            sec_stages = {k: {"ms": round(v, 4), "alg_MB": round(ab2[k] / 1e6, 3),
+                              "alg_GBps": round(ab2[k] / 1e9 / (v / 1e3), 1) if v > 0 else None}
+                          for k, v in st2.items() if k in ab2}
+            bwd_ms = st2.get("blend_bwd", 0.0)
+            bwd_ach = ab2["blend_bwd"] / 1e9 / (bwd_ms / 1e3) if bwd_ms > 0 else 0.0
+            t2doc, t2file = traffic_doc("c2") if args.points is None else (None, None)
+            tk2 = t2doc["kernels"].get("blend_bwd") if t2doc else None
+            sec_roof = {"kernel": "blend_bwd", "launch_ms": round(bwd_ms, 4), "alg_bytes_per_launch": int(ab2["blend_bwd"]),
+                        "hbm": {"achieved": round(bwd_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(bwd_ach / HBM_PEAK_GBS, 4),
+                                "traffic": int((2 * tk2["FETCH_SIZE_KB"] + tk2["WRITE_SIZE_KB"]) * 1024) if tk2 else None}}
+            if tk2 and tk2.get("SQ_INSTS_VALU") and bwd_ms > 0:
+                g2 = tk2["SQ_INSTS_VALU"] / 1e9 / (bwd_ms / 1e3)
+                sec_roof.update({"bound": "valu", "achieved": round(g2, 1), "peak": VALU_PEAK_GINSTR,
+                                 "unit": "G wave-instr/s", "frac": round(g2 / VALU_PEAK_GINSTR, 4),
+                                 "instr_per_launch": int(tk2["SQ_INSTS_VALU"]), "source": "profiles/" + t2file})
+            out["secondary"] = {"metric": "fwd+bwd ms/frame @ %d Gaussians, %dx%d, SH3" % (P2, W2, H2),
                                 "value": round(ms2, 4), "unit": "ms/frame", "higher_is_better": False,
-                                "stages_ms": {k: round(v, 4) for k, v in st2.items()}}
+                                "frame_stats": {"num_rendered": R2, "consumed_entries_Rp": Rp2, "visible": Pv2},
+                                "stages_ms": sec_stages, "roofline": sec_roof}
+            if not args.no_cpu_baseline:
+                # C2 CPU baseline (SURVEY 8d "must"): oracle forward + backward on the same frames, with the
+                # parity gate (image bit-exact, every gradient within 1e-4 * max) in the same run
+                from oracle import oracle as O
+                kw2 = oracle_kwargs(cams2[3], sc2, True)
+                dnp = dpix.cpu().numpy()
+                n_cpu, cpu_s = 0, 0.0
+                while n_cpu < 12 and cpu_s < 8.0:
+                    rs = cams2[(3 + n_cpu) % len(cams2)]
+                    kw2.update(view_matrix=rs.view_matrix.cpu().numpy(), proj_matrix=rs.proj_matrix.cpu().numpy(),
+                               campos=rs.campos.cpu().numpy())
+                    tc = time.perf_counter()
+                    fr2 = O.Frame(**kw2)
+                    gref = fr2.backward(dnp)
+                    cpu_s += time.perf_counter() - tc
+                    n_cpu += 1
+                _, o2, g2t = fb(3 + n_cpu - 1)
+                same2 = bool(np.array_equal(o2[1].cpu().numpy().view(np.uint32), fr2.out_color.view(np.uint32)))
+                names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
+                worst = 0.0
+                for nme, tg in zip(names, g2t):
+                    ref = gref[nme]
+                    worst = max(worst, float(np.abs(ref - tg.cpu().numpy().reshape(ref.shape)).max())
+                                / max(1.0, float(np.abs(ref).max())))
+                out["secondary"]["cpu_baseline"] = {
+                    "value": round(1e3 * cpu_s / n_cpu, 3), "unit": "ms/frame", "cores": O.num_threads(), "kind": "port",
+                    "sample": "%d frames forward+backward in %.1f s (oracle/, OpenMP)" % (n_cpu, cpu_s),
+                    "gpu_image_bit_exact_vs_cpu": same2, "worst_gradient_error_over_max": float("%.3g" % worst)}
             # the reference-faithful variant: render the full 960x540 sensor, keep a 640x448 crop
             # (utils/helpers.py:255-260) -- the loss only sees the crop, so dL/dpixel is zero outside it
-            del fwd2
+            del fwd2, fb
             torch.cuda.empty_cache()
             _, _, _, _, fwd3 = load_scene("C2", None if args.points is None else min(args.points, 500000), size=(960, 540))
             dfull = torch.zeros((3, 540, 960), dtype=torch.float32, device=dev)
             y0, x0 = (540 - H2) // 2, (960 - W2) // 2
             dfull[:, y0:y0 + H2, x0:x0 + W2] = dpix
-
-            def fb3(pose):
-                a, o = fwd3(pose)
-                (bg, m3, col, opa, scl, rot, smod, cov, view, proj, tfx, tfy, h, w, sh, deg, campos, _, _) = a
-                R, color, radii, geom, binning, img = o
-                crop = color[:, y0:y0 + H2, x0:x0 + W2]
-                ext.rasterize_gaussians_backward(bg, m3, radii, col, scl, rot, smod, cov, view, proj, tfx, tfy,
-                                                 dfull, sh, deg, campos, geom, R, binning, img, False)
-                return crop
+            fb3 = make_fwd_bwd(fwd3, dfull)
             for i in range(3):
                 fb3(i)
             torch.cuda.synchronize()
@@ -433,12 +545,29 @@ def main():
         dist.destroy_process_group()
 
 
+def cpu_baseline_c1(O, synth, Wrapper, torch, oracle_kwargs):
+    """C1 (BASELINE configs[0]: 10k random Gaussians, 256x256, SH degree 0, forward only, the CPU-runnable plumbing
+    case -- SURVEY 8d "must"): the oracle on the host cores, all 24 orbit poses."""
+    cfg, sc = synth.make_scene("C1")
+    W, H = cfg["W"], cfg["H"]
+    wr = Wrapper(synth.intrinsics(W, H), (W, H), device=torch.device("cpu"))
+    cams = [wr._get_gaussian_rasterization_settings(p, q)._replace(sh_degree=0) for p, q in synth.orbit_poses()]
+    O.Frame(**oracle_kwargs(cams[0], sc, True))
+    tc = time.perf_counter()
+    for rs in cams:
+        O.Frame(**oracle_kwargs(rs, sc, True))
+    dt = time.perf_counter() - tc
+    return {"value": round(len(cams) / dt, 2), "unit": "frames/s", "cores": O.num_threads(), "kind": "port",
+            "sample": "24 orbit frames, 10000 Gaussians, 256x256, SH degree 0, forward (oracle/, OpenMP)"}
+
+
 def committed_traffic(tag, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_traffic_<tag>.json)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % tag)
-    if not os.path.exists(path):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic_%s.json" % tag)))
+    if not files:
         return None
-    k = json.load(open(path))["kernels"].get(kernel)
+    k = json.load(open(files[-1]))["kernels"].get(kernel)
     return int((2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024) if k else None
 
 
@@ -723,8 +852,9 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
     n_ar = 5
     barrier()
     t1 = time.perf_counter()
+    n_msg = 0
     for _ in range(n_ar):
-        allreduce_gradients([h.param_grad])
+        n_msg = allreduce_gradients([h.param_grad])
     barrier()
     ar_ms = 1e3 * (time.perf_counter() - t1) / n_ar
     if world > 1:
@@ -741,9 +871,11 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (gcity-synth-v1 %s, seed %d)" % (cfg["scene"], cfg["seed"]),
             "config": {"workload": "C4: %d points, precomputed colours, %dx%d render, %dx%d crop, "
-                                   "69,809,101 fp32 stand-in gradients" % (cfg["P"], W, H, cw, ch),
+                                   "69,809,101 fp32 stand-in gradients (a buffer with the BG generator's message size, "
+                                   "filled with one scalar per step -- not its values)" % (cfg["P"], W, H, cw, ch),
                        "parallelism": "DDP shape: one frame per rank per step, bucketed all-reduce(avg) over RCCL"},
             "allreduce_ms": round(ar_ms, 4) if world > 1 else None, "allreduce_bytes": nbytes,
+            "allreduce_messages": n_msg if world > 1 else None,
             "allreduce_bus_GBps": round(bus, 1) if bus else None}), flush=True)
     if world > 1:
         dist.barrier()

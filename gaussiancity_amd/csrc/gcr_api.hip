@@ -306,7 +306,7 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
               "tile scatter");
     } else if (R_layout > 0) {
       HIP_TRY(gcr_launch_scatter_instances(nblocks, chunk, vis_list, vis_count, rec, gx,
-                                           (uint32_t*)(ib + L.img_tile_cursor), pairs, s),
+                                           (uint32_t*)(ib + L.img_tile_cursor), pairs, ranges, T, frame_guard, s),
               "scatter instances");
     }
   }

@@ -234,11 +234,16 @@ __global__ __launch_bounds__(1024) void k_table_colscan(uint32_t* __restrict__ t
 
 // Global-cursor variant of the scatter, used only when the tile table does not fit in LDS
 // (T * 4 B > 160 KiB, i.e. images beyond ~8K x 5K): one returning device-scope atomic per instance.
+// `frame` (optional) is the speculative-launch guard: a vetoed frame (capacity guess too short)
+// must neither write past the capacity-sized `pairs` buffer nor advance the cursors the retry
+// will scatter from.
 __global__ __launch_bounds__(256) void k_scatter_instances(int chunk, const uint32_t* __restrict__ vis_list,
                                                            const uint32_t* __restrict__ vis_count,
                                                            const float4* __restrict__ rec, int gx,
                                                            uint32_t* __restrict__ cursor,
-                                                           uint64_t* __restrict__ pairs) {
+                                                           uint64_t* __restrict__ pairs,
+                                                           const unsigned long long* __restrict__ frame) {
+  if (frame != nullptr && frame[2] == 0ull) return;  // speculative launch vetoed
   const uint32_t nvis = vis_count[blockIdx.x];
   const uint32_t* __restrict__ my_list = vis_list + (size_t)blockIdx.x * chunk;
   for (uint32_t it = threadIdx.x; it < nvis; it += 256) {
@@ -572,11 +577,22 @@ hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1,
   return hipGetLastError();
 }
 
+// cursor[t] = ranges[t].start: makes the global-cursor scatter idempotent (a frame may be
+// scattered again from the same scan, e.g. gcr_forward_render called twice on one preprocess).
+__global__ __launch_bounds__(256) void k_restore_cursors(const uint32_t* __restrict__ ranges,
+                                                         uint32_t* __restrict__ cursor, int T) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < T) cursor[(size_t)t * GCR_CURSOR_STRIDE] = ranges[2 * t];
+}
+
 hipError_t gcr_launch_scatter_instances(int nblocks, int chunk, const uint32_t* vis_list,
                                         const uint32_t* vis_count, const float4* rec, int gx,
-                                        uint32_t* tile_cursor, uint64_t* pairs, hipStream_t s) {
+                                        uint32_t* tile_cursor, uint64_t* pairs, const uint32_t* ranges, int T,
+                                        const unsigned long long* frame, hipStream_t s) {
   if (nblocks <= 0) return hipSuccess;
-  k_scatter_instances<<<nblocks, 256, 0, s>>>(chunk, vis_list, vis_count, rec, gx, tile_cursor, pairs);
+  if (frame == nullptr)  // staged (retry) path: the cursors may have been consumed by an earlier scatter
+    k_restore_cursors<<<(T + 255) / 256, 256, 0, s>>>(ranges, tile_cursor, T);
+  k_scatter_instances<<<nblocks, 256, 0, s>>>(chunk, vis_list, vis_count, rec, gx, tile_cursor, pairs, frame);
   return hipGetLastError();
 }
 

@@ -105,7 +105,8 @@ hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1,
                                    unsigned long long cap_list, hipStream_t s);
 hipError_t gcr_launch_scatter_instances(int nblocks, int chunk, const uint32_t* vis_list,
                                         const uint32_t* vis_count, const float4* rec, int gx,
-                                        uint32_t* tile_cursor, uint64_t* pairs, hipStream_t s);
+                                        uint32_t* tile_cursor, uint64_t* pairs, const uint32_t* ranges, int T,
+                                        const unsigned long long* frame, hipStream_t s);
 int gcr_tile_sort_capacity(void);  // longest per-tile list the LDS sort accepts
 hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, const uint64_t* pairs, uint32_t* list,
                                 int64_t max_tile_instances, const unsigned long long* frame, hipStream_t s);

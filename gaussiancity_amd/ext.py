@@ -11,6 +11,7 @@ Differences, all on the safe side:
     side-stream bucket all-reduce orders correctly against them;
   * scratch buffers live on means3D's device (the reference uses "current device").
 """
+import collections
 import ctypes as C
 
 import torch
@@ -22,7 +23,25 @@ NUM_CHANNELS = 3  # cr/config.h:15
 # num_rendered of the last frame per (device, P, W, H): the next frame's binning buffer is
 # allocated for 1.5x that before the frame starts, which lets gcr_forward enqueue the whole frame
 # without a mid-frame host stall.  A wrong guess only costs the staged path for that frame.
-_capacity_hint = {}
+# Bounded (least recently used first out): a training loop whose point count changes every step
+# would otherwise grow the table without limit.
+_CAPACITY_HINT_MAX = 64
+_capacity_hint = collections.OrderedDict()
+
+
+def _hint_get(key):
+    v = _capacity_hint.get(key)
+    if v is None:
+        return 0, 0
+    _capacity_hint.move_to_end(key)
+    return v
+
+
+def _hint_put(key, value):
+    _capacity_hint[key] = value
+    _capacity_hint.move_to_end(key)
+    while len(_capacity_hint) > _CAPACITY_HINT_MAX:
+        _capacity_hint.popitem(last=False)
 
 
 def _dev_f32(t, name, device):
@@ -140,7 +159,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         img = torch.empty((L.gcr_image_bytes(W, H),), **byte)
         info = N.FrameInfo()
         key = (device.index, P, W, H)
-        capacity, list_cap = _capacity_hint.get(key, (0, 0))
+        capacity, list_cap = _hint_get(key)
         binning = torch.empty((L.gcr_binning_bytes(capacity, W, H) if capacity else 0,), **byte)
         rc = N.check(L.gcr_forward(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
                                    binning.data_ptr() if capacity else None, binning.numel(), capacity,
@@ -155,7 +174,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                          img.numel(), C.byref(info), out_color.data_ptr(), stream),
                     "gcr_forward_render")
         longest = int(info.max_tile_instances)
-        _capacity_hint[key] = (R + R // 2 + 4096, longest + longest // 2 + 64)
+        _hint_put(key, (R + R // 2 + 4096, longest + longest // 2 + 64))
         del keep_c, keep_g
     return R, out_color, radii, geom, binning, img
 

@@ -60,35 +60,61 @@ def render_sharded(render_fn, n_frames, rank=None, world=None, gather=True, grou
 
 
 def allreduce_gradients(tensors, group=None, bucket_bytes=64 << 20, average=True):
-    """DDP-style gradient exchange: pack `tensors` (in order) into flat fp32 buckets of about
-    `bucket_bytes`, all-reduce each bucket, scale by 1/world, and scatter back in place.
-    Returns the number of buckets used.  Bucket size is a knob because a ring all-reduce over
-    xGMI is per-link bound (7 links x ~153 GB/s per GPU): fewer, larger messages amortise the
-    launch + protocol latency; 64 MB keeps a 279 MB gradient set at five messages."""
+    """DDP-style gradient exchange, in place.  Returns the number of all-reduce messages issued.
+
+    * A contiguous tensor of at least `bucket_bytes` is reduced IN PLACE through `bucket_bytes`-sized
+      views of itself -- no staging copy in, no copy back (a 279 MB gradient set = five 64 MB
+      messages, issued asynchronously so message k+1 is queued while k is on the links).
+    * Smaller tensors are packed, in order, into one flat staging bucket of about `bucket_bytes`
+      (the usual DDP bucket), reduced, and scattered back.
+    Bucket size is a knob because a ring all-reduce over xGMI is per-link bound (7 links x ~153 GB/s
+    per GPU): few large messages amortise the launch + protocol latency."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0
     world = dist.get_world_size(group)
-    buckets, cur, cur_bytes = [], [], 0
-    for t in tensors:
-        nbytes = t.numel() * t.element_size()
-        if cur and cur_bytes + nbytes > bucket_bytes:
-            buckets.append(cur)
-            cur, cur_bytes = [], 0
-        cur.append(t)
-        cur_bytes += nbytes
-    if cur:
-        buckets.append(cur)
-    for b in buckets:
-        flat = torch.cat([t.reshape(-1) for t in b])
+    scale = 1.0 / world
+    messages = 0
+    pending = []  # (work handle, view to scale) of the in-place messages
+
+    def flush(bucket):
+        nonlocal messages
+        if not bucket:
+            return
+        flat = torch.cat([t.reshape(-1) for t in bucket])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        messages += 1
         if average:
-            flat.div_(world)
+            flat.mul_(scale)
         off = 0
-        for t in b:
+        for t in bucket:
             n = t.numel()
             t.copy_(flat[off:off + n].view_as(t))
             off += n
-    return len(buckets)
+
+    cur, cur_bytes = [], 0
+    for t in tensors:
+        nbytes = t.numel() * t.element_size()
+        if nbytes >= bucket_bytes and t.is_contiguous():
+            flush(cur)  # keep the reduction order = the tensor order on every rank
+            cur, cur_bytes = [], 0
+            flat = t.view(-1)
+            step = max(1, bucket_bytes // t.element_size())
+            for off in range(0, flat.numel(), step):
+                view = flat[off:off + step]
+                pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group, async_op=True), view))
+                messages += 1
+            continue
+        if cur and cur_bytes + nbytes > bucket_bytes:
+            flush(cur)
+            cur, cur_bytes = [], 0
+        cur.append(t)
+        cur_bytes += nbytes
+    flush(cur)
+    for work, view in pending:
+        work.wait()
+        if average:
+            view.mul_(scale)
+    return messages
 
 
 class TrainStepHarness:
@@ -96,7 +122,9 @@ class TrainStepHarness:
     points -> rasterize (wrapper API) -> crop -> stand-in loss -> backward -> gradient
     all-reduce of a stand-in parameter set.  The generator/discriminator/VGG are out of scope
     (plain torch modules); `n_param` fp32 values stand in for their gradients so the RCCL
-    message sizes match the real training step (BG generator: 69,809,101 parameters)."""
+    message sizes match the real training step (BG generator: 69,809,101 parameters).  The
+    stand-in buffer is FILLED with one scalar derived from d(loss)/d(points) -- it has the
+    generator's message size, not its values; the real gradients of the step are `points.grad`."""
 
     def __init__(self, rasterizer_wrapper, n_param=69_809_101, crop=None, device=None, group=None, lr=None):
         self.rw = rasterizer_wrapper
@@ -108,7 +136,8 @@ class TrainStepHarness:
         self._opt = None      # (the reference steps its generator's optimizer, core/train.py:293-295)
 
     def step(self, points, cam_pos, cam_quat, target=None):
-        """points: [N,14] leaf tensor requiring grad.  Returns (loss, image)."""
+        """points: [N,14] leaf tensor requiring grad.  Returns (loss, image, n_messages)."""
+        points.grad = None  # the reference zero_grads inside its G-step (core/train.py:263-295)
         img = self.rw(points, cam_pos, cam_quat)
         if self.crop is not None:
             x, y, w, h = self.crop
@@ -168,10 +197,17 @@ class InferenceLoop:
                 out.append((idx, frame.copy()))
             pending[slot] = None
 
+        caller = torch.cuda.current_stream(self.device) if self.cuda else None
         for i, (cam_pos, cam_quat) in enumerate(poses):
             slot = i & 1
             drain(slot)  # the buffer this frame will land in must have been consumed
             if self.cuda:
+                # `points` is normally produced on the caller's stream just before run(): the side
+                # stream must not read it earlier, and the allocator must not recycle it while a
+                # side stream still uses it
+                self.streams[slot].wait_stream(caller)
+                if isinstance(points, torch.Tensor) and points.is_cuda:
+                    points.record_stream(self.streams[slot])
                 with torch.cuda.stream(self.streams[slot]):
                     frame = self.to_uint8_hwc(self.render_fn(points, cam_pos, cam_quat))
                     if self._pinned[slot] is None or self._pinned[slot].shape != frame.shape:
@@ -187,4 +223,7 @@ class InferenceLoop:
         n = len(poses)
         for slot in ((n & 1), 1 - (n & 1)):  # oldest first
             drain(slot)
+        if self.cuda:  # whatever the caller does next with `points` is ordered after the last frame
+            for st in self.streams:
+                caller.wait_stream(st)
         return [f for _, f in sorted(out, key=lambda t: t[0])] if consume is None else None

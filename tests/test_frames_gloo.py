@@ -40,7 +40,16 @@ def _worker(rank, world, port, q):
         g = [torch.full((1000,), float(rank + 1)), torch.full((17, 3), float(10 * (rank + 1))),
              torch.full((5,), float(-rank))]
         nb = frames.allreduce_gradients(g, bucket_bytes=4096)
-        q.put((rank, rendered, ok_gather, sorted(local_only), nb, [float(t.reshape(-1)[0]) for t in g]))
+        # ONE tensor much larger than the bucket (the C4 stand-in shape): reduced in place through views of
+        # itself -- several messages, no staging copy (the storage pointer must not change), ragged tail
+        big = torch.arange(10_007, dtype=torch.float32) * (rank + 1)
+        ptr = big.data_ptr()
+        nb_big = frames.allreduce_gradients([torch.full((3,), float(rank)), big, torch.full((2,), 4.0 * rank)],
+                                            bucket_bytes=4096)
+        big_ok = (big.data_ptr() == ptr and
+                  bool(torch.allclose(big, torch.arange(10_007, dtype=torch.float32) * 1.5)))
+        q.put((rank, rendered, ok_gather, sorted(local_only), nb, [float(t.reshape(-1)[0]) for t in g],
+               nb_big, big_ok))
     finally:
         dist.destroy_process_group()
 
@@ -62,6 +71,8 @@ def test_frame_sharding_and_gradient_allreduce_world2():
     assert res[0][4] == res[1][4] >= 2                                  # several buckets
     want = [1.5, 15.0, -0.5]                                            # averages over the 2 ranks
     assert np.allclose(res[0][5], want) and np.allclose(res[1][5], want)
+    # 10007 floats in 1024-float views = 10 in-place messages + the two small buckets around it
+    assert res[0][6] == res[1][6] == 12 and res[0][7] and res[1][7]
 
 
 def test_single_process_paths():
@@ -88,8 +99,7 @@ def test_train_step_harness_optimizer_and_inference_loop():
     h = frames.TrainStepHarness(_FakeWrapper(), n_param=1000, crop=(0, 0, 4, 3), lr=1e-2)
     target = torch.zeros(3, 3, 4)
     losses = []
-    for i in range(5):
-        pts.grad = None
+    for i in range(5):  # step() clears points.grad itself (the reference zero_grads inside its G-step)
         loss, img, _ = h.step(pts, np.array([1.0, 2.0, 3.0]), np.array([0, 0, 0, 1.0]), target)
         losses.append(float(loss))
     assert not torch.equal(pts.detach(), before) and losses[-1] < losses[0]      # Adam moved the points downhill

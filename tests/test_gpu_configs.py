@@ -1,0 +1,265 @@
+"""-m gpu: every BASELINE.json config (C1..C5, SURVEY.md section 8d "Config mapping") at its FULL size, HIP path
+vs the CPU oracle on the same `gcity-synth-v1` inputs.
+
+  C1  10k S-rand, 256x256, degree 0, forward (precomputed colours AND the SH run)       -- full state, bit-exact
+  C2  500k S-rand, 640x448, SH3, forward + backward                                      -- full state bit-exact,
+                                                                                            all 8 gradient tensors <= 1e-4*max
+  C3  5M S-city, 1920x1080, SH3, forward, 3 orbit poses                                  -- full state (1 pose), image/radii/
+                                                                                            n_contrib (2 more), bit-exact
+  C4  16384 points, 960x540 -> 640x448 crop, through helpers.get_gaussian_points /
+      get_gaussian_rasterization / GaussianRasterizerWrapper / autograd (core/train.py:263-295,
+      utils/helpers.py:226-270)                                                           -- image bit-exact, leaf gradients
+  C5  20M S-city, 3840x2160, SH3, forward                                                 -- image/radii/R/n_contrib bit-exact
+                                                                                            (1 pose) + list properties
+Bars as in test_gpu_parity.py: integer state exact, float forward state and image BIT-exact, gradients
+max|d| <= 1e-4 * max(1, max|ref|).
+"""
+import numpy as np
+import pytest
+import torch
+
+import gpu_util as G
+import scenes
+from gaussiancity_amd import synth
+from test_gpu_parity import GRAD_TOL, _check_forward, _check_grads, _frame
+
+pytestmark = pytest.mark.gpu
+
+ALL_GRADS = ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"]
+
+
+def _orbit_camera(cfg, pose):
+    return scenes.camera(cfg["W"], cfg["H"], pose_index=pose, radius=512.0, altitude=640.0)._replace(
+        sh_degree=cfg["sh_degree"])
+
+
+def _light_check(fr, out, W, H):
+    """R, radii, n_contrib, final_T and the image against the oracle without decoding the geometry buffer."""
+    R, color, radii, geom, binning, img = out
+    assert R == fr.R
+    assert np.array_equal(radii.cpu().numpy(), fr.radii)
+    L = G.N.get_layout(fr.P, W, H, R)
+    nc = img[L.img_n_contrib:L.img_n_contrib + 4 * W * H].view(torch.int32).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(nc, fr.n_contrib)
+    ft = img[L.img_final_T:L.img_final_T + 4 * W * H].view(torch.int32).cpu().numpy().view(np.uint32)
+    assert np.array_equal(ft, fr.final_T.view(np.uint32)), "final_T not bit-exact"
+    got = color.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), fr.out_color.view(np.uint32)), (
+        "image not bit-exact: %d pixels differ, max |d| %g" % (int((got != fr.out_color).any(0).sum()),
+                                                            float(np.abs(got - fr.out_color).max())))
+
+
+@pytest.mark.parametrize("variant", ["precomputed_colour", "sh_degree0"])
+def test_c1_10k_256x256_forward(oracle_mod, cuda_device, variant):
+    cfg, sc = synth.make_scene("C1")
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    use_sh = variant == "sh_degree0"
+    for pose in (0, 7, 19):
+        rs = _orbit_camera(cfg, pose)
+        fr = _frame(oracle_mod, rs, sc, use_sh)
+        assert fr.R > 0
+        args, out = G.run_forward(rs, sc, cuda_device, use_sh=use_sh)
+        _check_forward(fr, G.decode(P, W, H, out), P, use_sh)
+
+
+def test_c2_500k_640x448_sh3_forward_backward(oracle_mod, cuda_device):
+    cfg, sc = synth.make_scene("C2")
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    rs = _orbit_camera(cfg, 3)
+    fr = _frame(oracle_mod, rs, sc)
+    assert fr.R > 100000 and (fr.radii > 0).sum() > 10000
+    args, out = G.run_forward(rs, sc, cuda_device)
+    _check_forward(fr, G.decode(P, W, H, out), P, True)
+    dpix = synth.grad_image(W, H, cfg["seed"])
+    gref = fr.backward(dpix)
+    ggpu = G.run_backward(args, out, dpix, cuda_device)
+    _check_grads(gref, ggpu, ALL_GRADS)
+    # nothing leaks into Gaussians that were not rendered
+    hidden = fr.radii <= 0
+    for n in ("dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot", "dL_dopacity"):
+        assert not np.any(ggpu[n][hidden]), n
+    # a second pose, forward only, image-level (different tile lists)
+    rs2 = _orbit_camera(cfg, 14)
+    _light_check(_frame(oracle_mod, rs2, sc), G.run_forward(rs2, sc, cuda_device)[1], W, H)
+
+
+def test_c2_reference_faithful_960x540_then_crop(oracle_mod, cuda_device):
+    """the reference renders the full 960x540 sensor and crops 640x448 (utils/helpers.py:255-260); the
+    loss only sees the crop, so dL/dpixel is zero outside it."""
+    cfg, sc = synth.make_scene("C2")
+    P, W, H = cfg["P"], 960, 540
+    rs = scenes.camera(W, H, pose_index=5, radius=512.0, altitude=640.0)._replace(sh_degree=3)
+    fr = _frame(oracle_mod, rs, sc)
+    args, out = G.run_forward(rs, sc, cuda_device)
+    _light_check(fr, out, W, H)
+    dfull = np.zeros((3, H, W), np.float32)
+    y0, x0 = (H - 448) // 2, (W - 640) // 2
+    dfull[:, y0:y0 + 448, x0:x0 + 640] = synth.grad_image(640, 448, cfg["seed"])
+    _check_grads(fr.backward(dfull), G.run_backward(args, out, dfull, cuda_device), ALL_GRADS)
+
+
+def test_c3_5m_1080p_three_poses_vs_oracle(oracle_mod, cuda_device):
+    cfg, sc = synth.make_scene("C3")
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    for k, pose in enumerate((0, 9, 17)):
+        rs = _orbit_camera(cfg, pose)
+        fr = _frame(oracle_mod, rs, sc)
+        assert fr.R > 500000
+        args, out = G.run_forward(rs, sc, cuda_device)
+        if k == 0:
+            _check_forward(fr, G.decode(P, W, H, out), P, True)   # every sub-array of the three buffers
+        else:
+            _light_check(fr, out, W, H)
+
+
+def test_c4_training_step_through_helpers_wrapper_and_autograd(oracle_mod, cuda_device):
+    """The G-step's rasterizer leg exactly as the reference calls it: get_gaussian_points -> [B,N,14] ->
+    get_gaussian_rasterization(wrapper, crop) -> loss -> autograd back to the generator's outputs."""
+    from gaussiancity_amd import helpers
+    from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper
+    cfg, sc = synth.make_scene("C4")
+    N, W, H = cfg["P"], cfg["W"], cfg["H"]
+    cw, ch = cfg["crop"]
+    dev = cuda_device
+    wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), device=dev)
+    pos, quat = synth.orbit_poses()[5]   # the bench's C4 camera (bench.py --train-step)
+    xyz_leaf = torch.from_numpy(sc["means3D"][None]).to(dev).requires_grad_(True)
+    scl_leaf = torch.from_numpy(sc["scales"][None]).to(dev).requires_grad_(True)
+    rgb_leaf = torch.from_numpy(sc["colors_precomp"][None]).to(dev).requires_grad_(True)
+    # get_gaussian_points updates xyz / scales in place (utils/helpers.py:232-234): hand it non-leaf views
+    offset = torch.full((1, N, 3), 0.25, device=dev)
+    gs = helpers.get_gaussian_points(xyz_leaf * 1.0, scl_leaf * 1.0, {"rgb": rgb_leaf, "xyz": offset, "scale": 2.0})
+    assert gs.shape == (1, N, 14)
+    box = {"x": (W - cw) // 2, "y": (H - ch) // 2, "w": cw, "h": ch}
+    img = helpers.get_gaussian_rasterization(gs, wr, [pos], [quat], crop_bboxes=[box])
+    assert img.shape == (1, 3, ch, cw)
+    dpix = synth.grad_image(cw, ch, cfg["seed"])
+    (img[0] * torch.from_numpy(dpix).to(dev)).sum().backward()
+    # oracle on what the wrapper feeds the native module (dgr/__init__.py:382-426)
+    rs = wr._get_gaussian_rasterization_settings(pos, quat)
+    rs_cpu = rs._replace(bg=rs.bg.cpu(), view_matrix=rs.view_matrix.cpu(), proj_matrix=rs.proj_matrix.cpu(),
+                         campos=rs.campos.cpu())
+    rot = np.zeros((N, 4), np.float32)
+    rot[:, 0] = 1.0
+    sco = dict(means3D=sc["means3D"] + np.float32(0.25), scales=sc["scales"] * np.float32(2.0), rotations=rot,
+               opacities=np.ones((N, 1), np.float32), colors_precomp=sc["colors_precomp"])
+    fr = _frame(oracle_mod, rs_cpu, sco, use_sh=False)
+    assert fr.R > 1000 and (fr.radii > 0).sum() > 500
+    want = fr.out_color[:, :, ::-1][:, box["y"]:box["y"] + ch, box["x"]:box["x"] + cw]       # flip_lr, then crop
+    got = img[0].detach().cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32)), "C4 image not bit-exact"
+    dfull = np.zeros((3, H, W), np.float32)
+    dfull[:, box["y"]:box["y"] + ch, box["x"]:box["x"] + cw] = dpix
+    gref = fr.backward(np.ascontiguousarray(dfull[:, :, ::-1]))
+    got_g = {"dL_dmean3D": xyz_leaf.grad[0].cpu().numpy(), "dL_dcolor": rgb_leaf.grad[0].cpu().numpy(),
+             "dL_dscale": scl_leaf.grad[0].cpu().numpy()}
+    gref = dict(gref, dL_dscale=gref["dL_dscale"] * np.float32(2.0))  # d(scale*2)/d(scale)
+    _check_grads(gref, got_g, list(got_g))
+    assert np.abs(got_g["dL_dmean3D"]).max() > 0
+
+
+def test_c5_20m_4k_forward_vs_oracle_and_list_properties(oracle_mod, cuda_device):
+    cfg, sc = synth.make_scene("C5")
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    rs = _orbit_camera(cfg, 11)
+    fr = _frame(oracle_mod, rs, sc)
+    assert fr.R > 2000000
+    args, out = G.run_forward(rs, sc, cuda_device)
+    _light_check(fr, out, W, H)
+    R, _, radii, geom, binning, img = out
+    # the sorted list itself and the tile ranges, against the oracle's
+    L = G.N.get_layout(P, W, H, R)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    plist = binning[L.bin_vals[L.bin_sorted]:L.bin_vals[L.bin_sorted] + 4 * R].view(torch.int32).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(plist, fr.point_list[:R])
+    ranges = img[L.img_ranges:L.img_ranges + 8 * T].view(torch.int32).view(T, 2).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(ranges, fr.ranges)
+    # idempotence at this size (second run takes the speculative path)
+    _, out2 = G.run_forward(rs, sc, cuda_device)
+    assert out2[0] == R and torch.equal(out2[1].view(torch.int32), out[1].view(torch.int32))
+
+
+def _c4_points(sc):
+    """[N,14] = xyz, opacity, scale3, rot4 (r,x,y,z), rgb3 as get_gaussian_points builds it (identity rotation)."""
+    N = sc["means3D"].shape[0]
+    rot = np.zeros((N, 4), np.float32)
+    rot[:, 0] = 1.0
+    return np.concatenate([sc["means3D"], np.ones((N, 1), np.float32), sc["scales"], rot, sc["colors_precomp"]],
+                          axis=1).astype(np.float32), rot
+
+
+def test_c4_train_step_harness_with_the_real_rasterizer(oracle_mod, cuda_device):
+    """frames.TrainStepHarness (core/train.py:263-295) on the GPU with the real wrapper: the image of the
+    step and d(loss)/d(points) equal the oracle's, stale gradients do not accumulate, Adam moves the points."""
+    from gaussiancity_amd import frames
+    from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper
+    cfg, sc = synth.make_scene("C4")
+    N, W, H = cfg["P"], cfg["W"], cfg["H"]
+    cw, ch = cfg["crop"]
+    dev = cuda_device
+    wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), device=dev)
+    pts_np, rot = _c4_points(sc)
+    points = torch.from_numpy(pts_np).to(dev).requires_grad_(True)
+    crop = ((W - cw) // 2, (H - ch) // 2, cw, ch)
+    target = torch.zeros((3, ch, cw), device=dev)
+    h = frames.TrainStepHarness(wr, n_param=4096, crop=crop, device=dev)
+    pos, quat = synth.orbit_poses()[2]
+    points.grad = torch.full_like(points, 123.0)   # stale gradient: step() must not add to it
+    loss, img, _ = h.step(points, pos, quat, target)
+    rs = wr._get_gaussian_rasterization_settings(pos, quat)
+    rs_cpu = rs._replace(bg=rs.bg.cpu(), view_matrix=rs.view_matrix.cpu(), proj_matrix=rs.proj_matrix.cpu(),
+                         campos=rs.campos.cpu())
+    sco = dict(means3D=sc["means3D"], scales=sc["scales"], rotations=rot, opacities=np.ones((N, 1), np.float32),
+               colors_precomp=sc["colors_precomp"])
+    fr = _frame(oracle_mod, rs_cpu, sco, use_sh=False)
+    x, y, w, hh = crop
+    want = np.ascontiguousarray(fr.out_color[:, :, ::-1][:, y:y + hh, x:x + w])
+    assert np.array_equal(img.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # d|img|.mean()/d img = sign(img)/numel on the crop, zero elsewhere; un-flip for the oracle
+    dcrop = np.sign(want) / np.float32(want.size)
+    dfull = np.zeros((3, H, W), np.float32)
+    dfull[:, y:y + hh, x:x + w] = dcrop
+    gref = fr.backward(np.ascontiguousarray(dfull[:, :, ::-1]))
+    g = points.grad.cpu().numpy()
+    got = {"dL_dmean3D": g[:, 0:3], "dL_dopacity": g[:, 3:4], "dL_dscale": g[:, 4:7], "dL_drot": g[:, 7:11],
+           "dL_dcolor": g[:, 11:14]}
+    for n in got:   # gradients of a mean over 860k values are ~1e-6: the bar is relative to the tensor's own maximum
+        ref = gref[n]
+        assert float(np.abs(ref - got[n]).max()) <= GRAD_TOL * float(np.abs(ref).max()) + 1e-12, n
+    assert float(h.param_grad[0]) == float(h.param_grad[-1]) != 0.0
+    # with a learning rate the harness applies Adam (replicas stay equal through the rank-averaged gradient)
+    h2 = frames.TrainStepHarness(wr, n_param=4096, crop=crop, device=dev, lr=1e-2)
+    before = points.detach().clone()
+    l0 = float(h2.step(points, pos, quat, target)[0])
+    for _ in range(4):
+        l1 = float(h2.step(points, pos, quat, target)[0])
+    assert not torch.equal(points.detach(), before) and l1 < l0
+
+
+def test_inference_loop_frames_equal_the_oracle(oracle_mod, cuda_device):
+    """frames.InferenceLoop (scripts/inference.py:655-667 shape: pose list -> wrapper -> uint8 HWC frames, two
+    streams, pinned double buffer) against the ORACLE's frames, not against the HIP path itself; `points` is
+    produced on the caller's stream immediately before run() (the ordering ADVICE r01 flagged)."""
+    from gaussiancity_amd import frames
+    from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper
+    W, H = 256, 144
+    dev = cuda_device
+    wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), device=dev)
+    sc = scenes.blob_scene(6000, 93, 0)
+    rot_xyzw = sc["rotations"]   # the wrapper passes columns 7:11 straight through as (r,x,y,z)
+    base = np.concatenate([sc["means3D"], sc["opacities"], sc["scales"], rot_xyzw, sc["colors_precomp"]], axis=1)
+    poses = synth.orbit_poses(9, 60.0, 50.0)
+    staging = torch.from_numpy(base.astype(np.float32)).to(dev)
+    big = torch.randn(64 << 20, device=dev)          # keeps the caller's stream busy ...
+    big = big * 1.0001 + 0.5
+    pts = staging * 1.0                               # ... so `pts` is written late on that stream
+    got = frames.InferenceLoop(wr, device=dev).run(pts, poses)
+    assert len(got) == len(poses)
+    for (pos, quat), frame in zip(poses, got):
+        rs = wr._get_gaussian_rasterization_settings(pos, quat)
+        rs_cpu = rs._replace(bg=rs.bg.cpu(), view_matrix=rs.view_matrix.cpu(), proj_matrix=rs.proj_matrix.cpu(),
+                             campos=rs.campos.cpu())
+        fr = _frame(oracle_mod, rs_cpu, sc, use_sh=False)
+        want = frames.InferenceLoop.to_uint8_hwc(torch.from_numpy(np.ascontiguousarray(fr.out_color[:, :, ::-1]))).numpy()
+        assert np.array_equal(frame, want)
+    assert any(f.any() for f in got)

@@ -194,10 +194,23 @@ def test_tile_list_longer_than_lds_capacity(oracle_mod, cuda_device):
         _check_forward(fr, G.decode(P, W, H, out), P, False)
 
 
-def test_fused_forward_speculation_and_retry(oracle_mod, cuda_device):
+@pytest.mark.parametrize("global_cursor", [0, 1], ids=["lds_tile_table", "global_cursor"])
+def test_fused_forward_speculation_and_retry(oracle_mod, cuda_device, global_cursor):
     """gcr_forward enqueues the whole frame on a capacity guess: first call (no guess) goes
     through the staged path, the second speculates, a deliberately short guess must be vetoed on
-    the device and retried -- all three give the oracle's bits."""
+    the device and retried -- all three give the oracle's bits.  With the global-cursor binning
+    variant too: a vetoed speculative scatter must neither write past the capacity-sized buffer
+    nor advance the cursors the retry scatters from."""
+    from gaussiancity_amd import _native as N
+    from gaussiancity_amd import ext
+    N.set_option("force_global_cursor", global_cursor)
+    try:
+        _speculation_and_retry(oracle_mod, cuda_device)
+    finally:
+        N.set_option("force_global_cursor", 0)
+
+
+def _speculation_and_retry(oracle_mod, cuda_device):
     from gaussiancity_amd import ext
     P, W, H = 3500, 176, 128
     rs = scenes.camera(W, H)._replace(sh_degree=2)

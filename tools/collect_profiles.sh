@@ -25,6 +25,21 @@ python $R/tools/rocpd_pmc.py /tmp/${TAG}_w/p_results.db $O/${TAG}_pmc_write.txt 
 python $R/tools/rocpd_pmc.py /tmp/${TAG}_sq/p_results.db $O/${TAG}_pmc_sq.txt > /dev/null
 python $R/tools/make_traffic.py /tmp/${TAG}_f/p_results.db /tmp/${TAG}_w/p_results.db $O/${TAG}_traffic.json /tmp/${TAG}_sq/p_results.db > /dev/null
 
+# ---- C2 forward + backward (BASELINE metric's second half): kernel trace + counters for K7 / K8 ---------------
+B="python $R/bench.py --config C2 --backward --no-cpu-baseline --no-secondary"
+rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_c2_kt -o k -- $B --steps 200 > /dev/null 2>&1
+python $R/tools/rocpd_stats.py /tmp/${TAG}_c2_kt/k_results.db $O/${TAG}_c2_bwd_kernel_trace_stats.txt > /dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_c2_f -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_c2_w -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
+  --kernel-trace -d /tmp/${TAG}_c2_sq -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
+python $R/tools/rocpd_pmc.py /tmp/${TAG}_c2_f/p_results.db $O/${TAG}_c2_bwd_pmc_fetch.txt > /dev/null
+python $R/tools/rocpd_pmc.py /tmp/${TAG}_c2_w/p_results.db $O/${TAG}_c2_bwd_pmc_write.txt > /dev/null
+python $R/tools/rocpd_pmc.py /tmp/${TAG}_c2_sq/p_results.db $O/${TAG}_c2_bwd_pmc_sq.txt > /dev/null
+python $R/tools/make_traffic.py /tmp/${TAG}_c2_f/p_results.db /tmp/${TAG}_c2_w/p_results.db $O/${TAG}_traffic_c2.json \
+  /tmp/${TAG}_c2_sq/p_results.db "C2 (500k S-rand, 640x448, SH3, forward + backward)" > /dev/null
+[ -n "${RASTER_ONLY:-}" ] && { python $R/bench.py > $O/${TAG}_bench_c3.json 2>/dev/null; echo collected $TAG raster only; ls $O | grep "^${TAG}_"; exit 0; }
+
 # ---- visibility and hash-grid encoder ------------------------------------------------------------------------
 for P in visibility grid-encoder; do
   N=${P/-/_}

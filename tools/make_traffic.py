@@ -2,7 +2,7 @@
 """profiles/<tag>_traffic.json from the FETCH_SIZE / WRITE_SIZE rocpd databases of
 tools/collect_profiles.sh: per bench.py stage, the per-launch averages of the stage's kernels summed.
 
-usage: make_traffic.py <fetch.db> <write.db> <out.json> [<sq.db>]
+usage: make_traffic.py <fetch.db> <write.db> <out.json> [<sq.db> [<workload label>]]
 """
 import json
 import re
@@ -16,7 +16,11 @@ STAGES = {
     "emit": ("k_tile_table<true>", "k_tile_table<1>", "k_tile_tableILb1"),
     "sort": ("k_tile_sort",),
     "blend_fwd": ("k_blend_fwd",),
+    "blend_bwd": ("k_blend_bwd",),
+    "preprocess_bwd": ("k_preprocess_bwd",),
 }
+SQ_COUNTERS = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
+               "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")
 
 
 def per_kernel(db, counter):
@@ -28,20 +32,23 @@ def per_kernel(db, counter):
     return {k: (v, n) for k, v, n in rows}
 
 
-def main(fetch_db, write_db, out, sq_db=None):
+def main(fetch_db, write_db, out, sq_db=None, workload="C3 (5M S-city, 1920x1080, SH3, forward)"):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
-    valu = per_kernel(sq_db, "SQ_INSTS_VALU") if sq_db else {}
+    sq = {c: per_kernel(sq_db, c) for c in SQ_COUNTERS} if sq_db else {}
     kernels = {}
     for stage, pats in STAGES.items():
         fs = sum(v for k, (v, _) in f.items() if any(p in k for p in pats))
         ws = sum(v for k, (v, _) in w.items() if any(p in k for p in pats))
         names = sorted(set(re.search(r"k_\w+(<\w+>)?", k).group(0) for k in f if any(p in k for p in pats)))
+        if not names:
+            continue
         kernels[stage] = {"FETCH_SIZE_KB": round(fs, 1), "WRITE_SIZE_KB": round(ws, 1), "kernels": names}
-        if valu:
-            kernels[stage]["SQ_INSTS_VALU"] = round(sum(v for k, (v, _) in valu.items() if any(p in k for p in pats)))
+        for c, tab in sq.items():
+            if tab:
+                kernels[stage][c] = round(sum(v for k, (v, _) in tab.items() if any(p in k for p in pats)))
     doc = {
-        "workload": "C3 (5M S-city, 1920x1080, SH3, forward)",
+        "workload": workload,
         "unit": "KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE per-dispatch averages, summed over the stage's kernels)",
         "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: MI355X_MICROARCH.md says FETCH_SIZE reports half the "
                 "bytes of 16-B/lane reads on gfx950; raw values kept here",
@@ -52,4 +59,4 @@ def main(fetch_db, write_db, out, sq_db=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

@@ -1,0 +1,103 @@
+// valu_probe.hip -- issue cost of the VALU instructions the blend kernels are made of, on the box it runs on.
+// Every wave runs a long loop of 8 INDEPENDENT chains of one instruction (so the 4-cycle dependent latency is
+// hidden and what is timed is issue), 8 waves per SIMD.  Reported: cycles per wave64 instruction per SIMD,
+// assuming the clock given on the command line (default 2400 MHz).
+//   build: hipcc --offload-arch=gfx950 -O3 tools/valu_probe.hip -o tools/_build/valu_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define REP8(X) X X X X X X X X
+template <int KIND>
+__global__ __launch_bounds__(256) void k_probe(float* out, int iters, float seed) {
+  float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * 0.5f, b3 = a3 * 0.5f, b4 = a4 * .5f, b5 = a5 * .5f, b6 = a6 * .5f, b7 = a7 * .5f;
+  const float m = 0.999f, c = 0.001f;
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  v2 p0 = {a0, b0}, p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3}, p4 = {a4, b4}, p5 = {a5, b5}, p6 = {a6, b6}, p7 = {a7, b7};
+  const v2 pm = {m, m}, pc = {c, c};
+  for (int i = 0; i < iters; i++) {
+    if (KIND == 0) {  // v_fma_f32
+#define S(r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(m), "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 1) {  // v_pk_fma_f32 (two fp32 FMAs per lane)
+#define S(r) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(pm), "v"(pc));
+      REP8(S(p0) S(p1) S(p2) S(p3) S(p4) S(p5) S(p6) S(p7))
+#undef S
+    } else if (KIND == 2) {  // v_pk_mul_f32
+#define S(r) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(r) : "v"(pm));
+      REP8(S(p0) S(p1) S(p2) S(p3) S(p4) S(p5) S(p6) S(p7))
+#undef S
+    } else if (KIND == 3) {  // v_exp_f32 (transcendental)
+#define S(r) asm volatile("v_exp_f32 %0, %0" : "+v"(r));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 4) {  // v_cndmask_b32 (select on vcc)
+#define S(r) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r) : "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 5) {  // v_cmp_lt_f32 writing an SGPR pair
+#define S(r) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" : : "v"(r), "v"(c) : "s20", "s21");
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 6) {  // v_rcp_f32
+#define S(r) asm volatile("v_rcp_f32 %0, %0" : "+v"(r));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 7) {  // v_mul_f32 with an SGPR operand
+#define S(r) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(r) : "s"(m));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 8) {  // v_pk_add_f32
+#define S(r) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(r) : "v"(pc));
+      REP8(S(p0) S(p1) S(p2) S(p3) S(p4) S(p5) S(p6) S(p7))
+#undef S
+    } else if (KIND == 9) {  // v_ldexp_f32
+#define S(r) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(r) : "v"(0));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    }
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
+}
+
+template <int KIND>
+double run(const char* name, float* out, int blocks, int iters, double mhz) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  k_probe<KIND><<<blocks, 256>>>(out, 64, 1.0f);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k_probe<KIND><<<blocks, 256>>>(out, iters, 1.0f);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  // waves per SIMD = blocks * 4 waves / (256 CUs * 4 SIMDs); instructions per wave = iters * 64
+  const double waves_per_simd = blocks * 4.0 / 1024.0;
+  const double cyc = ms * 1e-3 * mhz * 1e6 / (waves_per_simd * iters * 64.0);
+  printf("{\"instr\": \"%s\", \"ms\": %.4f, \"cycles_per_wave_instr_per_simd\": %.3f}\n", name, ms, cyc);
+  return cyc;
+}
+
+int main(int argc, char** argv) {
+  const double mhz = argc > 1 ? atof(argv[1]) : 2400.0;
+  const int blocks = 256 * 8, iters = 4096;  // 8 blocks per CU = 8 waves per SIMD
+  float* out;
+  hipMalloc(&out, sizeof(float) * blocks * 256);
+  printf("{\"assumed_clock_MHz\": %.0f, \"blocks\": %d, \"waves_per_simd\": 8, \"independent_chains\": 8}\n", mhz, blocks);
+  run<0>("v_fma_f32", out, blocks, iters, mhz);
+  run<1>("v_pk_fma_f32", out, blocks, iters, mhz);
+  run<2>("v_pk_mul_f32", out, blocks, iters, mhz);
+  run<8>("v_pk_add_f32", out, blocks, iters, mhz);
+  run<3>("v_exp_f32", out, blocks, iters, mhz);
+  run<6>("v_rcp_f32", out, blocks, iters, mhz);
+  run<4>("v_cndmask_b32", out, blocks, iters, mhz);
+  run<5>("v_cmp_lt_f32 -> sgpr", out, blocks, iters, mhz);
+  run<7>("v_mul_f32 (sgpr operand)", out, blocks, iters, mhz);
+  run<9>("v_ldexp_f32", out, blocks, iters, mhz);
+  hipFree(out);
+  return 0;
+}
