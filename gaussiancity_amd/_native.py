@@ -16,8 +16,9 @@ EXPORTED_SYMBOLS = (
     "gcr_abi_version", "gcr_last_error", "gcr_geometry_bytes", "gcr_image_bytes",
     "gcr_binning_bytes", "gcr_get_layout", "gcr_forward", "gcr_forward_preprocess", "gcr_forward_render",
     "gcr_backward", "gcr_mark_visible", "gcr_rasterize_forward", "gcr_set_option",
-    "gcr_get_stage_ms",
+    "gcr_get_stage_ms", "gcr_grad_record_floats",
 )
+GRAD_REC_FLOATS = 16  # gcr_grad_record_floats(): floats per Gaussian of gcr_grads.dL_dconic (checked at load)
 
 STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "ranges", "blend_fwd", "blend_bwd",
                "preprocess_bwd")
@@ -67,7 +68,7 @@ class FrameInfo(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("max_tile_instances", C.c_int64)]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 _lib = None
@@ -129,6 +130,9 @@ def lib():
     L.gcr_set_option.argtypes = [C.c_char_p, C.c_int]
     L.gcr_get_stage_ms.restype = C.c_int
     L.gcr_get_stage_ms.argtypes = [C.POINTER(C.c_float), C.c_int]
+    L.gcr_grad_record_floats.restype = C.c_int
+    if L.gcr_grad_record_floats() != GRAD_REC_FLOATS:
+        raise RuntimeError("libgcr_hip.so gradient record size mismatch")
     if L.gcr_abi_version() != ABI_VERSION:
         raise RuntimeError("libgcr_hip.so ABI version mismatch")
     _lib = L

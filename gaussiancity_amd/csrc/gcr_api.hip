@@ -15,6 +15,7 @@ std::atomic<int> g_fast_exp{0};
 std::atomic<int> g_timing{0};
 std::atomic<int> g_force_radix{0};
 std::atomic<int> g_force_global_cursor{0};
+std::atomic<int> g_k7_skip_flush{0};  // timing experiment only: results are wrong when set
 
 enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PRE_BWD, ST_COUNT };
 
@@ -158,6 +159,7 @@ int check_inputs(const gcr_camera* cam, const gcr_gaussians* g, bool need_opacit
 extern "C" {
 
 int gcr_abi_version(void) { return GCR_ABI_VERSION; }
+int gcr_grad_record_floats(void) { return GCR_GRAD_REC_FLOATS; }
 const char* gcr_last_error(void) { return g_err.c_str(); }
 
 size_t gcr_geometry_bytes(int32_t P) {
@@ -187,6 +189,7 @@ int gcr_set_option(const char* name, int value) {
   if (!strcmp(name, "timing")) return g_timing.exchange(value);
   if (!strcmp(name, "force_radix")) return g_force_radix.exchange(value);
   if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.exchange(value);
+  if (!strcmp(name, "k7_skip_flush")) return g_k7_skip_flush.exchange(value);
   return -1;
 }
 
@@ -528,8 +531,8 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     b.final_T = (float*)(ib + L.img_final_T);
     b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
     b.dL_dpix = dL_dpix;
-    b.dL_dmean2D = gr->dL_dmeans2D; b.dL_dconic = gr->dL_dconic;
-    b.dL_dopacity = gr->dL_dopacity; b.dL_dcolor = gr->dL_dcolors;
+    b.grad_rec = gr->dL_dconic;  // [P][GCR_GRAD_REC_FLOATS] accumulation records (include/gcr.h)
+    b.debug_flags = g_k7_skip_flush.load() ? 1 : 0;
     StageTimer t(s, ST_BLEND_BWD);
     HIP_TRY(gcr_launch_blend_bwd(b, g_fast_exp.load() != 0, s), "blend backward");
   }
@@ -549,7 +552,8 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   a.vis_list = (const uint32_t*)(gb + L.geom_vis_list);
   a.vis_count = (const uint32_t*)(gb + L.geom_vis_count);
   gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &a.nblocks, &a.chunk);
-  a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dconic = gr->dL_dconic; a.dL_dcolor = gr->dL_dcolors;
+  a.grad_rec = (const float4*)gr->dL_dconic;
+  a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dcolor = gr->dL_dcolors; a.dL_dopacity = gr->dL_dopacity;
   a.dL_dmean3D = gr->dL_dmeans3D; a.dL_dcov3D = gr->dL_dcov3D; a.dL_dsh = gr->dL_dsh;
   a.dL_dscale = gr->dL_dscales; a.dL_drot = gr->dL_drotations;
   {

@@ -1,6 +1,6 @@
 // gcr_device.h -- device-side helpers shared by every gfx950 kernel of the rasterizer.
 //
-// Numerics contract "gcr-fp32-v1" (DESIGN.md section 4): IEEE binary32, source association
+// Numerics contract "gcr-fp32-v2" (DESIGN.md section 4): IEEE binary32, source association
 // order of the reference, no implicit contraction (the library is built with
 // -ffp-contract=off), correctly rounded division / sqrt
 // (-fhip-fp32-correctly-rounded-divide-sqrt), denormals kept, fused multiply-adds only where
@@ -28,13 +28,20 @@ GCR_DEV int gcr_f2i_sat(float v) {
   return (int)v;
 }
 
-// gcr-fp32-v1 exponential (two-term Cody-Waite reduction, degree-6 polynomial, < 1 ulp).
-// Replaces exp() at cr/forward.cu:317 and cr/backward.cu:525.  Every step is an exactly
-// specified IEEE operation, so CPU and GPU agree bit for bit (v_exp_f32 would not).
-GCR_DEV float gcr_expf(float x) {
-  if (x < -87.0f) return 0.0f;
-  if (x > 88.0f) return __builtin_inff();
-  const float n = __builtin_rintf(x * 1.44269504088896341f);
+// gcr-fp32-v2 exponential: two-term Cody-Waite reduction, degree-6 polynomial, < 1 ulp on [-87, 0].
+// Replaces exp() at cr/forward.cu:317 and cr/backward.cu:525.  Every step is an exactly specified
+// IEEE operation, so CPU (oracle/gcr_oracle.c: gcr_expf) and GPU agree bit for bit (v_exp_f32 would
+// not).  11 VALU instructions:
+//   t = fma(x, log2(e), 1.5*2^23)   -> the integer n = round(x*log2 e) sits in t's low mantissa bits
+//   n = t - 1.5*2^23                 (exact)
+//   r = x - n*ln2                    (two FMAs, hi/lo split of ln 2)
+//   p = poly6(r)                     (six FMAs)
+//   result = bits(p) + (bits(t) << 23)   = p * 2^n: ONE integer shift-add (0x4B400000 << 23 == 0 mod 2^32,
+//            so only n reaches the exponent field); exact while p * 2^n is a normal number.
+#define GCR_EXP_MAGIC 12582912.0f  // 1.5 * 2^23
+GCR_DEV float gcr_expf_core(float x) {
+  const float t = __builtin_fmaf(x, 1.44269504088896341f, GCR_EXP_MAGIC);
+  const float n = t - GCR_EXP_MAGIC;
   float r = __builtin_fmaf(n, -0.693145751953125f, x);
   r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
   float p = 0.0013933652080595493f;
@@ -44,25 +51,18 @@ GCR_DEV float gcr_expf(float x) {
   p = __builtin_fmaf(p, r, 0.5f);
   p = __builtin_fmaf(p, r, 1.0f);
   p = __builtin_fmaf(p, r, 1.0f);
-  return p * __int_as_float(((int)n + 127) << 23);
+  return __uint_as_float(__float_as_uint(p) + (__float_as_uint(t) << 23));
+}
+GCR_DEV float gcr_expf(float x) {
+  if (x < -87.0f) return 0.0f;
+  if (x > 88.0f) return __builtin_inff();
+  return gcr_expf_core(x);
 }
 
 // Same function without the range guards, for callers that guarantee -87 <= x <= 0 (the blend
 // kernels clamp their skip bound to >= -87, which is exactly what the x < -87 guard does:
 // exp -> 0 -> alpha = 0 < 1/255 -> skipped).  Bit-identical to gcr_expf on that domain.
-GCR_DEV float gcr_expf_noguard(float x) {
-  const float n = __builtin_rintf(x * 1.44269504088896341f);
-  float r = __builtin_fmaf(n, -0.693145751953125f, x);
-  r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
-  float p = 0.0013933652080595493f;
-  p = __builtin_fmaf(p, r, 0.008363181725144386f);
-  p = __builtin_fmaf(p, r, 0.04166646674275398f);
-  p = __builtin_fmaf(p, r, 0.16666576266288757f);
-  p = __builtin_fmaf(p, r, 0.5f);
-  p = __builtin_fmaf(p, r, 1.0f);
-  p = __builtin_fmaf(p, r, 1.0f);
-  return p * __int_as_float(((int)n + 127) << 23);
-}
+GCR_DEV float gcr_expf_noguard(float x) { return gcr_expf_core(x); }
 
 // Non-parity variant (option "fast_exp"): hardware v_exp_f32, ~1 ulp, NOT bit-reproducible.
 GCR_DEV float gcr_expf_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }

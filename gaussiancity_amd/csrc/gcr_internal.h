@@ -57,9 +57,17 @@ struct GcrPreprocessBwdArgs {
   const uint8_t* clamped;
   const uint32_t *vis_list, *vis_count;  // K1's per-block survivor lists
   int nblocks, chunk;
-  const float *dL_dmean2D, *dL_dconic, *dL_dcolor;
+  const float4* grad_rec;  // K7's per-Gaussian accumulation records (GCR_GRAD_REC_FLOATS each)
+  float *dL_dmean2D, *dL_dcolor, *dL_dopacity;  // written here from the records (API outputs)
   float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 };
+
+// K7 accumulates its nine per-(tile, Gaussian) sums into ONE 64-byte record per Gaussian
+//   [0..3] = dL_dcolor.rgb, dL_dopacity   [4..7] = dL_dmean2D.xy, dL_dconic.x, dL_dconic.y   [8] = dL_dconic.w
+// so that the nine global atomics of a flush land in one cache line and leave the CU as one
+// memory-side transaction (scattered over four arrays they were 44 % of K7: DESIGN.md section 5).
+// K8 reads the record with three dwordx4 loads and writes the API's dL_dmeans2D / dL_dcolors / dL_dopacity.
+#define GCR_GRAD_REC_FLOATS 16
 
 struct GcrBlendArgs {
   const uint32_t* ranges;  // [T][2]
@@ -72,7 +80,8 @@ struct GcrBlendArgs {
   float* out_color;         // fwd
   const unsigned long long* frame;  // optional device guard: frame[2]==0 -> kernel does nothing
   const float* dL_dpix;     // bwd
-  float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor;  // bwd
+  float* grad_rec;          // bwd: [P][GCR_GRAD_REC_FLOATS] accumulation records (zero-filled by the caller)
+  int debug_flags;  // experiments only (gcr_set_option "k7_skip_flush"): bit 0 = K7 drops its global atomics
 };
 
 // launchers (each enqueues on `s`, returns hipGetLastError())

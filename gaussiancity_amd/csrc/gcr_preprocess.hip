@@ -585,7 +585,18 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
   float cv[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) cv[i] = a.cov3D[6 * (size_t)idx + i];
-  const float dcx = a.dL_dconic[4 * idx], dcy = a.dL_dconic[4 * idx + 1], dcz = a.dL_dconic[4 * idx + 3];
+  // K7's accumulation record of this Gaussian (gcr_internal.h); the API's per-Gaussian outputs of the
+  // blend gradient are written from it here
+  const float4 g0 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 0];  // dcolor.rgb, dopacity
+  const float4 g1 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 1];  // dmean2D.xy, dconic.x, dconic.y
+  const float4 g2 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 2];  // dconic.w
+  const float dcx = g1.z, dcy = g1.w, dcz = g2.x;
+  a.dL_dmean2D[3 * (size_t)idx] = g1.x;
+  a.dL_dmean2D[3 * (size_t)idx + 1] = g1.y;
+  a.dL_dcolor[3 * (size_t)idx] = g0.x;
+  a.dL_dcolor[3 * (size_t)idx + 1] = g0.y;
+  a.dL_dcolor[3 * (size_t)idx + 2] = g0.z;
+  a.dL_dopacity[idx] = g0.w;
 
   // ---- K8a
   Cov2DCtx c;
@@ -652,7 +663,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
     const float m_w = 1.0f / (mhw + 0.0000001f);
     const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
     const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-    const float d2x = a.dL_dmean2D[3 * idx], d2y = a.dL_dmean2D[3 * idx + 1];
+    const float d2x = g1.x, d2y = g1.y;
     const float ax = (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
     const float ay = (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
     const float az = (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
@@ -671,8 +682,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
     float* __restrict__ dsh = a.dL_dsh + (size_t)idx * a.M * 3;
     const uint8_t cl = a.clamped[idx];
     float dRGB[3];
+    const float dcol[3] = {g0.x, g0.y, g0.z};
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) dRGB[ch] = a.dL_dcolor[3 * idx + ch] * (((cl >> ch) & 1) ? 0.f : 1.f);
+    for (int ch = 0; ch < 3; ch++) dRGB[ch] = dcol[ch] * (((cl >> ch) & 1) ? 0.f : 1.f);
     float gdx[3] = {0, 0, 0}, gdy[3] = {0, 0, 0}, gdz[3] = {0, 0, 0};
     const int deg = a.D;
 #define SHV(i) sh[3 * (i) + ch]

@@ -196,7 +196,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
     # The reference allocates nine torch::zeros tensors (dgr/rasterize_points.cu:118-126); here
     # they are nine views of ONE zero-filled buffer, i.e. a single fill launch.
-    shapes = ((P, 3), (P, 3), (P, NUM_CHANNELS), (P, 2, 2), (P, 1), (P, 6), (P, M, 3), (P, 3), (P, 4))
+    # dL_dconic is the native side's accumulation scratch: one 64-byte record per Gaussian (include/gcr.h)
+    shapes = ((P, 3), (P, 3), (P, NUM_CHANNELS), (P, N.GRAD_REC_FLOATS), (P, 1), (P, 6), (P, M, 3), (P, 3), (P, 4))
     sizes = [int(torch.Size(sh).numel()) for sh in shapes]
     starts, off = [], 0
     for n in sizes:  # every view starts 256-byte aligned (the kernels use float4 stores)

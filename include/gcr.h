@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GCR_ABI_VERSION 3
+#define GCR_ABI_VERSION 4
 #define GCR_BLOCK_X 16 /* cr/config.h:16 */
 #define GCR_BLOCK_Y 16 /* cr/config.h:17 */
 #define GCR_NUM_CHANNELS 3 /* cr/config.h:15 */
@@ -84,10 +84,15 @@ typedef struct gcr_gaussians {
 } gcr_gaussians;
 
 /* Gradient outputs (cr/rasterizer.h:39-48); every array must be ZERO-FILLED by the caller,
- * as dgr/rasterize_points.cu:118-126 does with torch::zeros. */
+ * as dgr/rasterize_points.cu:118-126 does with torch::zeros.  dL_dmeans2D / dL_dcolors / dL_dopacity
+ * are written by the preprocess-backward kernel from the accumulation records (Gaussians that were
+ * not rendered keep the caller's zeros). */
 typedef struct gcr_grads {
   float *dL_dmeans2D;   /* [P,3] (x,y used) */
-  float *dL_dconic;     /* [P,4] scratch, (x,y,w used) -- dgr/rasterize_points.cu:121 */
+  float *dL_dconic;     /* [P, gcr_grad_record_floats() = 16] scratch, 64-byte aligned: the role of the
+                           reference's dL_dconic [P,2,2] (dgr/rasterize_points.cu:121), widened to one
+                           64-byte accumulation record per Gaussian (colour 3, opacity 1, mean2D 2,
+                           conic 3, pad) so that K7's nine atomics per (tile, Gaussian) share a cache line */
   float *dL_dopacity;   /* [P] */
   float *dL_dcolors;    /* [P,3] */
   float *dL_dmeans3D;   /* [P,3] */
@@ -178,6 +183,9 @@ int gcr_forward_render(const gcr_camera *cam, const gcr_gaussians *g, void *geom
                        void *hip_stream);
 
 /* K7 (reverse-walk blend gradient) + K8 (preprocess gradient). dL_dpix is [3,H,W]. */
+/* floats per Gaussian of gcr_grads.dL_dconic (16) */
+int gcr_grad_record_floats(void);
+
 int gcr_backward(const gcr_camera *cam, const gcr_gaussians *g, const int32_t *radii,
                  const void *geom, size_t geom_bytes, const void *binning,
                  size_t binning_bytes, const void *img, size_t img_bytes, int64_t R,

@@ -9,7 +9,8 @@
 
 #define REP8(X) X X X X X X X X
 template <int KIND>
-__global__ __launch_bounds__(256) void k_probe(float* out, int iters, float seed) {
+__global__ __launch_bounds__(256) void k_probe(float* out, int iters, float seed, unsigned long long* ticks) {
+  const unsigned long long t_begin = __builtin_readcyclecounter();
   float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * 0.5f, b3 = a3 * 0.5f, b4 = a4 * .5f, b5 = a5 * .5f, b6 = a6 * .5f, b7 = a7 * .5f;
   const float m = 0.999f, c = 0.001f;
@@ -57,8 +58,48 @@ __global__ __launch_bounds__(256) void k_probe(float* out, int iters, float seed
 #define S(r) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(r) : "v"(0));
       REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
 #undef S
+    } else if (KIND == 10) {  // v_cndmask_b32 with an SGPR-pair mask (VOP3)
+#define S(r) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[22:23]" : "+v"(r) : "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 11) {  // half v_fma_f32, half v_cndmask_b32 (vcc), interleaved
+#define S(r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(m), "v"(c));
+#define Q(r) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r) : "v"(c));
+      REP8(S(a0) Q(a1) S(a2) Q(a3) S(a4) Q(a5) S(a6) Q(a7))
+#undef S
+#undef Q
+    } else if (KIND == 12) {  // v_mov_b32 (what an exec-masked update costs)
+#define S(r) asm volatile("v_mov_b32 %0, %1" : "+v"(r) : "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 13) {  // v_cndmask_b32 whose two sources differ from the destination
+#define S(r, q) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(r) : "v"(q), "v"(c));
+      REP8(S(a0, b0) S(a1, b1) S(a2, b2) S(a3, b3) S(a4, b4) S(a5, b5) S(a6, b6) S(a7, b7))
+#undef S
+    } else if (KIND == 14) {  // v_mul_f32, all VGPR operands
+#define S(r) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(r) : "v"(m));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 15) {  // v_cmp_lt_f32 writing vcc (VOPC)
+#define S(r) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(r), "v"(c) : "vcc");
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 16) {  // v_min_f32 / v_max_f32 pair (select-free clamps)
+#define S(r) asm volatile("v_min_f32 %0, %0, %1" : "+v"(r) : "v"(m));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 17) {  // v_fmac_f32 (VOP2 two-operand FMA)
+#define S(r) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(r) : "v"(m), "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 18) {  // v_fma_f32 with two literal-free inline constants (VOP3, 3 VGPR reads vs 2)
+#define S(r) asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(r) : "v"(m));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
     }
   }
+  const unsigned long long t_end = __builtin_readcyclecounter();
+  if (ticks != nullptr && (threadIdx.x & 63) == 0) ticks[(blockIdx.x * 256 + threadIdx.x) >> 6] = t_end - t_begin;
   out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
 }
 
@@ -67,10 +108,12 @@ double run(const char* name, float* out, int blocks, int iters, double mhz) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  k_probe<KIND><<<blocks, 256>>>(out, 64, 1.0f);
+  static unsigned long long* ticks = nullptr;
+  if (!ticks) hipMalloc(&ticks, sizeof(unsigned long long) * blocks * 4);
+  k_probe<KIND><<<blocks, 256>>>(out, 64, 1.0f, nullptr);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k_probe<KIND><<<blocks, 256>>>(out, iters, 1.0f);
+  k_probe<KIND><<<blocks, 256>>>(out, iters, 1.0f, ticks);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -78,7 +121,17 @@ double run(const char* name, float* out, int blocks, int iters, double mhz) {
   // waves per SIMD = blocks * 4 waves / (256 CUs * 4 SIMDs); instructions per wave = iters * 64
   const double waves_per_simd = blocks * 4.0 / 1024.0;
   const double cyc = ms * 1e-3 * mhz * 1e6 / (waves_per_simd * iters * 64.0);
-  printf("{\"instr\": \"%s\", \"ms\": %.4f, \"cycles_per_wave_instr_per_simd\": %.3f}\n", name, ms, cyc);
+  // the same from the waves' own s_memtime deltas (shader-clock ticks, no clock assumption): a wave shares its SIMD
+  // with waves_per_simd - 1 others, so ticks per instruction per SIMD = mean delta / (instructions * waves_per_simd)
+  static unsigned long long host_ticks[1 << 16];
+  hipMemcpy(host_ticks, ticks, sizeof(unsigned long long) * blocks * 4, hipMemcpyDeviceToHost);
+  double mean = 0;
+  for (int i = 0; i < blocks * 4; i++) mean += (double)host_ticks[i];
+  mean /= blocks * 4;
+  const double tick_cyc = mean / (iters * 64.0 * waves_per_simd);
+  printf("{\"instr\": \"%s\", \"ms\": %.4f, \"cycles_per_wave_instr_per_simd_at_assumed_clock\": %.3f, "
+         "\"memtime_ticks_per_wave_instr_per_simd\": %.3f, \"implied_clock_MHz_if_tick_is_a_cycle\": %.0f}\n",
+         name, ms, cyc, tick_cyc, mean / (ms * 1e-3) / 1e6);
   return cyc;
 }
 
@@ -98,6 +151,15 @@ int main(int argc, char** argv) {
   run<5>("v_cmp_lt_f32 -> sgpr", out, blocks, iters, mhz);
   run<7>("v_mul_f32 (sgpr operand)", out, blocks, iters, mhz);
   run<9>("v_ldexp_f32", out, blocks, iters, mhz);
+  run<14>("v_mul_f32 (vgpr operands)", out, blocks, iters, mhz);
+  run<17>("v_fmac_f32", out, blocks, iters, mhz);
+  run<18>("v_fma_f32 (inline constant addend)", out, blocks, iters, mhz);
+  run<16>("v_min_f32", out, blocks, iters, mhz);
+  run<12>("v_mov_b32", out, blocks, iters, mhz);
+  run<10>("v_cndmask_b32_e64 (sgpr-pair mask)", out, blocks, iters, mhz);
+  run<13>("v_cndmask_b32 (dst != src)", out, blocks, iters, mhz);
+  run<11>("v_fma_f32 / v_cndmask_b32 interleaved", out, blocks, iters, mhz);
+  run<15>("v_cmp_lt_f32 -> vcc", out, blocks, iters, mhz);
   hipFree(out);
   return 0;
 }
