@@ -66,7 +66,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "D1"],
+                    help="BASELINE configs C1..C5 (default C3 = the headline); D1 = dense general-3DGS-like stress scene "
+                         "(long tile lists; informational, not a BASELINE config)")
     ap.add_argument("--points", type=int, default=None, help="override P (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -410,7 +412,8 @@ def main():
                                       "with that many frames in flight; `frame_latency_ms` is one frame alone)" % len(streams),
                        "exp": "v_exp_f32 (non-parity)" if args.fast_exp else "%s (bit-exact vs oracle)" % NUMERICS},
             "frame_stats": {"num_rendered": R_mean, "consumed_entries_Rp": Rp_mean, "visible": Pv_mean,
-                            "tiles": T_tiles, "sort_passes": sort_passes},
+                            "tiles": T_tiles, "entries_per_tile": round(R_mean / T_tiles, 1),
+                            "ns_per_instance": round(1e9 * elapsed / args.steps / max(R_mean, 1.0), 4)},
             "stages_ms": stages,
             "roofline": roofline,
         }

@@ -277,7 +277,7 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
 // Enqueues scatter + per-tile LDS sort + forward blend (the default binning path).
 // `frame_guard` (device {R, max, go}) makes the three kernels no-ops when go == 0.
 static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, void* geom, void* binning, void* img,
-                              int64_t R_layout, int64_t lds_list_capacity, bool speculative,
+                              int64_t R_layout, int64_t lds_list_capacity, bool long_lists, bool speculative,
                               unsigned long long cap_instances, unsigned long long cap_list, float* out_color,
                               hipStream_t s) {
   gcr_layout L;
@@ -316,7 +316,9 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   if (int rc = debug_sync(cam, s, "scatter instances")) return rc;
   if (R_layout > 0) {
     StageTimer t(s, ST_SORT);
-    HIP_TRY(gcr_launch_tile_sort(ranges, T, pairs, list, lds_list_capacity, frame_guard, s), "tile sort");
+    HIP_TRY(gcr_launch_tile_sort(ranges, T, pairs, (uint64_t*)(bb + L.bin_keys[1]), list, lds_list_capacity, long_lists,
+                                 frame_guard, s),
+            "tile sort");
   }
   if (int rc = debug_sync(cam, s, "tile sort")) return rc;
   GcrBlendArgs b;
@@ -388,8 +390,16 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
   if (int rc = g_readback.ensure()) return rc;
   hipStream_t s = (hipStream_t)hip_stream;
   const bool speculate = binning_capacity > 0 && !g_force_radix.load() && !cam->debug;
-  unsigned long long cap_list = (unsigned long long)gcr_tile_sort_capacity();
-  if (tile_list_capacity > 0 && (unsigned long long)tile_list_capacity < cap_list) {
+  // Longest tile list the speculative launches are sized for.  A guess within the LDS sort capacity sizes
+  // the LDS of k_tile_sort (a longer list vetoes the speculation); a guess beyond it means "this scene has
+  // long lists": the per-tile long-list sort is enqueued too and the list length never vetoes.
+  const unsigned long long lds_cap = (unsigned long long)gcr_tile_sort_capacity();
+  unsigned long long cap_list = lds_cap;
+  bool long_lists = false;
+  if (tile_list_capacity > 0 && (unsigned long long)tile_list_capacity > lds_cap) {
+    cap_list = ~0ull;
+    long_lists = true;
+  } else if (tile_list_capacity > 0 && (unsigned long long)tile_list_capacity < cap_list) {
     cap_list = 64;  // round the guess up to a power of two: that is what the LDS sort allocates
     while (cap_list < (unsigned long long)tile_list_capacity) cap_list <<= 1;
   }
@@ -403,7 +413,8 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
   if (speculate) {
     // Everything else of the frame is enqueued before the host knows R: the kernels read the
     // tile ranges from device memory and are vetoed by frame[2] if the capacity guess was short.
-    if (int rc = enqueue_render_lds(cam, g, geom, binning, img, binning_capacity, (int64_t)cap_list, true,
+    if (int rc = enqueue_render_lds(cam, g, geom, binning, img, binning_capacity,
+                                    (int64_t)(long_lists ? lds_cap : cap_list), long_lists, true,
                                     (unsigned long long)binning_capacity, cap_list, out_color, s))
       return rc;
   }
@@ -435,13 +446,14 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   if (img_bytes < L.img_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "image buffer too small");
   if (R > 0 && binning_bytes < L.bin_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "binning buffer too small");
   hipStream_t s = (hipStream_t)hip_stream;
-  const bool lds_sort = !g_force_radix.load() && info->max_tile_instances <= gcr_tile_sort_capacity();
-  if (R == 0 || lds_sort)
-    return enqueue_render_lds(cam, g, geom, binning, img, R, info->max_tile_instances, false, ~0ull, ~0ull,
-                              out_color, s);
+  // Tile lists beyond the LDS sort capacity are sorted per tile by k_tile_sort_long; every other tile stays
+  // on the LDS path (no whole-frame fallback for a long list).
+  if (R == 0 || !g_force_radix.load())
+    return enqueue_render_lds(cam, g, geom, binning, img, R, info->max_tile_instances,
+                              info->max_tile_instances > gcr_tile_sort_capacity(), false, ~0ull, ~0ull, out_color, s);
 
-  // Fallback (a tile list longer than the LDS capacity, or "force_radix"): the reference's own
-  // scheme -- emit tile|depth keys in index order, stable global radix sort, boundary scan.
+  // "force_radix" (A/B and test option): the reference's own scheme -- emit tile|depth keys in index
+  // order, stable global radix sort, boundary scan.
   char *gb = (char*)geom, *bb = (char*)binning, *ib = (char*)img;
   const int gx = (cam->img_w + GCR_BLOCK_X - 1) / GCR_BLOCK_X;
   const int gy = (cam->img_h + GCR_BLOCK_Y - 1) / GCR_BLOCK_Y;

@@ -273,17 +273,51 @@ __global__ __launch_bounds__(256) void k_scatter_instances(int chunk, const uint
 // One workgroup per tile sorts the tile's n <= capacity keys in LDS and writes the Gaussian
 // indices (low 32 bits) to the sorted list: chunked rank sort + merge for n <= RANK_MERGE_MAX, bitonic network (padded to a
 // power of two with ~0) above.
+// In-LDS bitonic network over s[0, N2) (N2 a power of two >= 2, keys padded with ~0), 256 threads.
+// Wave w owns the contiguous span [w*N2/4, (w+1)*N2/4): a stage whose pairs (a, a|j) stay inside a span
+// (2j <= span) only needs the wave's own LDS ordering, so block barriers are paid only for the few
+// long-stride stages (3 of 55 for N2 = 1024).  Ends with a block barrier.
+GCR_DEV void gcr_bitonic_sort_lds(uint64_t* s, int N2, int tid) {
+  const int half = N2 >> 1, wave_pairs = half >> 2;  // pairs per wave and stage
+  const int lane = tid & 63, w = tid >> 6;
+  const int span = N2 >> 2;
+  bool prev_local = false;
+  for (int k = 2; k <= N2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const bool local = 2 * j <= span;
+      if (!local && prev_local) __syncthreads();  // other waves' spans are about to be read
+      for (int t = lane; t < wave_pairs; t += 64) {
+        const int i = w * wave_pairs + t;
+        const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int b = a | j;
+        const uint64_t x = s[a], y = s[b];
+        const bool ascending = (a & k) == 0;
+        if ((x > y) == ascending) {
+          s[a] = y;
+          s[b] = x;
+        }
+      }
+      if (local)
+        __builtin_amdgcn_wave_barrier();
+      else
+        __syncthreads();
+      prev_local = local;
+    }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ ranges,
                                                    const uint64_t* __restrict__ pairs,
                                                    uint32_t* __restrict__ list,
-                                                   const unsigned long long* __restrict__ frame) {
+                                                   const unsigned long long* __restrict__ frame, int lds_capacity) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
   uint64_t* s = reinterpret_cast<uint64_t*>(gcr_smem);
   if (frame != nullptr && frame[2] == 0ull) return;  // speculative launch vetoed
   const int tid = threadIdx.x;
   const uint32_t r0 = ranges[2 * blockIdx.x], r1 = ranges[2 * blockIdx.x + 1];
   const int n = (int)(r1 - r0);
-  if (n <= 0) return;
+  if (n <= 0 || n > lds_capacity) return;  // longer lists belong to k_tile_sort_long
   if (n == 1) {
     if (tid == 0) list[r0] = (uint32_t)pairs[r0];
     return;
@@ -354,37 +388,88 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
   while (N2 < n) N2 <<= 1;
   for (int i = tid; i < N2; i += 256) s[i] = i < n ? pairs[r0 + i] : ~0ull;
   __syncthreads();
-  // Bitonic network.  Wave w owns the contiguous span [w*N2/4, (w+1)*N2/4): a stage whose pairs
-  // (a, a|j) stay inside a span (2j <= span) only needs the wave's own LDS ordering, so block
-  // barriers are paid only for the few long-stride stages (3 of 55 for N2 = 1024).
-  const int half = N2 >> 1, wave_pairs = half >> 2;  // pairs per wave and stage
-  const int lane = tid & 63, w = tid >> 6;
-  const int span = N2 >> 2;
-  bool prev_local = false;
-  for (int k = 2; k <= N2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const bool local = 2 * j <= span;
-      if (!local && prev_local) __syncthreads();  // other waves' spans are about to be read
-      for (int t = lane; t < wave_pairs; t += 64) {
-        const int i = w * wave_pairs + t;
-        const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-        const int b = a | j;
-        const uint64_t x = s[a], y = s[b];
-        const bool ascending = (a & k) == 0;
-        if ((x > y) == ascending) {
-          s[a] = y;
-          s[b] = x;
+  gcr_bitonic_sort_lds(s, N2, tid);
+  for (int i = tid; i < n; i += 256) list[r0 + i] = (uint32_t)s[i];
+}
+
+// Tile lists LONGER than the LDS sort capacity (dense general 3DGS scenes; GaussianCity's own scenes have
+// ~150 entries per tile): one workgroup per such tile, everything else returns at once.
+//   1. runs of LONG_RUN keys are sorted in LDS (the bitonic network above) and written back in place;
+//   2. log2(#runs) merge passes ping-pong between the key buffer and its spare half: every thread produces
+//      a contiguous slice of each merged pair, located with a merge-path binary search (keys are unique);
+//   3. the Gaussian indices (low 32 bits) go to the sorted list.
+// The other tiles of the frame stay on k_tile_sort: a long list no longer sends the whole frame to the
+// global radix sort (cr/rasterizer_impl.cu:252-260 sorts everything globally; the order produced is the same).
+constexpr int LONG_RUN = 4096;
+
+__global__ __launch_bounds__(256) void k_tile_sort_long(const uint32_t* __restrict__ ranges,
+                                                        uint64_t* __restrict__ bufA, uint64_t* __restrict__ bufB,
+                                                        uint32_t* __restrict__ list,
+                                                        const unsigned long long* __restrict__ frame,
+                                                        int lds_capacity) {
+  __shared__ uint64_t s[LONG_RUN];
+  if (frame != nullptr && frame[2] == 0ull) return;  // speculative launch vetoed
+  const int tid = threadIdx.x;
+  const uint32_t r0 = ranges[2 * blockIdx.x], r1 = ranges[2 * blockIdx.x + 1];
+  const uint32_t n = r1 - r0;
+  if (n <= (uint32_t)lds_capacity) return;
+  uint64_t* __restrict__ A = bufA + r0;
+  uint64_t* __restrict__ B = bufB + r0;
+  // 1. sorted runs
+  for (uint32_t c0 = 0; c0 < n; c0 += LONG_RUN) {
+    const uint32_t len = min((uint32_t)LONG_RUN, n - c0);
+    for (uint32_t i = tid; i < (uint32_t)LONG_RUN; i += 256) s[i] = i < len ? A[c0 + i] : ~0ull;
+    __syncthreads();
+    gcr_bitonic_sort_lds(s, LONG_RUN, tid);
+    for (uint32_t i = tid; i < len; i += 256) A[c0 + i] = s[i];
+    __syncthreads();
+  }
+  // 2. merge passes
+  uint64_t* src = A;
+  uint64_t* dst = B;
+  for (uint32_t run = LONG_RUN; run < n; run <<= 1) {
+    for (uint32_t p0 = 0; p0 < n; p0 += 2 * run) {
+      const uint32_t la = min(run, n - p0);
+      const uint32_t lb = p0 + run < n ? min(run, n - p0 - run) : 0u;
+      const uint64_t* __restrict__ a = src + p0;
+      const uint64_t* __restrict__ b = src + p0 + run;
+      uint64_t* __restrict__ o = dst + p0;
+      const uint32_t tot = la + lb;
+      const uint32_t per = (tot + 255u) / 256u;
+      const uint32_t d0 = min(tot, (uint32_t)tid * per), d1 = min(tot, d0 + per);
+      if (d0 < d1) {
+        // merge path: the first d0 outputs take i keys of a and d0-i of b, i = the smallest index with
+        // a[i] > b[d0-1-i] (unique keys: no ties)
+        uint32_t lo = d0 > lb ? d0 - lb : 0u, hi = min(d0, la);
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (a[mid] < b[d0 - 1 - mid])
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        uint32_t i = lo, j = d0 - lo;
+        uint64_t ka = i < la ? a[i] : ~0ull, kb = j < lb ? b[j] : ~0ull;
+        for (uint32_t k = d0; k < d1; k++) {
+          if (ka < kb) {
+            o[k] = ka;
+            i++;
+            ka = i < la ? a[i] : ~0ull;
+          } else {
+            o[k] = kb;
+            j++;
+            kb = j < lb ? b[j] : ~0ull;
+          }
         }
       }
-      if (local)
-        __builtin_amdgcn_wave_barrier();
-      else
-        __syncthreads();
-      prev_local = local;
     }
+    __syncthreads();  // the pass is complete (workgroup-scope visibility of the global stores) before it is read
+    uint64_t* t = src;
+    src = dst;
+    dst = t;
   }
-  __syncthreads();
-  for (int i = tid; i < n; i += 256) list[r0 + i] = (uint32_t)s[i];
+  // 3. Gaussian indices
+  for (uint32_t i = tid; i < n; i += 256) list[r0 + i] = (uint32_t)src[i];
 }
 
 // ------------------------------------------------------------------------------------- K4
@@ -634,16 +719,22 @@ hipError_t gcr_launch_tiles_touched(int P, int nblocks, int chunk, const uint32_
   return hipGetLastError();
 }
 
-int gcr_tile_sort_capacity(void) { return 4096; }  // 32 KiB of LDS per workgroup at most
+int gcr_tile_sort_capacity(void) { return LONG_RUN; }  // 32 KiB of LDS per workgroup at most
 
-hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, const uint64_t* pairs, uint32_t* list,
-                                int64_t max_tile_instances, const unsigned long long* frame, hipStream_t s) {
+// `max_tile_instances`: longest list the caller expects (sizes the LDS of k_tile_sort, at most the capacity);
+// `long_lists`: some list may exceed the LDS capacity -> also launch the per-tile long-list sort, which needs
+// the spare key buffer `pairs_spare` (same size as `pairs`).
+hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, uint64_t* pairs, uint64_t* pairs_spare,
+                                uint32_t* list, int64_t max_tile_instances, bool long_lists,
+                                const unsigned long long* frame, hipStream_t s) {
   if (T <= 0) return hipSuccess;
+  const int cap = gcr_tile_sort_capacity();
   size_t n2 = 64;
-  while ((int64_t)n2 < max_tile_instances) n2 <<= 1;
+  while ((int64_t)n2 < max_tile_instances && n2 < (size_t)cap) n2 <<= 1;
   // bitonic path: n2 keys; rank/merge path (<= RANK_MERGE_MAX keys): two buffers of n rounded up to 64
   const size_t lds = n2 <= (size_t)RANK_MERGE_MAX ? 2 * n2 * sizeof(uint64_t) : n2 * sizeof(uint64_t);
-  k_tile_sort<<<T, 256, lds, s>>>(ranges, pairs, list, frame);
+  k_tile_sort<<<T, 256, lds, s>>>(ranges, pairs, list, frame, (int)n2);
+  if (long_lists) k_tile_sort_long<<<T, 256, 0, s>>>(ranges, pairs, pairs_spare, list, frame, (int)n2);
   return hipGetLastError();
 }
 

@@ -117,8 +117,9 @@ hipError_t gcr_launch_scatter_instances(int nblocks, int chunk, const uint32_t* 
                                         uint32_t* tile_cursor, uint64_t* pairs, const uint32_t* ranges, int T,
                                         const unsigned long long* frame, hipStream_t s);
 int gcr_tile_sort_capacity(void);  // longest per-tile list the LDS sort accepts
-hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, const uint64_t* pairs, uint32_t* list,
-                                int64_t max_tile_instances, const unsigned long long* frame, hipStream_t s);
+hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, uint64_t* pairs, uint64_t* pairs_spare,
+                                uint32_t* list, int64_t max_tile_instances, bool long_lists,
+                                const unsigned long long* frame, hipStream_t s);
 // Stable LSD radix sort of R (u64 key, u32 value) pairs on bits [0, end_bit).  Ping-pongs
 // between (k0,v0) and (k1,v1); returns in *sorted_half which half holds the result.
 size_t gcr_sort_hist_bytes(int64_t R, int end_bit);

@@ -101,6 +101,25 @@ def s_city(P, seed, sh_degree=3):
                 colors_precomp=colors, shs=shs, sh_degree=sh_degree)
 
 
+def s_dense(P, seed, sh_degree=3, sigma=110.0):
+    """S-dense: a general-3DGS-like stress scene (NOT a GaussianCity workload): anisotropic, rotated,
+    mostly translucent Gaussians (opacity U(.02,.5)) piled up around the orbit centre with a normal density
+    (x,y ~ N(1024, sigma), z ~ U(0,80)), scales exp(U(ln .6, ln 8)) per axis.  From the inference orbit this
+    gives thousands of list entries per tile, the central tiles beyond the 4096-entry LDS sort capacity."""
+    rng = np.random.default_rng(seed)
+    xyz = np.empty((P, 3), dtype=np.float32)
+    xyz[:, 0] = PROJ_SIZE // 2 + rng.normal(0, sigma, P)
+    xyz[:, 1] = PROJ_SIZE // 2 + rng.normal(0, sigma, P)
+    xyz[:, 2] = rng.uniform(0, 80, P)
+    scales = np.exp(rng.uniform(math.log(0.6), math.log(8.0), size=(P, 3))).astype(np.float32)
+    rot = rng.normal(size=(P, 4))
+    rot /= np.linalg.norm(rot, axis=1, keepdims=True)
+    opacity = rng.uniform(0.02, 0.5, size=(P, 1)).astype(np.float32)
+    colors = rng.uniform(-1.0, 1.0, size=(P, 3)).astype(np.float32)
+    return dict(means3D=xyz, scales=scales, rotations=rot.astype(np.float32), opacities=opacity,
+                colors_precomp=colors, shs=_sh(rng, P, sh_degree), sh_degree=sh_degree)
+
+
 def grad_image(W, H, seed):
     """dL/d(out_color) ~ N(0,1) [3,H,W] with a fixed seed (backward tests / bench)."""
     return np.random.default_rng(seed + 77).normal(size=(3, H, W)).astype(np.float32)
@@ -114,6 +133,9 @@ CONFIGS = {
     "C4": dict(scene="s_city", P=16_384, W=960, H=540, sh_degree=0, seed=1004, backward=True,
                crop=(640, 448), precomp_color=True),
     "C5": dict(scene="s_city", P=20_000_000, W=3840, H=2160, sh_degree=3, seed=1005, backward=False),
+    # not a BASELINE config: dense general-3DGS-like stress scene (long tile lists), informational
+    "D1": dict(scene="s_dense", P=2_700_000, W=1920, H=1080, sh_degree=3, seed=1006, backward=False,
+               sigma=330.0),
 }
 
 
@@ -121,8 +143,11 @@ def make_scene(name, P=None):
     cfg = dict(CONFIGS[name])
     if P is not None:
         cfg["P"] = int(P)
-    gen = s_rand if cfg["scene"] == "s_rand" else s_city
-    scene = gen(cfg["P"], cfg["seed"], cfg["sh_degree"])
+    if cfg["scene"] == "s_dense":
+        scene = s_dense(cfg["P"], cfg["seed"], cfg["sh_degree"], cfg.get("sigma", 110.0))
+    else:
+        gen = s_rand if cfg["scene"] == "s_rand" else s_city
+        scene = gen(cfg["P"], cfg["seed"], cfg["sh_degree"])
     return cfg, scene
 
 

@@ -136,7 +136,8 @@ typedef struct gcr_layout {
  * gcr_forward_render (the library keeps no state between calls). */
 typedef struct gcr_frame_info {
   int64_t num_rendered;       /* R: total (Gaussian,tile) instances == the reference's return value */
-  int64_t max_tile_instances; /* longest per-tile list; selects the binning strategy */
+  int64_t max_tile_instances; /* longest per-tile list: sizes the per-tile sort (lists beyond the LDS
+                                 capacity of 4096 are sorted per tile by a merge sort through HBM) */
 } gcr_frame_info;
 
 int gcr_abi_version(void);
@@ -158,14 +159,17 @@ int gcr_forward_preprocess(const gcr_camera *cam, const gcr_gaussians *g, void *
 /* Whole forward in ONE call without a mid-frame host stall.  `binning` must hold
  * gcr_binning_bytes(binning_capacity) bytes; binning_capacity is the caller's guess of
  * num_rendered (e.g. 1.5 x the previous frame's value; 0 = no guess) and tile_list_capacity its
- * guess of the longest per-tile list (sizes the LDS of the per-tile sort; 0 = the maximum the
- * LDS sort supports).  All kernels of the frame
+ * guess of the longest per-tile list (0 = the LDS sort's capacity, 4096): a guess within that
+ * capacity sizes the LDS of the per-tile sort and a longer list vetoes the speculation; a guess
+ * beyond it declares a scene with long lists -- the per-tile long-list sort (sorted 4096-key runs
+ * merged through the spare key buffer) is enqueued as well and the list length never vetoes.
+ * All kernels of the frame
  * are enqueued at once -- they take the tile ranges from device memory and a device-side flag
  * vetoes them if the guess was too small -- and the host waits only for the 24-byte frame
  * summary, which lands in pinned memory as soon as K2 is done.
  * Returns 0: frame complete, *info_host valid.
- * Returns 1 (GCR_RETRY_RENDER): *info_host valid, nothing rendered yet (guess too small, a
- *   tile list longer than the LDS sort capacity, or "force_radix"): allocate
+ * Returns 1 (GCR_RETRY_RENDER): *info_host valid, nothing rendered yet (a guess was too small, or
+ *   "force_radix"): allocate
  *   gcr_binning_bytes(info_host->num_rendered) and call gcr_forward_render.
  * Returns <0: error. */
 #define GCR_RETRY_RENDER 1

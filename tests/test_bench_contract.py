@@ -34,13 +34,19 @@ def _check(line, with_cpu=True):
 
 def test_committed_bench_lines_follow_the_contract():
     for name, cpu in (("r01_bench_c3.json", True), ("r01_bench_visibility.json", True), ("r01_bench_grid_encoder.json", True),
-                      ("r01_bench_c5.json", False)):
+                      ("r01_bench_c5.json", False), ("r02_bench_c3.json", True)):
         line = json.load(open(os.path.join(ROOT, "profiles", name)))
         _check(line, cpu)
     c3 = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_c3.json")))
     assert c3["unit"] == "frames/s" and "5000000 Gaussians, 1920x1080" in c3["metric"] and c3["scaling"] == "weak"
     assert c3["cpu_baseline"]["gpu_image_bit_exact_vs_cpu"] is True
     assert json.load(open(os.path.join(ROOT, "profiles", "r01_bench_visibility.json")))["cpu_baseline"]["kind"] == "reference"
+    r2 = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_c3.json")))
+    assert r2["cpu_baseline"]["gpu_image_bit_exact_vs_cpu"] is True and "C1" in r2["cpu_baseline"]
+    sec = r2["secondary"]                     # C2 forward+backward: stats, per-stage bytes, K7 roofline, CPU baseline
+    assert sec["unit"] == "ms/frame" and sec["roofline"]["kernel"] == "blend_bwd" and "frame_stats" in sec
+    assert sec["cpu_baseline"]["gpu_image_bit_exact_vs_cpu"] is True
+    assert sec["cpu_baseline"]["worst_gradient_error_over_max"] <= 1e-4
 
 
 def test_bench_cli_surface():

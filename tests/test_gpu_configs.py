@@ -263,3 +263,20 @@ def test_inference_loop_frames_equal_the_oracle(oracle_mod, cuda_device):
         want = frames.InferenceLoop.to_uint8_hwc(torch.from_numpy(np.ascontiguousarray(fr.out_color[:, :, ::-1]))).numpy()
         assert np.array_equal(frame, want)
     assert any(f.any() for f in got)
+
+
+def test_dense_3dgs_like_scene_long_lists(oracle_mod, cuda_device):
+    """General-3DGS-like stress scene (synth.s_dense; not a GaussianCity workload, the API must still support it):
+    ~2000 list entries per tile on average, the central tiles beyond the 4096-entry LDS sort capacity, early
+    termination active.  Forward state, image and gradients against the oracle."""
+    P, W, H = 300_000, 640, 360
+    sc = synth.s_dense(P, 7)
+    rs = scenes.camera(W, H, pose_index=5, radius=512.0, altitude=640.0)._replace(sh_degree=3)
+    fr = _frame(oracle_mod, rs, sc)
+    lens = fr.ranges[:, 1].astype(np.int64) - fr.ranges[:, 0]
+    assert lens.mean() > 2000 and (lens > 4096).sum() >= 3 and fr.consumed_entries() < 0.8 * fr.R
+    for _ in range(2):   # staged, then speculative with the long-list hint
+        args, out = G.run_forward(rs, sc, cuda_device)
+        _check_forward(fr, G.decode(P, W, H, out), P, True)
+    dpix = synth.grad_image(W, H, 7)
+    _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device), ALL_GRADS)
