@@ -16,7 +16,10 @@ POSE_FIELDS = ("id", "tx", "ty", "tz", "qx", "qy", "qz", "qw")
 
 
 def write_points_pkl(path, prj, vpm, msk, pts):
-    """prj: dict of local BEV maps, vpm: [H,W] visible-point map (-1 = none), msk: [H,W] bool, pts: [N,5] int16."""
+    """prj: dict of local BEV maps; pts: [N,5] int16, ONLY the points visible in this view, in ascending order
+    of their original index; vpm: [H,W] index into `pts` of the point each pixel sees -- upstream re-indexes with
+    np.searchsorted over the visible ids (scripts/dataset_generator.py:1606-1617), so a pixel that sees nothing
+    holds 0, not -1; msk: [H,W] bool."""
     with open(path, "wb") as fp:
         pickle.dump({"prj": prj, "vpm": vpm, "msk": msk, "pts": pts}, fp)
 
@@ -44,10 +47,17 @@ def read_camera_poses_csv(path):
         return {int(r["id"]): r for r in csv.DictReader(fp)}
 
 
-def pose_arrays(row):
-    """One CSV row -> (cam_pos float32 [3], cam_quat float32 [4] in (x, y, z, w)), utils/datasets.py:119-127."""
-    return (np.array([row["tx"], row["ty"], row["tz"]], dtype=np.float32),
-            np.array([row["qx"], row["qy"], row["qz"], row["qw"]], dtype=np.float32))
+# cfg.DATASETS.<name>.SCALE / MAP_SIZE of the reference (config.py:45-46,73-74)
+DATASET_CONSTANTS = {"GOOGLE_EARTH": {"SCALE": 1, "MAP_SIZE": 2048}, "KITTI_360": {"SCALE": 1, "MAP_SIZE": 0}}
+
+
+def pose_arrays(row, scale=1, map_size=0):
+    """One CSV row -> (cam_pos float32 [3], cam_quat float32 [4] in (x, y, z, w)) normalised to the map the way
+    utils/datasets.py:119-127 and scripts/dataset_generator.py:1543-1549 do: position / SCALE, then x and y
+    shifted by MAP_SIZE // 2.  The defaults leave the CSV values as they are."""
+    pos = np.array([row["tx"], row["ty"], row["tz"]], dtype=np.float32) / scale
+    pos[:2] += map_size // 2
+    return pos, np.array([row["qx"], row["qy"], row["qz"], row["qw"]], dtype=np.float32)
 
 
 def save_checkpoint(path, cfg, epoch_index, gaussian_g, gaussian_d=None):
@@ -58,10 +68,48 @@ def save_checkpoint(path, cfg, epoch_index, gaussian_g, gaussian_d=None):
     torch.save(ckpt, path)
 
 
+def _ensure_easydict():
+    """Upstream checkpoints pickle their `cfg` as easydict.EasyDict (config.py:10, core/train.py:376-380).  When that
+    package is not installed, a minimal attribute-access dict under the same module/class name lets them unpickle."""
+    import sys
+    try:
+        import easydict  # noqa: F401
+        return
+    except ImportError:
+        pass
+    import types
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            super().__setitem__(k, v)
+
+        __setattr__ = __setitem__
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+    EasyDict.__module__ = "easydict"
+    EasyDict.__qualname__ = "EasyDict"
+    mod = types.ModuleType("easydict")
+    mod.EasyDict = EasyDict
+    sys.modules["easydict"] = mod
+
+
 def load_checkpoint(path, map_location="cpu"):
     """Returns the dict; `gaussian_g` is the generator's state_dict -- its `pos_encoder.embeddings` /
     `pos_encoder.offsets` entries load into gaussiancity_amd.grid_encoder.GridEncoder unchanged."""
     import torch
+    _ensure_easydict()
     ckpt = torch.load(path, map_location=map_location, weights_only=False)
     for k in ("cfg", "epoch_index", "gaussian_g"):
         if k not in ckpt:
@@ -69,14 +117,24 @@ def load_checkpoint(path, map_location="cpu"):
     return ckpt
 
 
-def replay_visible_points(points_pkl, pose_row, cam_rig, null_class_id=0):
+def replay_visible_points(points_pkl, pose_row, cam_rig, dataset="GOOGLE_EARTH", null_class_id=0):
     """Recomputes the stored `vpm` of one dataset frame with this build's visibility path and returns
-    (vp_map, stored_vpm, fraction_equal) -- the end-to-end check to run once real data is at hand."""
+    (vp_map, stored_vpm, fraction_equal) -- the end-to-end check to run once real data is at hand.
+
+    Follows how upstream produced the file (scripts/dataset_generator.py:1543-1549,1591-1617): the camera position
+    is the CSV row divided by SCALE and shifted by MAP_SIZE // 2; cube sides are column 3 (get_point_scales without
+    special classes); KITTI-360 maps are flipped left-right; the stored `pts` are only the points visible in the
+    view (a first hit stays a first hit when hidden points are removed, so tracing them alone reproduces the map)
+    and the stored `vpm` was re-indexed with np.searchsorted, which sends "no hit" (-1) to 0."""
     from . import points as P
     d = read_points_pkl(points_pkl) if isinstance(points_pkl, str) else points_pkl
     pts = np.asarray(d["pts"], np.int16)
     scales = np.repeat(pts[:, [3]], 3, axis=1)
-    cam_pos, cam_quat = pose_arrays(pose_row)
+    c = DATASET_CONSTANTS[dataset]
+    cam_pos, cam_quat = pose_arrays(pose_row, c["SCALE"], c["MAP_SIZE"])
     vp, _ = P.get_visible_points(pts, scales, cam_rig, cam_pos.astype(np.float64), cam_quat.astype(np.float64), null_class_id)
+    if dataset == "KITTI_360":
+        vp = np.fliplr(vp)
+    vp = np.where(vp < 0, 0, vp)  # what np.searchsorted(visible_ids, -1) yields upstream
     stored = np.asarray(d["vpm"])
     return vp, stored, float((vp == stored).mean()) if vp.shape == stored.shape else 0.0

@@ -240,6 +240,42 @@ def test_get_visible_points_end_to_end(cuda_device, po):
     assert vp3.shape == vp.shape and (vp3 >= 0).mean() > 0.5
 
 
+def test_replay_of_a_dataset_frame_as_the_generator_wrote_it(cuda_device, tmp_path):
+    """Row f4 end to end: a Points/%04d.pkl + CameraPoses.csv pair produced the way scripts/dataset_generator.py
+    produces them (:1543-1549 camera normalisation, :1591-1617 visible-only points re-indexed with searchsorted,
+    KITTI-360 flipped) is replayed by formats.replay_visible_points and reproduces the stored map exactly."""
+    from gaussiancity_amd import formats as F
+    size = 256
+    L = synth.s_layout(size, 2301, block=64, road=8, max_height=60)
+    inv = {v: k for k, v in synth.LAYOUT_CLASSES.items()}
+    points = P.get_points_from_projection(True, inv, synth.LAYOUT_SCALES, synth.LAYOUT_SEG_INS, L["INS"], L["TD_HF"],
+                                          L["BU_HF"], L["PTS"]).astype(np.int16)
+    scales = np.repeat(points[:, [3]], 3, axis=1)
+    rig, cam_pos, cam_quat = synth.layout_camera(size, W=200, H=120)
+    for dataset in ("GOOGLE_EARTH", "KITTI_360"):
+        c = F.DATASET_CONSTANTS[dataset]
+        # the CSV stores the pose BEFORE normalisation: invert cam_pos = csv / SCALE + MAP_SIZE // 2
+        csv_pos = cam_pos.astype(np.float32).copy()
+        csv_pos[:2] -= c["MAP_SIZE"] // 2
+        csv_pos *= c["SCALE"]
+        row = dict(id=7, tx=float(csv_pos[0]), ty=float(csv_pos[1]), tz=float(csv_pos[2]),
+                   qx=float(cam_quat[0]), qy=float(cam_quat[1]), qz=float(cam_quat[2]), qw=float(cam_quat[3]))
+        F.write_camera_poses_csv(str(tmp_path / "CameraPoses.csv"), [row])
+        row_read = F.read_camera_poses_csv(str(tmp_path / "CameraPoses.csv"))[7]
+        pos_n, quat_n = F.pose_arrays(row_read, c["SCALE"], c["MAP_SIZE"])
+        vp, _ = P.get_visible_points(points, scales, rig, pos_n.astype(np.float64), quat_n.astype(np.float64), 0)
+        if dataset == "KITTI_360":
+            vp = np.fliplr(vp)
+        vp_idx = np.sort(np.unique(vp))
+        vp_idx = vp_idx[vp_idx >= 0]
+        stored_pts, stored_vpm = points[vp_idx], np.searchsorted(vp_idx, vp)
+        assert len(stored_pts) < len(points) and (vp < 0).any()
+        pkl = str(tmp_path / ("%04d.pkl" % 7))
+        F.write_points_pkl(pkl, {k: L[k] for k in ("INS", "SEG", "TD_HF", "BU_HF", "PTS")}, stored_vpm, vp >= 0, stored_pts)
+        got, stored, frac = F.replay_visible_points(pkl, row_read, rig, dataset=dataset)
+        assert frac == 1.0 and np.array_equal(got, stored_vpm)
+
+
 def test_full_size_extruder_properties(cuda_device):
     """BASELINE-size map (2048 x 2048, ~17 M points): order, ranges and hollowness hold; two runs agree."""
     L = synth.s_layout(2048, 2001)
