@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured copy)
-NUMERICS = "gcr-fp32-v1"  # the numerics contract shared by oracle/ and the HIP kernels
+NUMERICS = "gcr-fp32-v2"  # the numerics contract shared by oracle/ and the HIP kernels
 
 
 def higher_msb(n):

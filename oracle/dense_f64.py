@@ -11,6 +11,11 @@ Reference semantics that plain autograd would NOT reproduce are encoded explicit
   * the frustum clamp of t.x,t.y in computeCov2D zeroes dL/dt.x but differentiates the rest
     as if the clamped t.x were a constant (cr/backward.cu:168-171,268-273)
                                                   -> clamped value detached;
+  * d(loss)/d(scale) as the reference returns it is the true derivative DIVIDED by scale_modifier:
+    cr/backward.cu:342-344 takes dot(Rt[i], dL_dMt[i]) for M = (mod*S) R without the chain-rule factor
+    `mod` (harmless for GaussianCity, which always passes scale_modifier = 1, dgr/__init__.py:393)
+                                                  -> callers divide autograd's scale gradient by mod
+                                                     (tests/test_oracle.py:_dense);
   * radius, tile rectangle, depth order, the power>0 / alpha<1/255 / T<1e-4 tests are
     discrete decisions without gradient; decisions are taken on float32-rounded values
     where the reference stores float32 (depth, pixel centre, radius).

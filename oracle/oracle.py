@@ -88,6 +88,7 @@ def lib():
         L.orc_expf.argtypes = [C.c_float]
         L.orc_higher_msb.restype = C.c_uint32
         L.orc_higher_msb.argtypes = [C.c_uint32]
+        L.orc_set_exp_bias.argtypes = [C.c_int]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -217,6 +218,11 @@ def mark_visible(means3D, view_matrix, proj_matrix):
 
 def expf(x):
     return float(lib().orc_expf(C.c_float(x)))
+
+
+def set_exp_bias(ulps):
+    """Census knob: shift every exp() result by `ulps` (0 restores the contract).  See gcr_oracle.c."""
+    lib().orc_set_exp_bias(int(ulps))
 
 
 def num_threads():
