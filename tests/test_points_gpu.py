@@ -252,6 +252,8 @@ def test_replay_of_a_dataset_frame_as_the_generator_wrote_it(cuda_device, tmp_pa
                                           L["BU_HF"], L["PTS"]).astype(np.int16)
     scales = np.repeat(points[:, [3]], 3, axis=1)
     rig, cam_pos, cam_quat = synth.layout_camera(size, W=200, H=120)
+    rig["intrinsics"][0] *= 0.3   # a wide field of view: part of the image looks past the map's edge ("no hit" pixels)
+    rig["intrinsics"][4] *= 0.3
     for dataset in ("GOOGLE_EARTH", "KITTI_360"):
         c = F.DATASET_CONSTANTS[dataset]
         # the CSV stores the pose BEFORE normalisation: invert cam_pos = csv / SCALE + MAP_SIZE // 2
