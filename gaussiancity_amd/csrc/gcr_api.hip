@@ -207,9 +207,11 @@ int gcr_get_stage_ms(float* ms_out, int capacity) {
 
 // Enqueues K1 + tile counting + tile scan; leaves {R, longest list, go flag} in the geometry
 // buffer (*frame_dev_out).  cap_* only influence the go flag used by speculative launches.
+// `host_R` (optional): pinned word that receives (seq << 32 | num_rendered) as soon as K1 is done.
 static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes,
                               void* img, size_t img_bytes, int32_t* radii, unsigned long long cap_instances,
-                              unsigned long long cap_list, unsigned long long** frame_dev_out, hipStream_t s) {
+                              unsigned long long cap_list, unsigned long long** frame_dev_out, hipStream_t s,
+                              unsigned long long* host_R = nullptr, unsigned int seq = 0) {
   if (!geom || !radii || !img) return fail(GCR_ERR_INVALID_ARGUMENT, "geom/img/radii must be non-null");
   gcr_layout L;
   compute_layout(g->P, cam->img_w, cam->img_h, 0, &L);
@@ -242,6 +244,9 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
   a.cand_count = (uint32_t*)(gb + L.geom_block_sums);
   gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &a.nblocks, &a.chunk);
   unsigned long long* frame = (unsigned long long*)(gb + L.geom_num_rendered);
+  a.frame = frame;
+  a.host_R = host_R;
+  a.seq = seq;
   *frame_dev_out = frame;
   int G = 1;
   const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, a.nblocks, &G);
@@ -277,9 +282,9 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
 // Enqueues scatter + per-tile LDS sort + forward blend (the default binning path).
 // `frame_guard` (device {R, max, go}) makes the three kernels no-ops when go == 0.
 static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, void* geom, void* binning, void* img,
-                              int64_t R_layout, int64_t lds_list_capacity, bool long_lists, bool speculative,
+                              int64_t R_layout, int64_t list_length_hint, bool speculative,
                               unsigned long long cap_instances, unsigned long long cap_list, float* out_color,
-                              hipStream_t s) {
+                              hipStream_t s, unsigned long long* host_longest = nullptr) {
   gcr_layout L;
   compute_layout(g->P, cam->img_w, cam->img_h, R_layout, &L);
   char *gb = (char*)geom, *bb = (char*)binning, *ib = (char*)img;
@@ -305,7 +310,8 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
       uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
       HIP_TRY(gcr_launch_tile_scatter(T, gx, NG, G, nblocks, chunk, vis_list, vis_count, rec,
                                       (uint32_t*)(ib + L.img_tile_table), cursor, cursor + (size_t)T,
-                                      cursor + 2 * (size_t)T, ranges, pairs, frame_dev, cap_instances, cap_list, s),
+                                      cursor + 2 * (size_t)T, ranges, pairs, frame_dev, cap_instances, cap_list,
+                                      host_longest, s),
               "tile scatter");
     } else if (R_layout > 0) {
       HIP_TRY(gcr_launch_scatter_instances(nblocks, chunk, vis_list, vis_count, rec, gx,
@@ -316,8 +322,7 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   if (int rc = debug_sync(cam, s, "scatter instances")) return rc;
   if (R_layout > 0) {
     StageTimer t(s, ST_SORT);
-    HIP_TRY(gcr_launch_tile_sort(ranges, T, pairs, (uint64_t*)(bb + L.bin_keys[1]), list, lds_list_capacity, long_lists,
-                                 frame_guard, s),
+    HIP_TRY(gcr_launch_tile_sort(ranges, T, pairs, (uint64_t*)(bb + L.bin_keys[1]), list, list_length_hint, frame_guard, s),
             "tile sort");
   }
   if (int rc = debug_sync(cam, s, "tile sort")) return rc;
@@ -340,14 +345,23 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
 }
 
 // pinned landing zone + event for the asynchronous {R, max, go} read-back (per host thread)
+// num_rendered reaches the host WITHOUT a copy: the last block of the exact projection pass stores
+// (frame tag << 32 | R) into a pinned, coherent host word and the host thread polls that word.  Compared with
+// the reference's blocking cudaMemcpy (cr/rasterizer_impl.cu:236) -- and with round 1's 24-byte async copy +
+// event after the column scan -- the host is released as soon as K1 is done (the tile-table kernels, the
+// scatter, the sort and the blend of the frame are enqueued but still to run), and a frame costs no
+// hipMemcpyAsync / hipEventRecord / hipEventSynchronize calls.  pinned[1] receives the frame's longest tile list
+// from the scatter kernel; nobody waits for it, the next call uses it as its length hint.
 struct FrameReadback {
-  unsigned long long* pinned = nullptr;
-  hipEvent_t ev = nullptr;
+  unsigned long long* pinned = nullptr;  // [0] = seq << 32 | R, [1] = longest list of the most recent scatter
+  unsigned int seq = 0;
   int ensure() {
-    if (!pinned && hipHostMalloc((void**)&pinned, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
-      return fail(GCR_ERR_DEVICE, "hipHostMalloc for the frame read-back failed");
-    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
-      return fail(GCR_ERR_DEVICE, "hipEventCreate for the frame read-back failed");
+    if (!pinned) {
+      if (hipHostMalloc((void**)&pinned, 8 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) !=
+          hipSuccess)
+        return fail(GCR_ERR_DEVICE, "hipHostMalloc for the frame read-back failed");
+      for (int i = 0; i < 8; i++) pinned[i] = 0ull;
+    }
     return 0;
   }
 };
@@ -390,43 +404,51 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
   if (int rc = g_readback.ensure()) return rc;
   hipStream_t s = (hipStream_t)hip_stream;
   const bool speculate = binning_capacity > 0 && !g_force_radix.load() && !cam->debug;
-  // Longest tile list the speculative launches are sized for.  A guess within the LDS sort capacity sizes
-  // the LDS of k_tile_sort (a longer list vetoes the speculation); a guess beyond it means "this scene has
-  // long lists": the per-tile long-list sort is enqueued too and the list length never vetoes.
-  const unsigned long long lds_cap = (unsigned long long)gcr_tile_sort_capacity();
-  unsigned long long cap_list = lds_cap;
-  bool long_lists = false;
-  if (tile_list_capacity > 0 && (unsigned long long)tile_list_capacity > lds_cap) {
-    cap_list = ~0ull;
-    long_lists = true;
-  } else if (tile_list_capacity > 0 && (unsigned long long)tile_list_capacity < cap_list) {
-    cap_list = 64;  // round the guess up to a power of two: that is what the LDS sort allocates
-    while (cap_list < (unsigned long long)tile_list_capacity) cap_list <<= 1;
-  }
+  // The longest-list guess only sizes the LDS of the tile sort (any length is sorted correctly), so the
+  // speculation can only be vetoed by num_rendered exceeding the binning capacity.
+  const int64_t list_hint = tile_list_capacity > 0 ? tile_list_capacity : (int64_t)gcr_tile_sort_capacity();
+  FrameReadback& rb = g_readback;
+  const unsigned int seq = ++rb.seq ? rb.seq : ++rb.seq;  // never 0: the word starts out as 0
   unsigned long long* frame = nullptr;
   if (int rc = enqueue_preprocess(cam, g, geom, geom_bytes, img, img_bytes, radii,
-                                  speculate ? (unsigned long long)binning_capacity : 0ull, cap_list, &frame, s))
+                                  speculate ? (unsigned long long)binning_capacity : 0ull, ~0ull, &frame, s,
+                                  rb.pinned, seq))
     return rc;
-  HIP_TRY(hipMemcpyAsync(g_readback.pinned, frame, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s),
-          "frame info copy");
-  HIP_TRY(hipEventRecord(g_readback.ev, s), "frame info event");
   if (speculate) {
     // Everything else of the frame is enqueued before the host knows R: the kernels read the
     // tile ranges from device memory and are vetoed by frame[2] if the capacity guess was short.
-    if (int rc = enqueue_render_lds(cam, g, geom, binning, img, binning_capacity,
-                                    (int64_t)(long_lists ? lds_cap : cap_list), long_lists, true,
-                                    (unsigned long long)binning_capacity, cap_list, out_color, s))
+    if (int rc = enqueue_render_lds(cam, g, geom, binning, img, binning_capacity, list_hint, true,
+                                    (unsigned long long)binning_capacity, ~0ull, out_color, s, rb.pinned + 1))
       return rc;
   }
-  HIP_TRY(hipEventSynchronize(g_readback.ev), "frame info sync");  // the one host wait of the frame
-  const unsigned long long R = g_readback.pinned[0], mx = g_readback.pinned[1];
-  // the same decision the scatter kernel takes on the device from the same two numbers
-  const bool go = R <= (unsigned long long)binning_capacity && mx <= cap_list;
+  // the one host wait of the frame: poll the pinned word until K1b's last block has tagged it with this frame
+  volatile unsigned long long* word = rb.pinned;
+  unsigned long long v = *word;
+  for (unsigned long spins = 0; (unsigned int)(v >> 32) != seq; v = *word) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xffffu) == 0) {  // every ~65k polls: make sure the stream is still alive
+      const hipError_t q = hipStreamQuery(s);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail_hip(q, "frame info wait");
+      if (q == hipSuccess && (unsigned int)(*word >> 32) != seq)
+        return fail(GCR_ERR_DEVICE, "the stream finished without publishing num_rendered");
+    }
+  }
+  const unsigned long long R = v & 0xffffffffull;
+  // the same decision the scatter kernel takes on the device from the same number
+  const bool go = R <= (unsigned long long)binning_capacity;
   if (R > 0x7fffffffull)
     return fail(GCR_ERR_OVERFLOW, "num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)");
   info_host->num_rendered = (int64_t)R;
+  if (speculate && go) {
+    // longest list: what the most recent scatter kernel of this thread published (a hint for the next guess)
+    info_host->max_tile_instances = (int64_t)((volatile unsigned long long*)rb.pinned)[1];
+    return 0;
+  }
+  // retry path: the caller needs the exact longest list of THIS frame to size the sort
+  unsigned long long mx = 0;
+  HIP_TRY(hipMemcpyAsync(&mx, frame + 1, sizeof(mx), hipMemcpyDeviceToHost, s), "longest list copy");
+  HIP_TRY(hipStreamSynchronize(s), "longest list sync");
   info_host->max_tile_instances = (int64_t)mx;
-  if (speculate && go) return 0;
   return 1;  // GCR_RETRY_RENDER: call gcr_forward_render with a binning buffer sized for info_host
 }
 
@@ -446,11 +468,10 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   if (img_bytes < L.img_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "image buffer too small");
   if (R > 0 && binning_bytes < L.bin_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "binning buffer too small");
   hipStream_t s = (hipStream_t)hip_stream;
-  // Tile lists beyond the LDS sort capacity are sorted per tile by k_tile_sort_long; every other tile stays
-  // on the LDS path (no whole-frame fallback for a long list).
+  // Tile lists beyond the LDS sort capacity are sorted by the same workgroup with runs + merge passes; every
+  // other tile stays on the LDS path (no whole-frame fallback for a long list).
   if (R == 0 || !g_force_radix.load())
-    return enqueue_render_lds(cam, g, geom, binning, img, R, info->max_tile_instances,
-                              info->max_tile_instances > gcr_tile_sort_capacity(), false, ~0ull, ~0ull, out_color, s);
+    return enqueue_render_lds(cam, g, geom, binning, img, R, info->max_tile_instances, false, ~0ull, ~0ull, out_color, s);
 
   // "force_radix" (A/B and test option): the reference's own scheme -- emit tile|depth keys in index
   // order, stable global radix sort, boundary scan.

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
                                                            uint64_t* __restrict__ pairs,
                                                            unsigned long long* __restrict__ frame,
                                                            unsigned long long cap_instances,
-                                                           unsigned long long cap_list) {
+                                                           unsigned long long cap_list,
+                                                           unsigned long long* __restrict__ host_longest) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
   uint32_t* cnt = reinterpret_cast<uint32_t*>(gcr_smem);  // [T]
   __shared__ uint32_t pre[TT_MAX_GROUP + 1];              // prefix of the group's list lengths
@@ -88,17 +89,17 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   uint32_t* __restrict__ row = table + (size_t)blockIdx.x * T;
   if (!SCATTER) {
-    if (blockIdx.x == 0 && tid == 0) {  // frame = {R, longest list, go}: accumulated by the column scan
-      frame[0] = 0ull;
-      frame[1] = 0ull;
-      frame[2] = 0ull;
-    }
+    // frame = {R, longest list, go}: zeroed by K1a, R added by K1b, longest list by the column scan
     for (int t = tid; t < T; t += TT_THREADS) cnt[t] = 0u;
   } else {
     // Speculative launch: the host may not know R yet.  Every workgroup takes the same decision
     // from the device-side frame summary; workgroup 0 publishes it for the later kernels.
     const bool go = frame[0] <= cap_instances && frame[1] <= cap_list;
-    if (blockIdx.x == 0 && tid == 0) frame[2] = go ? 1ull : 0ull;
+    if (blockIdx.x == 0 && tid == 0) {
+      frame[2] = go ? 1ull : 0ull;
+      // the frame's longest list, for the host's next length hint (pinned memory, nobody waits for it)
+      if (host_longest != nullptr) gcr_store_to_host(host_longest, frame[1]);
+    }
     if (!go) return;
     // tile starts = exclusive prefix of the 64-tile block totals (<= TT_MAX_TBLOCKS values, so
     // every workgroup redoes this tiny scan instead of paying a single-block kernel for it)
@@ -174,9 +175,9 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
 // table[g][t] (g < NG <= 512) -> exclusive prefix over g in place; tile_total[t] = column sum.
 // Workgroup = 64 tiles x 16 row groups; every thread keeps its <= 32 rows in registers, so the
 // column is read exactly once with all loads in flight.  Wave 0 then scans the workgroup's 64 tile
-// totals (tile_local = exclusive prefix inside the 64-tile block, blk_total = their sum) and adds
-// the block's contribution to the frame summary {R, longest list} with two device-scope atomics
-// (one per 64 tiles -- fire-and-forget, unlike per-instance atomics these are negligible).
+// totals (tile_local = exclusive prefix inside the 64-tile block, blk_total = their sum) and folds
+// the block's longest list into the frame summary with one device-scope atomicMax per 64 tiles
+// (fire-and-forget; R itself was accumulated by K1b so that the host can read it earlier).
 __global__ __launch_bounds__(1024) void k_table_colscan(uint32_t* __restrict__ table, int NG, int T,
                                                         uint32_t* __restrict__ tile_total,
                                                         uint32_t* __restrict__ tile_local,
@@ -226,7 +227,6 @@ __global__ __launch_bounds__(1024) void k_table_colscan(uint32_t* __restrict__ t
     }
     if (lane == 63) {
       blk_total[blockIdx.x] = incl;
-      if (incl) atomicAdd(&frame[0], (unsigned long long)incl);
       if (mx) atomicMax(&frame[1], (unsigned long long)mx);
     }
   }
@@ -307,8 +307,77 @@ GCR_DEV void gcr_bitonic_sort_lds(uint64_t* s, int N2, int tid) {
   __syncthreads();
 }
 
+// A tile list LONGER than the LDS this launch was given (dense general 3DGS scenes beyond the 4096-key maximum;
+// or simply a list that outgrew the caller's length hint -- GaussianCity's own scenes have ~150 entries per
+// tile): the same workgroup sorts it in three steps, everything else of the frame is untouched.
+//   1. runs of `run` keys (= the LDS capacity of the launch, a power of two) are sorted in LDS with the bitonic
+//      network and written back in place;
+//   2. log2(#runs) merge passes ping-pong between the key buffer and its spare half: every thread produces
+//      a contiguous slice of each merged pair, located with a merge-path binary search (keys are unique);
+//   3. the Gaussian indices (low 32 bits) go to the sorted list.
+// Round 1 sent the WHOLE frame to the global radix sort when one list was long (cr/rasterizer_impl.cu:252-260 sorts
+// everything globally; the order produced is the same).
+GCR_DEV void gcr_tile_sort_long(uint64_t* s, uint32_t run0, uint64_t* __restrict__ A, uint64_t* __restrict__ B,
+                                uint32_t* __restrict__ out, uint32_t n, int tid) {
+  // 1. sorted runs
+  for (uint32_t c0 = 0; c0 < n; c0 += run0) {
+    const uint32_t len = min(run0, n - c0);
+    for (uint32_t i = tid; i < run0; i += 256) s[i] = i < len ? A[c0 + i] : ~0ull;
+    __syncthreads();
+    gcr_bitonic_sort_lds(s, (int)run0, tid);
+    for (uint32_t i = tid; i < len; i += 256) A[c0 + i] = s[i];
+    __syncthreads();
+  }
+  // 2. merge passes
+  uint64_t* src = A;
+  uint64_t* dst = B;
+  for (uint32_t run = run0; run < n; run <<= 1) {
+    for (uint32_t p0 = 0; p0 < n; p0 += 2 * run) {
+      const uint32_t la = min(run, n - p0);
+      const uint32_t lb = p0 + run < n ? min(run, n - p0 - run) : 0u;
+      const uint64_t* __restrict__ a = src + p0;
+      const uint64_t* __restrict__ b = src + p0 + run;
+      uint64_t* __restrict__ o = dst + p0;
+      const uint32_t tot = la + lb;
+      const uint32_t per = (tot + 255u) / 256u;
+      const uint32_t d0 = min(tot, (uint32_t)tid * per), d1 = min(tot, d0 + per);
+      if (d0 < d1) {
+        // merge path: the first d0 outputs take i keys of a and d0-i of b, i = the smallest index with
+        // a[i] > b[d0-1-i] (unique keys: no ties)
+        uint32_t lo = d0 > lb ? d0 - lb : 0u, hi = min(d0, la);
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (a[mid] < b[d0 - 1 - mid])
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        uint32_t i = lo, j = d0 - lo;
+        uint64_t ka = i < la ? a[i] : ~0ull, kb = j < lb ? b[j] : ~0ull;
+        for (uint32_t k = d0; k < d1; k++) {
+          if (ka < kb) {
+            o[k] = ka;
+            i++;
+            ka = i < la ? a[i] : ~0ull;
+          } else {
+            o[k] = kb;
+            j++;
+            kb = j < lb ? b[j] : ~0ull;
+          }
+        }
+      }
+    }
+    __syncthreads();  // the pass is complete (workgroup-scope visibility of the global stores) before it is read
+    uint64_t* t = src;
+    src = dst;
+    dst = t;
+  }
+  // 3. Gaussian indices
+  for (uint32_t i = tid; i < n; i += 256) out[i] = (uint32_t)src[i];
+}
+
 __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ ranges,
-                                                   const uint64_t* __restrict__ pairs,
+                                                   uint64_t* __restrict__ pairs, uint64_t* __restrict__ pairs_spare,
                                                    uint32_t* __restrict__ list,
                                                    const unsigned long long* __restrict__ frame, int lds_capacity) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
@@ -317,7 +386,11 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
   const int tid = threadIdx.x;
   const uint32_t r0 = ranges[2 * blockIdx.x], r1 = ranges[2 * blockIdx.x + 1];
   const int n = (int)(r1 - r0);
-  if (n <= 0 || n > lds_capacity) return;  // longer lists belong to k_tile_sort_long
+  if (n <= 0) return;
+  if (n > lds_capacity) {  // longer than the LDS of this launch (a power of two >= 64): sorted runs + merge passes
+    gcr_tile_sort_long(s, (uint32_t)lds_capacity, pairs + r0, pairs_spare + r0, list + r0, (uint32_t)n, tid);
+    return;
+  }
   if (n == 1) {
     if (tid == 0) list[r0] = (uint32_t)pairs[r0];
     return;
@@ -390,86 +463,6 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
   __syncthreads();
   gcr_bitonic_sort_lds(s, N2, tid);
   for (int i = tid; i < n; i += 256) list[r0 + i] = (uint32_t)s[i];
-}
-
-// Tile lists LONGER than the LDS sort capacity (dense general 3DGS scenes; GaussianCity's own scenes have
-// ~150 entries per tile): one workgroup per such tile, everything else returns at once.
-//   1. runs of LONG_RUN keys are sorted in LDS (the bitonic network above) and written back in place;
-//   2. log2(#runs) merge passes ping-pong between the key buffer and its spare half: every thread produces
-//      a contiguous slice of each merged pair, located with a merge-path binary search (keys are unique);
-//   3. the Gaussian indices (low 32 bits) go to the sorted list.
-// The other tiles of the frame stay on k_tile_sort: a long list no longer sends the whole frame to the
-// global radix sort (cr/rasterizer_impl.cu:252-260 sorts everything globally; the order produced is the same).
-constexpr int LONG_RUN = 4096;
-
-__global__ __launch_bounds__(256) void k_tile_sort_long(const uint32_t* __restrict__ ranges,
-                                                        uint64_t* __restrict__ bufA, uint64_t* __restrict__ bufB,
-                                                        uint32_t* __restrict__ list,
-                                                        const unsigned long long* __restrict__ frame,
-                                                        int lds_capacity) {
-  __shared__ uint64_t s[LONG_RUN];
-  if (frame != nullptr && frame[2] == 0ull) return;  // speculative launch vetoed
-  const int tid = threadIdx.x;
-  const uint32_t r0 = ranges[2 * blockIdx.x], r1 = ranges[2 * blockIdx.x + 1];
-  const uint32_t n = r1 - r0;
-  if (n <= (uint32_t)lds_capacity) return;
-  uint64_t* __restrict__ A = bufA + r0;
-  uint64_t* __restrict__ B = bufB + r0;
-  // 1. sorted runs
-  for (uint32_t c0 = 0; c0 < n; c0 += LONG_RUN) {
-    const uint32_t len = min((uint32_t)LONG_RUN, n - c0);
-    for (uint32_t i = tid; i < (uint32_t)LONG_RUN; i += 256) s[i] = i < len ? A[c0 + i] : ~0ull;
-    __syncthreads();
-    gcr_bitonic_sort_lds(s, LONG_RUN, tid);
-    for (uint32_t i = tid; i < len; i += 256) A[c0 + i] = s[i];
-    __syncthreads();
-  }
-  // 2. merge passes
-  uint64_t* src = A;
-  uint64_t* dst = B;
-  for (uint32_t run = LONG_RUN; run < n; run <<= 1) {
-    for (uint32_t p0 = 0; p0 < n; p0 += 2 * run) {
-      const uint32_t la = min(run, n - p0);
-      const uint32_t lb = p0 + run < n ? min(run, n - p0 - run) : 0u;
-      const uint64_t* __restrict__ a = src + p0;
-      const uint64_t* __restrict__ b = src + p0 + run;
-      uint64_t* __restrict__ o = dst + p0;
-      const uint32_t tot = la + lb;
-      const uint32_t per = (tot + 255u) / 256u;
-      const uint32_t d0 = min(tot, (uint32_t)tid * per), d1 = min(tot, d0 + per);
-      if (d0 < d1) {
-        // merge path: the first d0 outputs take i keys of a and d0-i of b, i = the smallest index with
-        // a[i] > b[d0-1-i] (unique keys: no ties)
-        uint32_t lo = d0 > lb ? d0 - lb : 0u, hi = min(d0, la);
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (a[mid] < b[d0 - 1 - mid])
-            lo = mid + 1;
-          else
-            hi = mid;
-        }
-        uint32_t i = lo, j = d0 - lo;
-        uint64_t ka = i < la ? a[i] : ~0ull, kb = j < lb ? b[j] : ~0ull;
-        for (uint32_t k = d0; k < d1; k++) {
-          if (ka < kb) {
-            o[k] = ka;
-            i++;
-            ka = i < la ? a[i] : ~0ull;
-          } else {
-            o[k] = kb;
-            j++;
-            kb = j < lb ? b[j] : ~0ull;
-          }
-        }
-      }
-    }
-    __syncthreads();  // the pass is complete (workgroup-scope visibility of the global stores) before it is read
-    uint64_t* t = src;
-    src = dst;
-    dst = t;
-  }
-  // 3. Gaussian indices
-  for (uint32_t i = tid; i < n; i += 256) list[r0 + i] = (uint32_t)src[i];
 }
 
 // ------------------------------------------------------------------------------------- K4
@@ -643,7 +636,7 @@ hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, i
   if (e != hipSuccess) return e;
   k_tile_table<false><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(
       T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, nullptr, nullptr, nullptr, nullptr, nullptr,
-      frame, 0ull, 0ull);
+      frame, 0ull, 0ull, nullptr);
   k_table_colscan<<<(T + 63) / 64, 1024, 0, s>>>(table, NG, T, tile_total, tile_local, blk_total, frame);
   return hipGetLastError();
 }
@@ -653,12 +646,12 @@ hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1,
                                    const uint32_t* tile_total, const uint32_t* tile_local,
                                    const uint32_t* blk_total, uint32_t* ranges, uint64_t* pairs,
                                    unsigned long long* frame, unsigned long long cap_instances,
-                                   unsigned long long cap_list, hipStream_t s) {
+                                   unsigned long long cap_list, unsigned long long* host_longest, hipStream_t s) {
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
   k_tile_table<true><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(
       T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, tile_total, tile_local, blk_total, ranges, pairs,
-      frame, cap_instances, cap_list);
+      frame, cap_instances, cap_list, host_longest);
   return hipGetLastError();
 }
 
@@ -719,22 +712,21 @@ hipError_t gcr_launch_tiles_touched(int P, int nblocks, int chunk, const uint32_
   return hipGetLastError();
 }
 
-int gcr_tile_sort_capacity(void) { return LONG_RUN; }  // 32 KiB of LDS per workgroup at most
+int gcr_tile_sort_capacity(void) { return 4096; }  // 32 KiB of LDS per workgroup at most
 
-// `max_tile_instances`: longest list the caller expects (sizes the LDS of k_tile_sort, at most the capacity);
-// `long_lists`: some list may exceed the LDS capacity -> also launch the per-tile long-list sort, which needs
-// the spare key buffer `pairs_spare` (same size as `pairs`).
+// `list_length_hint`: the longest list the caller expects.  It only sizes the LDS of the launch (a power of two
+// between 64 and the capacity): lists within it take the in-LDS paths, longer ones the run + merge path through
+// the spare key buffer `pairs_spare` (same size as `pairs`) -- any length is sorted correctly.
 hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, uint64_t* pairs, uint64_t* pairs_spare,
-                                uint32_t* list, int64_t max_tile_instances, bool long_lists,
-                                const unsigned long long* frame, hipStream_t s) {
+                                uint32_t* list, int64_t list_length_hint, const unsigned long long* frame,
+                                hipStream_t s) {
   if (T <= 0) return hipSuccess;
   const int cap = gcr_tile_sort_capacity();
   size_t n2 = 64;
-  while ((int64_t)n2 < max_tile_instances && n2 < (size_t)cap) n2 <<= 1;
+  while ((int64_t)n2 < list_length_hint && n2 < (size_t)cap) n2 <<= 1;
   // bitonic path: n2 keys; rank/merge path (<= RANK_MERGE_MAX keys): two buffers of n rounded up to 64
   const size_t lds = n2 <= (size_t)RANK_MERGE_MAX ? 2 * n2 * sizeof(uint64_t) : n2 * sizeof(uint64_t);
-  k_tile_sort<<<T, 256, lds, s>>>(ranges, pairs, list, frame, (int)n2);
-  if (long_lists) k_tile_sort_long<<<T, 256, 0, s>>>(ranges, pairs, pairs_spare, list, frame, (int)n2);
+  k_tile_sort<<<T, 256, lds, s>>>(ranges, pairs, pairs_spare, list, frame, (int)n2);
   return hipGetLastError();
 }
 

@@ -76,6 +76,13 @@ GCR_DEV float gcr_power(float cx, float cy, float cz, float dx, float dy) {
 // cr/auxiliary.h:32-34 -- double arithmetic on purpose.
 GCR_DEV float gcr_ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
 
+// One 8-byte word to host-visible (pinned, coherent) memory, written through so that a polling host thread
+// sees it while later kernels of the stream are still running.  RELAXED on purpose: the word is the whole
+// message, and a system-scope RELEASE would first write back the XCD's L2 (everything the kernel just wrote).
+GCR_DEV void gcr_store_to_host(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- wave64 primitives -------------------------------------------------------------------
 // DPP butterfly: after the four in-row steps every lane of a 16-lane row holds its row sum;
 // row_bcast:15 / row_bcast:31 then chain the rows so that lanes 48..63 hold the wave sum.

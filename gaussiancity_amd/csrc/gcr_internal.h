@@ -29,6 +29,9 @@ struct GcrPreprocessArgs {
   uint32_t* vis_count;   // [nblocks]
   uint32_t* cand_list;   // [P] K1a's candidates of block b at [b*chunk, b*chunk + cand_count[b])
   uint32_t* cand_count;  // [nblocks]
+  unsigned long long* frame;  // {R, longest tile list, go, K1b ticket}: zeroed by K1a, R accumulated by K1b
+  unsigned long long* host_R;  // optional pinned (coherent) host word: K1b's last block stores (seq << 32 | R) there
+  unsigned int seq;            // tag of this frame in *host_R
   int nblocks, chunk;    // persistent grid: block b owns Gaussians [b*chunk, (b+1)*chunk)
 };
 
@@ -111,15 +114,15 @@ hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1,
                                    const uint32_t* tile_total, const uint32_t* tile_local,
                                    const uint32_t* blk_total, uint32_t* ranges, uint64_t* pairs,
                                    unsigned long long* frame, unsigned long long cap_instances,
-                                   unsigned long long cap_list, hipStream_t s);
+                                   unsigned long long cap_list, unsigned long long* host_longest, hipStream_t s);
 hipError_t gcr_launch_scatter_instances(int nblocks, int chunk, const uint32_t* vis_list,
                                         const uint32_t* vis_count, const float4* rec, int gx,
                                         uint32_t* tile_cursor, uint64_t* pairs, const uint32_t* ranges, int T,
                                         const unsigned long long* frame, hipStream_t s);
 int gcr_tile_sort_capacity(void);  // longest per-tile list the LDS sort accepts
 hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, uint64_t* pairs, uint64_t* pairs_spare,
-                                uint32_t* list, int64_t max_tile_instances, bool long_lists,
-                                const unsigned long long* frame, hipStream_t s);
+                                uint32_t* list, int64_t list_length_hint, const unsigned long long* frame,
+                                hipStream_t s);
 // Stable LSD radix sort of R (u64 key, u32 value) pairs on bits [0, end_bit).  Ping-pongs
 // between (k0,v0) and (k1,v1); returns in *sorted_half which half holds the result.
 size_t gcr_sort_hist_bytes(int64_t R, int end_bit);

@@ -159,18 +159,18 @@ int gcr_forward_preprocess(const gcr_camera *cam, const gcr_gaussians *g, void *
 /* Whole forward in ONE call without a mid-frame host stall.  `binning` must hold
  * gcr_binning_bytes(binning_capacity) bytes; binning_capacity is the caller's guess of
  * num_rendered (e.g. 1.5 x the previous frame's value; 0 = no guess) and tile_list_capacity its
- * guess of the longest per-tile list (0 = the LDS sort's capacity, 4096): a guess within that
- * capacity sizes the LDS of the per-tile sort and a longer list vetoes the speculation; a guess
- * beyond it declares a scene with long lists -- the per-tile long-list sort (sorted 4096-key runs
- * merged through the spare key buffer) is enqueued as well and the list length never vetoes.
- * All kernels of the frame
- * are enqueued at once -- they take the tile ranges from device memory and a device-side flag
- * vetoes them if the guess was too small -- and the host waits only for the 24-byte frame
- * summary, which lands in pinned memory as soon as K2 is done.
- * Returns 0: frame complete, *info_host valid.
- * Returns 1 (GCR_RETRY_RENDER): *info_host valid, nothing rendered yet (a guess was too small, or
- *   "force_radix"): allocate
- *   gcr_binning_bytes(info_host->num_rendered) and call gcr_forward_render.
+ * guess of the longest per-tile list (0 = 4096).  The list guess only sizes the LDS of the per-tile
+ * sort: lists within it are sorted in LDS, longer ones -- of any length -- by the same workgroup with
+ * sorted runs merged through the spare key buffer.  All kernels of the frame are enqueued at once --
+ * they take the tile ranges from device memory and a device-side flag vetoes them if
+ * binning_capacity was too small -- and the host waits only for num_rendered, which the exact
+ * projection pass accumulates and whose last workgroup stores it into a pinned host word the calling
+ * thread polls: no copy, no event, and the wait ends as soon as that pass is done (the tile-table
+ * kernels, the scatter, the sort and the blend run meanwhile).
+ * Returns 0: frame complete; info_host->num_rendered is exact, info_host->max_tile_instances is the
+ *   longest list of the most recent FINISHED frame of this host thread (a hint for the next guess).
+ * Returns 1 (GCR_RETRY_RENDER): *info_host exact, nothing rendered yet (binning_capacity too small, or
+ *   "force_radix"): allocate gcr_binning_bytes(info_host->num_rendered) and call gcr_forward_render.
  * Returns <0: error. */
 #define GCR_RETRY_RENDER 1
 int gcr_forward(const gcr_camera *cam, const gcr_gaussians *g, void *geom, size_t geom_bytes,
