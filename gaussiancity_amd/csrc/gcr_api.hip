@@ -245,8 +245,6 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
   gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &a.nblocks, &a.chunk);
   unsigned long long* frame = (unsigned long long*)(gb + L.geom_num_rendered);
   a.frame = frame;
-  a.host_R = host_R;
-  a.seq = seq;
   *frame_dev_out = frame;
   int G = 1;
   const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, a.nblocks, &G);
@@ -264,7 +262,7 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
     // tile_total | tile_local | blk_total share the (T x 128 B) cursor region, unused on this path
     HIP_TRY(gcr_launch_tile_count(T, a.gx, NG, G, a.nblocks, a.chunk, a.vis_list, a.vis_count, a.rec,
                                   (uint32_t*)(ib + L.img_tile_table), cursor, cursor + (size_t)T,
-                                  cursor + 2 * (size_t)T, frame, s),
+                                  cursor + 2 * (size_t)T, frame, host_R, seq, s),
             "tile count");
   } else {
     {
@@ -274,7 +272,8 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
     }
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
-    HIP_TRY(gcr_launch_scan_tiles(cursor, GCR_CURSOR_STRIDE, ranges, T, frame, cap_instances, cap_list, s), "tile scan");
+    HIP_TRY(gcr_launch_scan_tiles(cursor, GCR_CURSOR_STRIDE, ranges, T, frame, cap_instances, cap_list, host_R, seq, s),
+            "tile scan");
   }
   return 0;
 }
@@ -345,8 +344,8 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
 }
 
 // pinned landing zone + event for the asynchronous {R, max, go} read-back (per host thread)
-// num_rendered reaches the host WITHOUT a copy: the last block of the exact projection pass stores
-// (frame tag << 32 | R) into a pinned, coherent host word and the host thread polls that word.  Compared with
+// num_rendered reaches the host WITHOUT a copy: the exact projection pass accumulates it and the first workgroup
+// of the kernel that follows stores (frame tag << 32 | R) into a pinned, coherent host word the host thread polls.  Compared with
 // the reference's blocking cudaMemcpy (cr/rasterizer_impl.cu:236) -- and with round 1's 24-byte async copy +
 // event after the column scan -- the host is released as soon as K1 is done (the tile-table kernels, the
 // scatter, the sort and the blend of the frame are enqueued but still to run), and a frame costs no
@@ -421,7 +420,7 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
                                     (unsigned long long)binning_capacity, ~0ull, out_color, s, rb.pinned + 1))
       return rc;
   }
-  // the one host wait of the frame: poll the pinned word until K1b's last block has tagged it with this frame
+  // the one host wait of the frame: poll the pinned word until the kernel after K1 has tagged it with this frame
   volatile unsigned long long* word = rb.pinned;
   unsigned long long v = *word;
   for (unsigned long spins = 0; (unsigned int)(v >> 32) != seq; v = *word) {

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
                                                            unsigned long long* __restrict__ frame,
                                                            unsigned long long cap_instances,
                                                            unsigned long long cap_list,
-                                                           unsigned long long* __restrict__ host_longest) {
+                                                           unsigned long long* __restrict__ host_word,
+                                                           unsigned int seq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
   uint32_t* cnt = reinterpret_cast<uint32_t*>(gcr_smem);  // [T]
   __shared__ uint32_t pre[TT_MAX_GROUP + 1];              // prefix of the group's list lengths
@@ -89,7 +90,14 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   uint32_t* __restrict__ row = table + (size_t)blockIdx.x * T;
   if (!SCATTER) {
-    // frame = {R, longest list, go}: zeroed by K1a, R added by K1b, longest list by the column scan
+    // frame = {R, longest list, go}: zeroed by K1a, R added by K1b, longest list by the column scan.
+    // K1 is complete when this kernel starts, so its first workgroup publishes num_rendered to the host at once:
+    // (frame tag << 32 | R) in ONE 8-byte store to pinned memory that the calling thread polls -- no copy, no
+    // event, and the host is released while the tile tables, the scatter, the sort and the blend still run.
+    if (blockIdx.x == 0 && tid == 0 && host_word != nullptr) {
+      const unsigned long long total = frame[0];
+      gcr_store_to_host(host_word, ((unsigned long long)seq << 32) | (total > 0xffffffffull ? 0xffffffffull : total));
+    }
     for (int t = tid; t < T; t += TT_THREADS) cnt[t] = 0u;
   } else {
     // Speculative launch: the host may not know R yet.  Every workgroup takes the same decision
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
     if (blockIdx.x == 0 && tid == 0) {
       frame[2] = go ? 1ull : 0ull;
       // the frame's longest list, for the host's next length hint (pinned memory, nobody waits for it)
-      if (host_longest != nullptr) gcr_store_to_host(host_longest, frame[1]);
+      if (host_word != nullptr) gcr_store_to_host(host_word, frame[1]);
     }
     if (!go) return;
     // tile starts = exclusive prefix of the 64-tile block totals (<= TT_MAX_TBLOCKS values, so
@@ -631,12 +639,13 @@ static hipError_t tile_table_attr() {
 hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,
                                  uint32_t* tile_total, uint32_t* tile_local, uint32_t* blk_total,
-                                 unsigned long long* frame, hipStream_t s) {
+                                 unsigned long long* frame, unsigned long long* host_R, unsigned int seq,
+                                 hipStream_t s) {
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
   k_tile_table<false><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(
       T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, nullptr, nullptr, nullptr, nullptr, nullptr,
-      frame, 0ull, 0ull, nullptr);
+      frame, 0ull, 0ull, host_R, seq);
   k_table_colscan<<<(T + 63) / 64, 1024, 0, s>>>(table, NG, T, tile_total, tile_local, blk_total, frame);
   return hipGetLastError();
 }
@@ -651,7 +660,7 @@ hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1,
   if (e != hipSuccess) return e;
   k_tile_table<true><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(
       T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, tile_total, tile_local, blk_total, ranges, pairs,
-      frame, cap_instances, cap_list, host_longest);
+      frame, cap_instances, cap_list, host_longest, 0u);
   return hipGetLastError();
 }
 

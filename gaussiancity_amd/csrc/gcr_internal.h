@@ -29,9 +29,7 @@ struct GcrPreprocessArgs {
   uint32_t* vis_count;   // [nblocks]
   uint32_t* cand_list;   // [P] K1a's candidates of block b at [b*chunk, b*chunk + cand_count[b])
   uint32_t* cand_count;  // [nblocks]
-  unsigned long long* frame;  // {R, longest tile list, go, K1b ticket}: zeroed by K1a, R accumulated by K1b
-  unsigned long long* host_R;  // optional pinned (coherent) host word: K1b's last block stores (seq << 32 | R) there
-  unsigned int seq;            // tag of this frame in *host_R
+  unsigned long long* frame;  // {R, longest tile list, go}: zeroed by K1a, R accumulated by K1b
   int nblocks, chunk;    // persistent grid: block b owns Gaussians [b*chunk, (b+1)*chunk)
 };
 
@@ -103,12 +101,14 @@ hipError_t gcr_launch_emit(int P, const uint32_t* tiles_touched, const uint32_t*
 // Fast binning path: tile counts -> ranges/cursors (+ total, max), scatter, per-tile LDS sort.
 hipError_t gcr_launch_scan_tiles(uint32_t* tile_cursor, int stride, uint32_t* ranges, int T,
                                  unsigned long long* frame, unsigned long long cap_instances,
-                                 unsigned long long cap_list, hipStream_t s);
+                                 unsigned long long cap_list, unsigned long long* host_R, unsigned int seq,
+                                 hipStream_t s);
 int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out);
 hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,
                                  uint32_t* tile_total, uint32_t* tile_local, uint32_t* blk_total,
-                                 unsigned long long* frame, hipStream_t s);
+                                 unsigned long long* frame, unsigned long long* host_R, unsigned int seq,
+                                 hipStream_t s);
 hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                    const uint32_t* vis_count, const float4* rec, uint32_t* table,
                                    const uint32_t* tile_total, const uint32_t* tile_local,

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
   __shared__ uint32_t list_tail;  // length of this block's candidate list
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) list_tail = 0;
-  if (blockIdx.x == 0 && tid < 4) a.frame[tid] = 0ull;  // frame summary {R, longest list, go, ticket}: K1b adds R
+  if (blockIdx.x == 0 && tid < 3) a.frame[tid] = 0ull;  // frame summary {R, longest list, go}: K1b adds R
   __syncthreads();
   float vm[16], pm[16];
 #pragma unroll
@@ -404,13 +404,16 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
   uint32_t* __restrict__ my_cand = a.cand_list + chunk_begin;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-  PhaseAIn cur, nxt;
+  // two iterations of inputs in flight per wave: when the kernel shares the GPU with another frame's blend it
+  // gets a fraction of the wave slots, and bytes in flight per wave are what keeps the stream at HBM speed
+  PhaseAIn cur, nxt, nx2;
   long long idx64 = chunk_begin + tid;
   const long long last = (long long)a.P - 1;
   phase_a_load<PRECOMP_COV>(a, idx64 < last ? idx64 : last, cur);
+  phase_a_load<PRECOMP_COV>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);
   for (long long base = chunk_begin; base < chunk_end; base += 256) {
     idx64 = base + tid;
-    phase_a_load<PRECOMP_COV>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);  // prefetch
+    phase_a_load<PRECOMP_COV>(a, idx64 + 512 < last ? idx64 + 512 : last, nx2);  // prefetch, two iterations ahead
     bool candidate = false;
     if (idx64 < chunk_end) {
       candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur);
@@ -424,6 +427,7 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
       if (candidate) my_cand[wbase + (uint32_t)__popcll(m & lt_mask)] = (uint32_t)idx64;
     }
     cur = nxt;
+    nxt = nx2;
   }
   __syncthreads();
   if (tid == 0) a.cand_count[blockIdx.x] = list_tail;
@@ -488,22 +492,10 @@ __global__ __launch_bounds__(256) void k_preprocess_project(const GcrPreprocessA
   __syncthreads();
   if (tid == 0) {
     a.vis_count[blockIdx.x] = list_tail;
-    // ONE returning device atomic per block on a packed word (arrivals << 40 | sum of tile counts): the block
-    // that arrives last knows it, knows the total, and needs no fence (a __threadfence() per block would write
-    // back the XCD's L2 2048 times -- measured: K1 100 -> 195 us).  It stores R for the kernels that follow
-    // and publishes (frame tag << 32 | R) to the host in ONE 8-byte store to pinned memory, which the host
-    // thread polls -- no copy, no event, and the host is released as soon as K1 is done while the tile-table
-    // kernels, the scatter, the sort and the blend are still to run.  40 bits hold any total below 1.1e12;
-    // the API rejects frames beyond 2^31-1 instances anyway.
-    const unsigned long long old = atomicAdd(&a.frame[3], (1ull << 40) | blk_tiles);
-    if ((old >> 40) == (unsigned long long)gridDim.x - 1ull) {
-      const unsigned long long total = (old + blk_tiles) & ((1ull << 40) - 1ull);
-      a.frame[0] = total;
-      if (a.host_R != nullptr) {
-        const unsigned long long r32 = total > 0xffffffffull ? 0xffffffffull : total;  // host rejects > 2^31-1
-        gcr_store_to_host(a.host_R, ((unsigned long long)a.seq << 32) | r32);
-      }
-    }
+    // fire-and-forget device atomic (no returned value, no fence: a __threadfence() per block would write back
+    // the XCD's L2 2048 times -- measured: K1 100 -> 195 us); the first block of the kernel that follows reads
+    // the total and publishes it to the host
+    if (blk_tiles) atomicAdd(&a.frame[0], blk_tiles);
   }
 }
 
@@ -547,7 +539,8 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ curs
                                                      uint32_t* __restrict__ ranges, int T,
                                                      unsigned long long* __restrict__ frame,
                                                      unsigned long long cap_instances,
-                                                     unsigned long long cap_list) {
+                                                     unsigned long long cap_list,
+                                                     unsigned long long* __restrict__ host_R, unsigned int seq) {
   __shared__ unsigned long long wsum[16];
   __shared__ uint32_t wmax[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -592,6 +585,8 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ curs
     run = e64;
   }
   if (tid == 0) {
+    if (host_R != nullptr)  // (frame tag << 32 | R) for the polling host thread, see k_tile_table<false>
+      gcr_store_to_host(host_R, ((unsigned long long)seq << 32) | (total > 0xffffffffull ? 0xffffffffull : total));
     frame[0] = total;
     frame[1] = mm;
     frame[2] = (total <= cap_instances && (unsigned long long)mm <= cap_list) ? 1ull : 0ull;
@@ -884,8 +879,9 @@ hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long
 
 hipError_t gcr_launch_scan_tiles(uint32_t* tile_cursor, int stride, uint32_t* ranges, int T,
                                  unsigned long long* frame, unsigned long long cap_instances,
-                                 unsigned long long cap_list, hipStream_t s) {
-  k_scan_tiles<<<1, 1024, 0, s>>>(tile_cursor, stride, ranges, T, frame, cap_instances, cap_list);
+                                 unsigned long long cap_list, unsigned long long* host_R, unsigned int seq,
+                                 hipStream_t s) {
+  k_scan_tiles<<<1, 1024, 0, s>>>(tile_cursor, stride, ranges, T, frame, cap_instances, cap_list, host_R, seq);
   return hipGetLastError();
 }
 

@@ -164,7 +164,7 @@ int gcr_forward_preprocess(const gcr_camera *cam, const gcr_gaussians *g, void *
  * sorted runs merged through the spare key buffer.  All kernels of the frame are enqueued at once --
  * they take the tile ranges from device memory and a device-side flag vetoes them if
  * binning_capacity was too small -- and the host waits only for num_rendered, which the exact
- * projection pass accumulates and whose last workgroup stores it into a pinned host word the calling
+ * projection pass accumulates and the next kernel's first workgroup stores into a pinned host word the calling
  * thread polls: no copy, no event, and the wait ends as soon as that pass is done (the tile-table
  * kernels, the scatter, the sort and the blend run meanwhile).
  * Returns 0: frame complete; info_host->num_rendered is exact, info_host->max_tile_instances is the
