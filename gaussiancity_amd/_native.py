@@ -56,7 +56,7 @@ class Layout(C.Structure):
         ("geom_rec", C.c_size_t), ("geom_cov3D", C.c_size_t), ("geom_clamped", C.c_size_t),
         ("geom_tiles_touched", C.c_size_t), ("geom_block_sums", C.c_size_t),
         ("geom_vis_list", C.c_size_t), ("geom_vis_count", C.c_size_t),
-        ("geom_num_rendered", C.c_size_t), ("geom_total", C.c_size_t),
+        ("geom_num_rendered", C.c_size_t), ("geom_block_tiles", C.c_size_t), ("geom_total", C.c_size_t),
         ("img_final_T", C.c_size_t), ("img_n_contrib", C.c_size_t), ("img_ranges", C.c_size_t),
         ("img_tile_cursor", C.c_size_t), ("img_tile_table", C.c_size_t), ("img_total", C.c_size_t),
         ("bin_keys", C.c_size_t * 2), ("bin_vals", C.c_size_t * 2), ("bin_hist", C.c_size_t),

@@ -15,6 +15,7 @@ std::atomic<int> g_fast_exp{0};
 std::atomic<int> g_timing{0};
 std::atomic<int> g_force_radix{0};
 std::atomic<int> g_force_global_cursor{0};
+std::atomic<int> g_split_preprocess{0};  // 1: K1 as two kernels (streaming cull, then exact pass) instead of the fused one
 std::atomic<int> g_k7_skip_flush{0};  // timing experiment only: results are wrong when set
 
 enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PRE_BWD, ST_COUNT };
@@ -98,6 +99,7 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   L->geom_vis_list = o;       o = align_up(o + p * sizeof(uint32_t));
   L->geom_vis_count = o;      o = align_up(o + (nblk + 1) * sizeof(uint32_t));
   L->geom_num_rendered = o;   o = align_up(o + 4 * sizeof(uint64_t));  // {R, longest tile list, go flag}
+  L->geom_block_tiles = o;    o = align_up(o + GCR_K1_MAX_BLOCKS * sizeof(uint64_t));  // K1 blocks' shares of R
   L->geom_total = o;
 
   const size_t npix = (size_t)(W > 0 ? W : 0) * (size_t)(H > 0 ? H : 0);
@@ -190,6 +192,7 @@ int gcr_set_option(const char* name, int value) {
   if (!strcmp(name, "force_radix")) return g_force_radix.exchange(value);
   if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.exchange(value);
   if (!strcmp(name, "k7_skip_flush")) return g_k7_skip_flush.exchange(value);
+  if (!strcmp(name, "split_preprocess")) return g_split_preprocess.exchange(value);
   return -1;
 }
 
@@ -242,9 +245,9 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
   // candidate list / counts of K1a live in the arrays only the radix fallback needs later
   a.cand_list = (uint32_t*)(gb + L.geom_tiles_touched);
   a.cand_count = (uint32_t*)(gb + L.geom_block_sums);
-  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &a.nblocks, &a.chunk);
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(g_split_preprocess.load() != 0), &a.nblocks, &a.chunk);
   unsigned long long* frame = (unsigned long long*)(gb + L.geom_num_rendered);
-  a.frame = frame;
+  a.block_tiles = (unsigned long long*)(gb + L.geom_block_tiles);
   *frame_dev_out = frame;
   int G = 1;
   const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, a.nblocks, &G);
@@ -255,20 +258,20 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
     a.tile_count = nullptr;
     {
       StageTimer t(s, ST_PRE);
-      HIP_TRY(gcr_launch_preprocess(a, s), "preprocess");
+      HIP_TRY(gcr_launch_preprocess(a, g_split_preprocess.load() != 0, s), "preprocess");
     }
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
     // tile_total | tile_local | blk_total share the (T x 128 B) cursor region, unused on this path
     HIP_TRY(gcr_launch_tile_count(T, a.gx, NG, G, a.nblocks, a.chunk, a.vis_list, a.vis_count, a.rec,
                                   (uint32_t*)(ib + L.img_tile_table), cursor, cursor + (size_t)T,
-                                  cursor + 2 * (size_t)T, frame, host_R, seq, s),
+                                  cursor + 2 * (size_t)T, frame, a.block_tiles, host_R, seq, s),
             "tile count");
   } else {
     {
       StageTimer t(s, ST_PRE);
       HIP_TRY(hipMemsetAsync(a.tile_count, 0, sizeof(uint32_t) * GCR_CURSOR_STRIDE * (size_t)T, s), "tile count memset");
-      HIP_TRY(gcr_launch_preprocess(a, s), "preprocess");
+      HIP_TRY(gcr_launch_preprocess(a, g_split_preprocess.load() != 0, s), "preprocess");
     }
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
@@ -299,7 +302,7 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   unsigned long long* frame_dev = (unsigned long long*)(gb + L.geom_num_rendered);
   const unsigned long long* frame_guard = speculative ? frame_dev : nullptr;
   int nblocks, chunk;
-  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &nblocks, &chunk);
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(g_split_preprocess.load() != 0), &nblocks, &chunk);
   int G = 1;
   const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, nblocks, &G);
   {
@@ -484,7 +487,7 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   const uint32_t* vis_list = (const uint32_t*)(gb + L.geom_vis_list);
   const uint32_t* vis_count = (const uint32_t*)(gb + L.geom_vis_count);
   int nblocks, chunk;
-  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &nblocks, &chunk);
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(g_split_preprocess.load() != 0), &nblocks, &chunk);
   uint64_t* k0 = (uint64_t*)(bb + L.bin_keys[0]);
   uint64_t* k1 = (uint64_t*)(bb + L.bin_keys[1]);
   uint32_t* v0 = (uint32_t*)(bb + L.bin_vals[0]);
@@ -583,7 +586,7 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   a.clamped = (const uint8_t*)(gb + L.geom_clamped);
   a.vis_list = (const uint32_t*)(gb + L.geom_vis_list);
   a.vis_count = (const uint32_t*)(gb + L.geom_vis_count);
-  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(), &a.nblocks, &a.chunk);
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(g_split_preprocess.load() != 0), &a.nblocks, &a.chunk);
   a.grad_rec = (const float4*)gr->dL_dconic;
   a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dcolor = gr->dL_dcolors; a.dL_dopacity = gr->dL_dopacity;
   a.dL_dmean3D = gr->dL_dmeans3D; a.dL_dcov3D = gr->dL_dcov3D; a.dL_dsh = gr->dL_dsh;

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
                                                            unsigned long long cap_instances,
                                                            unsigned long long cap_list,
                                                            unsigned long long* __restrict__ host_word,
-                                                           unsigned int seq) {
+                                                           unsigned int seq,
+                                                           const unsigned long long* __restrict__ block_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
   uint32_t* cnt = reinterpret_cast<uint32_t*>(gcr_smem);  // [T]
   __shared__ uint32_t pre[TT_MAX_GROUP + 1];              // prefix of the group's list lengths
@@ -90,13 +91,29 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   uint32_t* __restrict__ row = table + (size_t)blockIdx.x * T;
   if (!SCATTER) {
-    // frame = {R, longest list, go}: zeroed by K1a, R added by K1b, longest list by the column scan.
-    // K1 is complete when this kernel starts, so its first workgroup publishes num_rendered to the host at once:
-    // (frame tag << 32 | R) in ONE 8-byte store to pinned memory that the calling thread polls -- no copy, no
-    // event, and the host is released while the tile tables, the scatter, the sort and the blend still run.
-    if (blockIdx.x == 0 && tid == 0 && host_word != nullptr) {
-      const unsigned long long total = frame[0];
-      gcr_store_to_host(host_word, ((unsigned long long)seq << 32) | (total > 0xffffffffull ? 0xffffffffull : total));
+    // K1 is complete when this kernel starts, so its first workgroup sums the K1 blocks' shares of num_rendered
+    // (what the reference gets from its inclusive scan, cr/rasterizer_impl.cu:228-238), starts the frame summary
+    // {R, longest list (added by the column scan), go} and publishes R to the host at once: (frame tag << 32 | R)
+    // in ONE 8-byte store to pinned memory that the calling thread polls -- no copy, no event, and the host is
+    // released while the tile tables, the scatter, the sort and the blend still run.
+    if (blockIdx.x == 0) {
+      unsigned long long part = 0ull;
+      for (int b = tid; b < nblocks_k1; b += TT_THREADS) part += block_tiles[b];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+      __shared__ unsigned long long wpart[TT_THREADS / 64];
+      if (lane == 0) wpart[w] = part;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long total = 0ull;
+#pragma unroll
+        for (int k = 0; k < TT_THREADS / 64; k++) total += wpart[k];
+        frame[0] = total;
+        frame[1] = 0ull;
+        frame[2] = 0ull;
+        if (host_word != nullptr)
+          gcr_store_to_host(host_word, ((unsigned long long)seq << 32) | (total > 0xffffffffull ? 0xffffffffull : total));
+      }
     }
     for (int t = tid; t < T; t += TT_THREADS) cnt[t] = 0u;
   } else {
@@ -639,13 +656,13 @@ static hipError_t tile_table_attr() {
 hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,
                                  uint32_t* tile_total, uint32_t* tile_local, uint32_t* blk_total,
-                                 unsigned long long* frame, unsigned long long* host_R, unsigned int seq,
-                                 hipStream_t s) {
+                                 unsigned long long* frame, const unsigned long long* block_tiles,
+                                 unsigned long long* host_R, unsigned int seq, hipStream_t s) {
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
   k_tile_table<false><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(
       T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, nullptr, nullptr, nullptr, nullptr, nullptr,
-      frame, 0ull, 0ull, host_R, seq);
+      frame, 0ull, 0ull, host_R, seq, block_tiles);
   k_table_colscan<<<(T + 63) / 64, 1024, 0, s>>>(table, NG, T, tile_total, tile_local, blk_total, frame);
   return hipGetLastError();
 }
@@ -660,7 +677,7 @@ hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1,
   if (e != hipSuccess) return e;
   k_tile_table<true><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(
       T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, tile_total, tile_local, blk_total, ranges, pairs,
-      frame, cap_instances, cap_list, host_longest, 0u);
+      frame, cap_instances, cap_list, host_longest, 0u, nullptr);
   return hipGetLastError();
 }
 

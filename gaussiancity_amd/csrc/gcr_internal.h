@@ -29,14 +29,14 @@ struct GcrPreprocessArgs {
   uint32_t* vis_count;   // [nblocks]
   uint32_t* cand_list;   // [P] K1a's candidates of block b at [b*chunk, b*chunk + cand_count[b])
   uint32_t* cand_count;  // [nblocks]
-  unsigned long long* frame;  // {R, longest tile list, go}: zeroed by K1a, R accumulated by K1b
+  unsigned long long* block_tiles;  // [nblocks] every K1 block's share of num_rendered
   int nblocks, chunk;    // persistent grid: block b owns Gaussians [b*chunk, (b+1)*chunk)
 };
 
 // Persistent-grid geometry of K1 (also used by the kernels that walk its visible lists):
 // as many blocks as are co-resident (one round, no tail), at most GCR_K1_MAX_BLOCKS.
 #define GCR_K1_MAX_BLOCKS 2048
-int gcr_preprocess_resident_blocks(void);  // occupancy x CUs of the current device (cached)
+int gcr_preprocess_resident_blocks(bool split);  // occupancy x CUs of the current device (cached)
 static inline void gcr_preprocess_grid(int P, int max_blocks, int* nblocks, int* chunk) {
   int nb = (P + 255) / 256;
   if (nb > max_blocks) nb = max_blocks;
@@ -88,7 +88,7 @@ struct GcrBlendArgs {
 // launchers (each enqueues on `s`, returns hipGetLastError())
 hipError_t gcr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present,
                                    hipStream_t s);
-hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, hipStream_t s);
+hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, bool split, hipStream_t s);
 hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long long* total,
                                       hipStream_t s);
 // fallback binning: per-Gaussian tile counts from radii + record rect, then emit in index order
@@ -107,8 +107,8 @@ int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out);
 hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,
                                  uint32_t* tile_total, uint32_t* tile_local, uint32_t* blk_total,
-                                 unsigned long long* frame, unsigned long long* host_R, unsigned int seq,
-                                 hipStream_t s);
+                                 unsigned long long* frame, const unsigned long long* block_tiles,
+                                 unsigned long long* host_R, unsigned int seq, hipStream_t s);
 hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                    const uint32_t* vis_count, const float4* rec, uint32_t* table,
                                    const uint32_t* tile_total, const uint32_t* tile_local,

@@ -5,6 +5,8 @@
 // and are fetched through the scalar cache (s_load), per-Gaussian attributes through
 // per-lane vector loads.  Arithmetic follows gcr-fp32-v1 (gcr_device.h) in the operation
 // order of cr/forward.cu / cr/backward.cu so that results are bit-identical to the oracle.
+#include <cstdlib>
+
 #include "gcr_device.h"
 #include "gcr_internal.h"
 
@@ -377,7 +379,6 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
   __shared__ uint32_t list_tail;  // length of this block's candidate list
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) list_tail = 0;
-  if (blockIdx.x == 0 && tid < 3) a.frame[tid] = 0ull;  // frame summary {R, longest list, go}: K1b adds R
   __syncthreads();
   float vm[16], pm[16];
 #pragma unroll
@@ -482,8 +483,8 @@ __global__ __launch_bounds__(256) void k_preprocess_project(const GcrPreprocessA
     }
   }
   // num_rendered = sum of the survivors' tile counts (what the reference obtains from its inclusive scan,
-  // cr/rasterizer_impl.cu:228-238), accumulated here so that the host can have R right after K1b instead of
-  // after the tile-count kernels.
+  // cr/rasterizer_impl.cu:228-238), accumulated per block here so that the host can have R right after K1
+  // instead of after the tile-count kernels.
   __shared__ unsigned long long blk_tiles;
   if (tid == 0) blk_tiles = 0ull;
   __syncthreads();
@@ -492,10 +493,150 @@ __global__ __launch_bounds__(256) void k_preprocess_project(const GcrPreprocessA
   __syncthreads();
   if (tid == 0) {
     a.vis_count[blockIdx.x] = list_tail;
-    // fire-and-forget device atomic (no returned value, no fence: a __threadfence() per block would write back
-    // the XCD's L2 2048 times -- measured: K1 100 -> 195 us); the first block of the kernel that follows reads
-    // the total and publishes it to the host
-    if (blk_tiles) atomicAdd(&a.frame[0], blk_tiles);
+    // this block's share of num_rendered; the first workgroup of the kernel that follows sums the blocks' shares
+    // and publishes the total to the host (no atomics, nothing to zero beforehand)
+    a.block_tiles[blockIdx.x] = blk_tiles;
+  }
+}
+
+// K1 fused (default): ONE kernel whose workgroups alternate between STREAMING their chunk through the cull
+// (K1a's loop) and PROCESSING the candidates they have collected -- exact projection, colour, record (K1b's body).
+// The candidates' inputs (index + 10 floats) wait in LDS, so they never go back to HBM and K1b's re-gather of three
+// 128-byte lines per candidate disappears; and while one workgroup is in its latency-bound processing pass the
+// other workgroups of the CU keep the HBM stream going, so the pass is hidden instead of being a second kernel
+// that starts only when the slowest streaming block has finished.  A processing pass runs whenever 256 candidates
+// are waiting (all lanes busy) and once more at the end of the chunk.
+constexpr int FUSED_CAP = 512;  // <= 255 left over + <= 256 new candidates per iteration
+
+template <bool PRECOMP_COV>
+__global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArgs a) {
+  __shared__ uint32_t sIdx[FUSED_CAP];
+  __shared__ float sIn[10][FUSED_CAP];
+  __shared__ uint32_t cand_tail, vis_tail;
+  __shared__ unsigned long long blk_tiles;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) {
+    cand_tail = 0;
+    vis_tail = 0;
+    blk_tiles = 0ull;
+  }
+  __syncthreads();
+  float vm[16], pm[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    vm[i] = gcr_uniform(a.view[i]);
+    pm[i] = gcr_uniform(a.proj[i]);
+  }
+  float wf2 = 0.0f;
+  {
+    const float wc[3][3] = {{vm[0], vm[1], vm[2]}, {vm[4], vm[5], vm[6]}, {vm[8], vm[9], vm[10]}};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      float row = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        row += __builtin_fabsf(wc[0][i] * wc[0][j] + wc[1][i] * wc[1][j] + wc[2][i] * wc[2][j]);
+      wf2 = __builtin_fmaxf(wf2, row);
+    }
+    wf2 *= 1.001f;
+  }
+  const long long chunk_begin = (long long)blockIdx.x * a.chunk;
+  const long long chunk_end = chunk_begin + a.chunk < a.P ? chunk_begin + a.chunk : a.P;
+  uint32_t* __restrict__ my_list = a.vis_list + chunk_begin;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  uint32_t my_tiles = 0;
+
+  PhaseAIn cur, nxt, nx2;
+  long long idx64 = chunk_begin + tid;
+  const long long last = (long long)a.P - 1;
+  phase_a_load<PRECOMP_COV>(a, idx64 < last ? idx64 : last, cur);
+  phase_a_load<PRECOMP_COV>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);
+  for (long long base = chunk_begin; base < chunk_end; base += 256) {
+    idx64 = base + tid;
+    phase_a_load<PRECOMP_COV>(a, idx64 + 512 < last ? idx64 + 512 : last, nx2);  // prefetch, two iterations ahead
+    bool candidate = false;
+    if (idx64 < chunk_end) {
+      candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur);
+      if (!candidate) a.radii[idx64] = 0;
+    }
+    const uint64_t m = __ballot(candidate);
+    if (m != 0ull) {
+      uint32_t wbase = 0;
+      if (lane == 0) wbase = atomicAdd(&cand_tail, (uint32_t)__popcll(m));
+      wbase = __shfl(wbase, 0, 64);
+      if (candidate) {
+        const uint32_t slot = wbase + (uint32_t)__popcll(m & lt_mask);
+        sIdx[slot] = (uint32_t)idx64;
+        sIn[0][slot] = cur.p.x; sIn[1][slot] = cur.p.y; sIn[2][slot] = cur.p.z;
+        sIn[3][slot] = cur.c0; sIn[4][slot] = cur.c1; sIn[5][slot] = cur.c2;
+        sIn[6][slot] = cur.c3; sIn[7][slot] = cur.c4; sIn[8][slot] = cur.c5;
+        sIn[9][slot] = cur.c6;
+      }
+    }
+    cur = nxt;
+    nxt = nx2;
+    __syncthreads();
+    const uint32_t waiting = cand_tail;  // block-uniform
+    const bool last_iter = base + 256 >= chunk_end;
+    if (waiting >= 256u || (last_iter && waiting > 0u)) {
+      // ---- processing passes over the waiting candidates: full 256-lane passes, plus the remainder at the end
+      uint32_t done = 0;
+      while (done + 256u <= waiting || (last_iter && done < waiting)) {
+        const uint32_t it = done + (uint32_t)tid;
+        bool keep = false;
+        int idx = 0, radius = 0;
+        PhaseAIn in;
+        Projected pr;
+        if (it < waiting) {
+          idx = (int)sIdx[it];
+          in.p = {sIn[0][it], sIn[1][it], sIn[2][it]};
+          in.c0 = sIn[3][it]; in.c1 = sIn[4][it]; in.c2 = sIn[5][it];
+          in.c3 = sIn[6][it]; in.c4 = sIn[7][it]; in.c5 = sIn[8][it];
+          in.c6 = sIn[9][it];
+          keep = phase_a1_exact<PRECOMP_COV>(a, vm, pm, idx, in, pr, radius);
+          a.radii[idx] = radius;
+        }
+        const uint64_t mk = __ballot(keep);
+        if (mk != 0ull) {
+          uint32_t lbase = 0;
+          if (lane == 0) lbase = atomicAdd(&vis_tail, (uint32_t)__popcll(mk));
+          lbase = __shfl(lbase, 0, 64);
+          if (keep) {
+            my_tiles += ((pr.rect_x >> 16) - (pr.rect_x & 0xffffu)) * ((pr.rect_y >> 16) - (pr.rect_y & 0xffffu));
+            PhaseBIn bin;
+            phase_b_fetch(a, idx, bin);
+            preprocess_phase_b(a, idx, in.p, pr, bin, lbase + (uint32_t)__popcll(mk & lt_mask), my_list);
+          }
+        }
+        done += 256u;
+      }
+      if (done > waiting) done = waiting;
+      // the (< 256) candidates that did not fill a pass move to the front and wait for the next one
+      const uint32_t left = waiting - done;
+      __syncthreads();  // every lane has read its candidate
+      uint32_t mv_idx = 0;
+      float mv[10];
+      if ((uint32_t)tid < left) {
+        mv_idx = sIdx[done + tid];
+#pragma unroll
+        for (int k = 0; k < 10; k++) mv[k] = sIn[k][done + tid];
+      }
+      __syncthreads();
+      if ((uint32_t)tid < left) {
+        sIdx[tid] = mv_idx;
+#pragma unroll
+        for (int k = 0; k < 10; k++) sIn[k][tid] = mv[k];
+      }
+      if (tid == 0) cand_tail = left;
+      __syncthreads();
+    }
+  }
+  const uint32_t wsum = gcr_wave_sum_u32(my_tiles);
+  if (lane == 0 && wsum) atomicAdd(&blk_tiles, (unsigned long long)wsum);
+  __syncthreads();
+  if (tid == 0) {
+    a.vis_count[blockIdx.x] = vis_tail;
+    a.block_tiles[blockIdx.x] = blk_tiles;  // summed (= num_rendered) by the first workgroup of the next kernel
   }
 }
 
@@ -844,7 +985,13 @@ hipError_t gcr_launch_mark_visible(int P, const float* means3D, const float* vie
   return hipGetLastError();
 }
 
-int gcr_preprocess_resident_blocks(void) {
+// Blocks of the K1 grid (every block owns one contiguous chunk of the Gaussians and one candidate / visible list):
+// as many as the streaming cull can keep co-resident (8 per CU -> 2048 on MI355X).  The fused kernel keeps fewer
+// co-resident (3 per CU) but is launched with the same number: measured, many short blocks co-schedule better with
+// the other frame's blend than one resident round of long ones (4 660 vs 4 470 frames/s), and the geometry does not
+// depend on the "split_preprocess" option.
+int gcr_preprocess_resident_blocks(bool split) {
+  (void)split;
   static int cached = [] {
     int dev = 0, cus = 256, per_cu = 4;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -854,13 +1001,21 @@ int gcr_preprocess_resident_blocks(void) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_preprocess_cull<false>, 256, 0) != hipSuccess || per_cu < 1)
       per_cu = 4;
     int n = per_cu * cus;
+    if (const char* e = getenv("GCR_K1_BLOCKS")) n = atoi(e);  // experiments only
     return n > GCR_K1_MAX_BLOCKS ? GCR_K1_MAX_BLOCKS : (n < 1 ? 1 : n);
   }();
   return cached;
 }
 
-hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, hipStream_t s) {
+hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, bool split, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
+  if (!split) {  // default: streaming cull and exact pass in one kernel
+    if (a.cov3D_precomp != nullptr)
+      k_preprocess_fused<true><<<a.nblocks, 256, 0, s>>>(a);
+    else
+      k_preprocess_fused<false><<<a.nblocks, 256, 0, s>>>(a);
+    return hipGetLastError();
+  }
   if (a.cov3D_precomp != nullptr) {
     k_preprocess_cull<true><<<a.nblocks, 256, 0, s>>>(a);
     k_preprocess_project<true><<<a.nblocks, 256, 0, s>>>(a);

@@ -114,7 +114,8 @@ typedef struct gcr_layout {
   size_t geom_block_sums;    /* uint32 per 256-Gaussian block (radix fallback path only) */
   size_t geom_vis_list;      /* uint32 per Gaussian: K1 block b's survivors, packed at b*chunk */
   size_t geom_vis_count;     /* uint32 per K1 block */
-  size_t geom_num_rendered;  /* uint64 total */
+  size_t geom_num_rendered;  /* uint64 {num_rendered, longest tile list, go flag} */
+  size_t geom_block_tiles;   /* uint64 per K1 block: its share of num_rendered */
   size_t geom_total;
   /* image buffer */
   size_t img_final_T;   /* float per pixel   (ImageState::accum_alpha) */
@@ -214,6 +215,8 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *   "force_radix"  1: always use the global LSD radix sort path for binning          default 0
  *   "force_global_cursor" 1: count/scatter with device-scope atomics instead of LDS  default 0
  *                     tile tables (the variant used when T*4 B does not fit in LDS)
+ *   "split_preprocess" 1: K1 as two kernels (streaming cull, then exact pass) instead of   default 0
+ *                     the fused one (A/B)
  *   "timing"       1: record per-stage HIP events (see gcr_get_stage_ms)             default 0
  * Returns the previous value or <0 if the name is unknown. */
 int gcr_set_option(const char *name, int value);

@@ -183,6 +183,28 @@ def test_both_binning_paths(oracle_mod, cuda_device, force_radix, force_cursor):
 
 @pytest.mark.parametrize("P,spread,longest", [(9000, 2.0, 4096), (60000, 4.0, 3 * 4096)],
                          ids=["two_runs", "many_runs_three_merge_passes"])
+@pytest.mark.parametrize("split", [0, 1], ids=["fused_k1", "two_kernel_k1"])
+def test_both_preprocess_variants(oracle_mod, cuda_device, split):
+    """K1 as one fused kernel (default: workgroups alternate between streaming their chunk and processing the
+    candidates waiting in LDS, several passes per chunk here) and as two kernels (option split_preprocess): same
+    state, bit for bit.  40 000 Gaussians around the view so that blocks collect more than one pass of candidates."""
+    from gaussiancity_amd import _native as N
+    P, W, H = 40000, 256, 160
+    rs = scenes.camera(W, H, pose_index=4)._replace(sh_degree=2)
+    sc = scenes.blob_scene(P, 53, 2, spread=90.0)
+    fr = _frame(oracle_mod, rs, sc)
+    assert (fr.radii > 0).sum() > 5000
+    N.set_option("split_preprocess", split)
+    try:
+        args, out = G.run_forward(rs, sc, cuda_device)
+        _check_forward(fr, G.decode(P, W, H, out), P, True)
+        dpix = np.random.default_rng(6).normal(size=(3, H, W)).astype(np.float32)
+        _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device),
+                     ["dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"])
+    finally:
+        N.set_option("split_preprocess", 0)
+
+
 def test_tile_list_longer_than_lds_capacity(oracle_mod, cuda_device, P, spread, longest):
     """Lists beyond the LDS sort capacity (4096): those tiles are sorted by the per-tile long-list sort
     (4096-key runs + merge passes through HBM) while the other tiles stay on the LDS path -- no whole-frame
