@@ -41,6 +41,9 @@
 
 GCR_CULL_FN uint32_t gcr_block_mask(float gx, float gy, float cx, float cy, float cz, float pmin,
                                     float tile_x0, float tile_y0) {
+// Nothing here is part of the numerics contract (the result only has to be conservative, and the margins cover
+// a fused multiply-add's single rounding many times over): let the compiler contract, ~30 fewer VALU per entry.
+#pragma clang fp contract(fast)
   if (!(pmin < 0.0f)) return 0u;  // alpha < 1/255 everywhere (power <= 0 always)
   const float det = cx * cz - cy * cy;
   if (!(det > 0.0f) || !(cx > 0.0f) || !(cz > 0.0f)) return 0xFFFFu;

@@ -181,8 +181,6 @@ def test_both_binning_paths(oracle_mod, cuda_device, force_radix, force_cursor):
                  ["dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"])
 
 
-@pytest.mark.parametrize("P,spread,longest", [(9000, 2.0, 4096), (60000, 4.0, 3 * 4096)],
-                         ids=["two_runs", "many_runs_three_merge_passes"])
 @pytest.mark.parametrize("split", [0, 1], ids=["fused_k1", "two_kernel_k1"])
 def test_both_preprocess_variants(oracle_mod, cuda_device, split):
     """K1 as one fused kernel (default: workgroups alternate between streaming their chunk and processing the
@@ -205,6 +203,8 @@ def test_both_preprocess_variants(oracle_mod, cuda_device, split):
         N.set_option("split_preprocess", 0)
 
 
+@pytest.mark.parametrize("P,spread,longest", [(9000, 2.0, 4096), (60000, 4.0, 3 * 4096)],
+                         ids=["two_runs", "many_runs_three_merge_passes"])
 def test_tile_list_longer_than_lds_capacity(oracle_mod, cuda_device, P, spread, longest):
     """Lists beyond the LDS sort capacity (4096): those tiles are sorted by the per-tile long-list sort
     (4096-key runs + merge passes through HBM) while the other tiles stay on the LDS path -- no whole-frame
