@@ -191,7 +191,7 @@ def test_both_preprocess_variants(oracle_mod, cuda_device, split):
     rs = scenes.camera(W, H, pose_index=4)._replace(sh_degree=2)
     sc = scenes.blob_scene(P, 53, 2, spread=90.0)
     fr = _frame(oracle_mod, rs, sc)
-    assert (fr.radii > 0).sum() > 5000
+    assert (fr.radii > 0).sum() > 3000
     N.set_option("split_preprocess", split)
     try:
         args, out = G.run_forward(rs, sc, cuda_device)
@@ -201,6 +201,42 @@ def test_both_preprocess_variants(oracle_mod, cuda_device, split):
                      ["dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"])
     finally:
         N.set_option("split_preprocess", 0)
+
+
+def test_fused_preprocess_with_many_passes_per_block(cuda_device):
+    """The fused K1 kernel's mid-chunk processing passes: with the grid forced down to 12 blocks (GCR_K1_BLOCKS, read
+    once per process -> a subprocess) every block streams ~3400 mostly visible Gaussians, so 256 candidates are
+    waiting several times per chunk, leftovers are moved to the front of the LDS buffer, and a final partial pass
+    runs.  Full state against the oracle, fused and two-kernel."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import gpu_util as G, scenes
+from gaussiancity_amd import _native as N
+from oracle import oracle as O
+from test_gpu_parity import _frame, _check_forward, _check_grads
+P, W, H = 40000, 256, 160
+rs = scenes.camera(W, H, pose_index=4)._replace(sh_degree=1)
+sc = scenes.blob_scene(P, 57, 1, spread=25.0, smax=3.0)
+fr = _frame(O, rs, sc)
+assert (fr.radii > 0).sum() > 30000, (fr.radii > 0).sum()
+dev = torch.device("cuda:0")
+for split in (0, 1):
+    N.set_option("split_preprocess", split)
+    args, out = G.run_forward(rs, sc, dev)
+    _check_forward(fr, G.decode(P, W, H, out), P, True)
+    dpix = np.random.default_rng(6).normal(size=(3, H, W)).astype(np.float32)
+    _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, dev), ["dL_dmean3D", "dL_dsh", "dL_dscale", "dL_dopacity"])
+print("MANY_PASSES_OK")
+""" % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, GCR_K1_BLOCKS="12")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MANY_PASSES_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("P,spread,longest", [(9000, 2.0, 4096), (60000, 4.0, 3 * 4096)],
