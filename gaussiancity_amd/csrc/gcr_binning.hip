@@ -62,11 +62,14 @@ __global__ __launch_bounds__(256) void k_emit(int P, const uint32_t* __restrict_
 // order the reference gets from its stable radix sort on tile<<32|depth over instances emitted
 // in index order (cr/rasterizer_impl.cu:66-99,255-260).
 constexpr int RANK_MERGE_MAX = 1024;  // chunked rank sort + merge below, bitonic network above
-constexpr int TT_THREADS = 512;
+// Threads per workgroup of the tile-table kernels (template parameter TT_THREADS): 512 while two tables fit a CU's
+// LDS (T*4 B <= 64 KiB), 1024 when a table only leaves room for one workgroup per CU (4K images: 130 KiB) so that
+// the CU still runs 16 waves (C5: count 60 -> 57 us, scatter 203 -> 197 us; the scatter there is bound by its
+// 8-byte stores landing in 32-byte sectors, not by occupancy).
 constexpr int TT_MAX_GROUP = 64;  // K1 blocks per group (host guarantees G <= this)
 constexpr int TT_MAX_TBLOCKS = 640;  // 64-tile blocks: T <= 40960 > the LDS limit of 150 KiB / 4 B
 
-template <bool SCATTER>
+template <bool SCATTER, int TT_THREADS>
 __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G, int nblocks_k1, int chunk,
                                                            const uint32_t* __restrict__ vis_list,
                                                            const uint32_t* __restrict__ vis_count,
@@ -646,12 +649,17 @@ int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out) {
 
 static hipError_t tile_table_attr() {
   static hipError_t done = [] {
-    hipError_t e = hipFuncSetAttribute((const void*)k_tile_table<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_tile_table<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    const void* fns[4] = {(const void*)k_tile_table<false, 512>, (const void*)k_tile_table<true, 512>,
+                          (const void*)k_tile_table<false, 1024>, (const void*)k_tile_table<true, 1024>};
+    for (const void* f : fns) {
+      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
   }();
   return done;
 }
+static inline bool tile_table_wide(int T) { return (size_t)T * sizeof(uint32_t) > 64 * 1024; }
 
 hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,
@@ -660,9 +668,14 @@ hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, i
                                  unsigned long long* host_R, unsigned int seq, hipStream_t s) {
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
-  k_tile_table<false><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(
-      T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, nullptr, nullptr, nullptr, nullptr, nullptr,
-      frame, 0ull, 0ull, host_R, seq, block_tiles);
+  if (tile_table_wide(T))
+    k_tile_table<false, 1024><<<NG, 1024, (size_t)T * sizeof(uint32_t), s>>>(
+        T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, nullptr, nullptr, nullptr, nullptr, nullptr,
+        frame, 0ull, 0ull, host_R, seq, block_tiles);
+  else
+    k_tile_table<false, 512><<<NG, 512, (size_t)T * sizeof(uint32_t), s>>>(
+        T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, nullptr, nullptr, nullptr, nullptr, nullptr,
+        frame, 0ull, 0ull, host_R, seq, block_tiles);
   k_table_colscan<<<(T + 63) / 64, 1024, 0, s>>>(table, NG, T, tile_total, tile_local, blk_total, frame);
   return hipGetLastError();
 }
@@ -675,9 +688,14 @@ hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1,
                                    unsigned long long cap_list, unsigned long long* host_longest, hipStream_t s) {
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
-  k_tile_table<true><<<NG, TT_THREADS, (size_t)T * sizeof(uint32_t), s>>>(
-      T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, tile_total, tile_local, blk_total, ranges, pairs,
-      frame, cap_instances, cap_list, host_longest, 0u, nullptr);
+  if (tile_table_wide(T))
+    k_tile_table<true, 1024><<<NG, 1024, (size_t)T * sizeof(uint32_t), s>>>(
+        T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, tile_total, tile_local, blk_total, ranges, pairs,
+        frame, cap_instances, cap_list, host_longest, 0u, nullptr);
+  else
+    k_tile_table<true, 512><<<NG, 512, (size_t)T * sizeof(uint32_t), s>>>(
+        T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, tile_total, tile_local, blk_total, ranges, pairs,
+        frame, cap_instances, cap_list, host_longest, 0u, nullptr);
   return hipGetLastError();
 }
 
