@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--fast-exp", action="store_true", help="non-parity v_exp_f32 variant (A/B only)")
+    ap.add_argument("--sort-in-blend", action="store_true",
+                    help="the forward blend sorts its own tiles (lower frame latency, lower throughput; A/B)")
     ap.add_argument("--split-preprocess", action="store_true",
                     help="K1 as two kernels (streaming cull, then exact pass) instead of the fused one (A/B only)")
     ap.add_argument("--backward", action="store_true",
@@ -142,6 +144,7 @@ def main():
     N.lib()
     N.set_option("fast_exp", 1 if args.fast_exp else 0)
     N.set_option("split_preprocess", 1 if args.split_preprocess else 0)
+    N.set_option("sort_in_blend", 1 if args.sort_in_blend else 0)
 
     def barrier():
         torch.cuda.synchronize()

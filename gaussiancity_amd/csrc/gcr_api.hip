@@ -15,6 +15,7 @@ std::atomic<int> g_fast_exp{0};
 std::atomic<int> g_timing{0};
 std::atomic<int> g_force_radix{0};
 std::atomic<int> g_force_global_cursor{0};
+std::atomic<int> g_sort_in_blend{0};     // 1: the forward blend sorts short tile lists itself (lower frame latency, lower throughput)
 std::atomic<int> g_split_preprocess{0};  // 1: K1 as two kernels (streaming cull, then exact pass) instead of the fused one
 std::atomic<int> g_k7_skip_flush{0};  // timing experiment only: results are wrong when set
 
@@ -35,6 +36,12 @@ int fail_hip(hipError_t e, const char* where) {
   } while (0)
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// Longest tile list (the caller's expectation, or the exact maximum on the staged path) up to which the forward
+// blend sorts its tiles itself.  Its fast path covers lists of one blend chunk (256); a somewhat longer list is
+// still ranked correctly by the same workgroup through global loads (n^2/256 compares per thread), so the
+// threshold leaves room for the longest list to grow from one frame to the next.
+constexpr int64_t GCR_SORT_IN_BLEND_MAX = 384;
 
 // Stage timer: a pair of hipEvents per stage recorded on the caller's stream.  Non-blocking:
 // the previous recording of a stage is resolved when the stage is recorded again (by then it
@@ -193,6 +200,7 @@ int gcr_set_option(const char* name, int value) {
   if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.exchange(value);
   if (!strcmp(name, "k7_skip_flush")) return g_k7_skip_flush.exchange(value);
   if (!strcmp(name, "split_preprocess")) return g_split_preprocess.exchange(value);
+  if (!strcmp(name, "sort_in_blend")) return g_sort_in_blend.exchange(value);
   return -1;
 }
 
@@ -322,9 +330,17 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
     }
   }
   if (int rc = debug_sync(cam, s, "scatter instances")) return rc;
-  if (R_layout > 0) {
+  // Option "sort_in_blend": short lists (the caller's expectation, or the exact maximum on the staged path) are
+  // sorted by the blend's own workgroups and K4 does not run as a kernel.  Measured at C3: one frame alone 0.287 ->
+  // 0.273 ms (one launch less on the critical path), but 4 870 -> 4 580 frames/s with two frames in flight (the
+  // VALU-bound blend grows by 14 us, while the separate latency-bound sort kernel hides behind the other frame's
+  // work) -- so it is off by default.
+  const bool sort_in_blend = R_layout > 0 && list_length_hint <= GCR_SORT_IN_BLEND_MAX && g_sort_in_blend.load() != 0;
+  if (R_layout > 0 && !sort_in_blend) {
     StageTimer t(s, ST_SORT);
-    HIP_TRY(gcr_launch_tile_sort(ranges, T, pairs, (uint64_t*)(bb + L.bin_keys[1]), list, list_length_hint, frame_guard, s),
+    // LDS of the sort sized for 1.5x the expected longest list (longer ones take its run + merge path)
+    HIP_TRY(gcr_launch_tile_sort(ranges, T, pairs, (uint64_t*)(bb + L.bin_keys[1]), list,
+                                 list_length_hint + list_length_hint / 2 + 64, frame_guard, s),
             "tile sort");
   }
   if (int rc = debug_sync(cam, s, "tile sort")) return rc;
@@ -339,9 +355,11 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
   b.out_color = out_color;
   b.frame = frame_guard;
+  b.pairs = pairs;
+  b.list_out = list;
   {
     StageTimer t(s, ST_BLEND_FWD);
-    HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, s), "blend forward");
+    HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, sort_in_blend, s), "blend forward");
   }
   return debug_sync(cam, s, "blend forward");
 }
@@ -526,7 +544,7 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   b.out_color = out_color;
   {
     StageTimer t(s, ST_BLEND_FWD);
-    HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, s), "blend forward");
+    HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, false, s), "blend forward");
   }
   return debug_sync(cam, s, "blend forward");
 }

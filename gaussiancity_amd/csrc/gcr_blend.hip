@@ -102,7 +102,14 @@ GCR_DEV uint32_t slot_of_offset(uint32_t off) { return (off * 1366u) >> 16; }
 //         NON-FINITE colour poisons every pixel of the 4x4 blocks that evaluate the Gaussian
 //         (upstream: only pixels it contributes to), and an accumulator that is exactly -0.0 (needs a
 //         colour below 1e-40) may become +0.0.
-template <bool FAST_EXP>
+//   * SORT (template): the workgroup sorts its own tile first.  GaussianCity's scenes have ~150 entries per tile, and
+//     sorting 150 keys is a microsecond of work for the workgroup that is about to gather them anyway -- as a
+//     separate kernel (K4) it is a latency-bound launch of 18 us on the frame's critical path.  Lists of up to
+//     CHUNK keys are rank-sorted in LDS (every thread counts the keys below its own through wave-uniform 16-byte
+//     reads; unique keys => rank = position); a longer list -- only possible when the caller's length hint was
+//     stale, the host then switches to the K4 path -- is ranked the same way through global loads: slow, correct.
+//     The sorted indices are also written to `list_out` for the backward.
+template <bool FAST_EXP, bool SORT>
 __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[CHUNK + 1];
   __shared__ uint32_t sMask[CHUNK];
@@ -130,6 +137,42 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   float Tw = inside ? 1.0f : -1.0f;
   float C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
   uint32_t last_contributor = 0;
+
+  uint32_t sorted_id = 0;  // SORT, total <= CHUNK: the Gaussian of list position `tid`
+  if (SORT && total > 0) {
+    const uint64_t* __restrict__ seg = a.pairs + r0;
+    uint32_t* __restrict__ out = a.list_out + r0;
+    if (total <= CHUNK) {
+      // keys into LDS (aliasing the record buffer, which is not live yet), padded with ~0 to a multiple of 2
+      uint64_t* sKey = reinterpret_cast<uint64_t*>(sE);
+      const uint64_t mine = tid < total ? seg[tid] : ~0ull;
+      sKey[tid] = mine;
+      __syncthreads();
+      const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(sKey);
+      uint32_t rank = 0;
+      for (int j = 0; j < (total + 1) / 2; j++) {  // wave-uniform (broadcast) reads
+        const ulonglong2 kk = k2[j];
+        rank += (kk.x < mine ? 1u : 0u) + (kk.y < mine ? 1u : 0u);
+      }
+      __syncthreads();  // every thread has read the keys: sMask may be written (it does not alias, sE does)
+      if (tid < total) {
+        sMask[rank] = (uint32_t)mine;  // sMask doubles as the sorted index list until the staging overwrites it
+        out[rank] = (uint32_t)mine;
+      }
+      __syncthreads();
+      sorted_id = tid < total ? sMask[tid] : 0u;
+      __syncthreads();  // sMask / sE are free for the staging below
+    } else {
+      // stale length hint: rank through global memory (n^2 / 256 compares per thread), then blend from list_out
+      for (int i = tid; i < total; i += 256) {
+        const uint64_t mine = seg[i];
+        uint32_t rank = 0;
+        for (int j = 0; j < total; j++) rank += seg[j] < mine ? 1u : 0u;
+        out[rank] = (uint32_t)mine;
+      }
+      __syncthreads();  // workgroup-scope visibility of list_out for the staging loads below
+    }
+  }
 
 // One list entry (record QA/QB/QC at byte offset OFF) against this lane's pixel.
 #define GCR_BLEND_STEP(QA, QB, QC, OFF)                                                      \
@@ -163,7 +206,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
     const int n = min(CHUNK, total - base);
     uint32_t my_mask = 0;
     if (tid < n) {
-      const uint32_t id = a.list[r0 + base + tid];
+      const uint32_t id = !SORT ? a.list[r0 + base + tid]
+                                : (total <= CHUNK ? sorted_id : a.list_out[r0 + base + tid]);
       const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
       const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
       const float pmin = gcr_alpha_skip_bound(q1.y);
@@ -464,13 +508,20 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
 
 }  // namespace
 
-hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool fast_exp, hipStream_t s) {
+hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool fast_exp, bool sort_in_kernel, hipStream_t s) {
   const int T = a.gx * a.gy;
   if (T <= 0) return hipSuccess;
-  if (fast_exp)
-    k_blend_fwd<true><<<T, 256, 0, s>>>(a);
-  else
-    k_blend_fwd<false><<<T, 256, 0, s>>>(a);
+  if (sort_in_kernel) {
+    if (fast_exp)
+      k_blend_fwd<true, true><<<T, 256, 0, s>>>(a);
+    else
+      k_blend_fwd<false, true><<<T, 256, 0, s>>>(a);
+  } else {
+    if (fast_exp)
+      k_blend_fwd<true, false><<<T, 256, 0, s>>>(a);
+    else
+      k_blend_fwd<false, false><<<T, 256, 0, s>>>(a);
+  }
   return hipGetLastError();
 }
 

@@ -73,6 +73,8 @@ struct GcrPreprocessBwdArgs {
 struct GcrBlendArgs {
   const uint32_t* ranges;  // [T][2]
   const uint32_t* list;    // sorted instance -> Gaussian
+  const uint64_t* pairs;   // fwd, sort-in-kernel variant: the tile segments of unsorted (depth << 32 | index) keys
+  uint32_t* list_out;      // ... and where the sorted indices go (the backward walks them)
   const float4* rec;
   int W, H, gx, gy;
   const float* bg;
@@ -131,7 +133,7 @@ hipError_t gcr_launch_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v
 int gcr_sort_passes(int end_bit);
 hipError_t gcr_launch_tile_ranges(const uint64_t* keys, int64_t R, uint32_t* ranges, int T,
                                   hipStream_t s);
-hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool fast_exp, hipStream_t s);
+hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool fast_exp, bool sort_in_kernel, hipStream_t s);
 hipError_t gcr_launch_blend_bwd(const GcrBlendArgs& a, bool fast_exp, hipStream_t s);
 hipError_t gcr_launch_preprocess_bwd(const GcrPreprocessBwdArgs& a, hipStream_t s);
 

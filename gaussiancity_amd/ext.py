@@ -174,7 +174,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                          img.numel(), C.byref(info), out_color.data_ptr(), stream),
                     "gcr_forward_render")
         longest = int(info.max_tile_instances)
-        _hint_put(key, (R + R // 2 + 4096, longest + longest // 2 + 64))
+        _hint_put(key, (R + R // 2 + 4096, longest))  # the library adds its own margin to the longest list
         del keep_c, keep_g
     return R, out_color, radii, geom, binning, img
 

@@ -159,10 +159,12 @@ int gcr_forward_preprocess(const gcr_camera *cam, const gcr_gaussians *g, void *
 
 /* Whole forward in ONE call without a mid-frame host stall.  `binning` must hold
  * gcr_binning_bytes(binning_capacity) bytes; binning_capacity is the caller's guess of
- * num_rendered (e.g. 1.5 x the previous frame's value; 0 = no guess) and tile_list_capacity its
- * guess of the longest per-tile list (0 = 4096).  The list guess only sizes the LDS of the per-tile
- * sort: lists within it are sorted in LDS, longer ones -- of any length -- by the same workgroup with
- * sorted runs merged through the spare key buffer.  All kernels of the frame are enqueued at once --
+ * num_rendered (e.g. 1.5 x the previous frame's value; 0 = no guess) and tile_list_capacity the
+ * longest per-tile list it expects (e.g. the previous frame's; 0 = 4096).  The list expectation only
+ * sizes the LDS of the per-tile sort (1.5 x the expectation; with option "sort_in_blend" an
+ * expectation <= 384 moves the sort into the forward blend) and never affects the result: a list
+ * longer than expected is sorted by a slower path of the same kernel (any length; the sort kernel
+ * merges sorted runs through the spare key buffer).  All kernels of the frame are enqueued at once --
  * they take the tile ranges from device memory and a device-side flag vetoes them if
  * binning_capacity was too small -- and the host waits only for num_rendered, which the exact
  * projection pass accumulates and the next kernel's first workgroup stores into a pinned host word the calling
@@ -215,6 +217,8 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *   "force_radix"  1: always use the global LSD radix sort path for binning          default 0
  *   "force_global_cursor" 1: count/scatter with device-scope atomics instead of LDS  default 0
  *                     tile tables (the variant used when T*4 B does not fit in LDS)
+ *   "sort_in_blend" 1: the forward blend sorts its own tile when the expected longest list  default 0
+ *                     is <= 384 (one launch less: lower frame latency, lower throughput)
  *   "split_preprocess" 1: K1 as two kernels (streaming cull, then exact pass) instead of   default 0
  *                     the fused one (A/B)
  *   "timing"       1: record per-stage HIP events (see gcr_get_stage_ms)             default 0

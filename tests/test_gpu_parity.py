@@ -181,6 +181,33 @@ def test_both_binning_paths(oracle_mod, cuda_device, force_radix, force_cursor):
                  ["dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"])
 
 
+@pytest.mark.parametrize("in_blend", [1, 0], ids=["sort_in_blend", "separate_sort_kernel"])
+@pytest.mark.parametrize("P,longest", [(900, 221), (1200, 297)], ids=["lists_within_a_chunk", "some_lists_beyond_256"])
+def test_tile_sort_inside_the_blend_and_as_a_kernel(oracle_mod, cuda_device, in_blend, P, longest):
+    """K4 has two homes: the per-tile sort kernel (default), or -- option sort_in_blend, for short lists -- the
+    forward blend's own workgroups (LDS rank sort up to one 256-entry chunk; a somewhat longer list, the 297-entry
+    case, through the same workgroup's global-rank path).  Same sorted list, same image; staged first call,
+    speculative second call."""
+    from gaussiancity_amd import _native as N
+    from gaussiancity_amd import ext
+    W = H = 64
+    rs = scenes.camera(W, H)._replace(sh_degree=1)
+    sc = scenes.blob_scene(P, 88, 1, smax=4.0)
+    fr = _frame(oracle_mod, rs, sc)
+    assert int((fr.ranges[:, 1].astype(np.int64) - fr.ranges[:, 0]).max()) == longest
+    ext._capacity_hint.pop((cuda_device.index, P, W, H), None)
+    N.set_option("sort_in_blend", in_blend)
+    try:
+        for _ in range(2):
+            args, out = G.run_forward(rs, sc, cuda_device)
+            _check_forward(fr, G.decode(P, W, H, out), P, True)
+        dpix = np.random.default_rng(9).normal(size=(3, H, W)).astype(np.float32)
+        _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device),
+                     ["dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"])
+    finally:
+        N.set_option("sort_in_blend", 0)
+
+
 @pytest.mark.parametrize("split", [0, 1], ids=["fused_k1", "two_kernel_k1"])
 def test_both_preprocess_variants(oracle_mod, cuda_device, split):
     """K1 as one fused kernel (default: workgroups alternate between streaming their chunk and processing the
