@@ -11,7 +11,7 @@ import sys
 
 # bench.py stage -> substrings of the kernel names launched inside that stage timer (gcr_api.hip)
 STAGES = {
-    "preprocess": ("k_preprocess_cull", "k_preprocess_project"),
+    "preprocess": ("k_preprocess_fused", "k_preprocess_cull", "k_preprocess_project"),
     "scan": ("k_tile_table<false>", "k_tile_table<0>", "k_tile_tableILb0", "k_table_colscan"),
     "emit": ("k_tile_table<true>", "k_tile_table<1>", "k_tile_tableILb1"),
     "sort": ("k_tile_sort",),
