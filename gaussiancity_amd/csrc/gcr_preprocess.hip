@@ -279,85 +279,101 @@ GCR_DEV bool phase_a1_exact(const GcrPreprocessArgs& a, const float (&vm)[16], c
   return true;
 }
 
-// Phase B inputs (SH coefficients / colour, opacity), fetched in one go for the survivors.
-struct PhaseBIn {
-  float sh[48];  // SH coefficients [coef][channel], or colour in sh[0..2] when precomputed
-  float opacity;
+// Phase B: colour (SH evaluation or the caller's colour), record, visible-list entry (and tile counts in the
+// global-cursor variant).
+//
+// computeColorFromSH, cr/forward.cu:20-66.  With M == 16 (the degree-3 layout) a Gaussian's 192 contiguous bytes are
+// consumed in FOUR groups of three dwordx4 loads = four coefficients x three channels each, in coefficient order:
+// every channel's sum is built in exactly the reference's order (the reference adds the terms of a degree left to
+// right, degree after degree), but only 12 coefficient registers are live at a time instead of 48 -- the exact pass
+// shares its registers with the streaming loop of the fused kernel, and fewer registers mean more of its workgroups
+// fit beside another frame's blend.  The memory clobbers between the groups keep the compiler from hoisting all
+// twelve loads to the front again.  (48 scalar loads with a 192-byte lane stride cost ~11 M cache-line requests per
+// frame; that is why the loads are 16-byte ones.)
+struct ShDir {
+  float x, y, z, xx, yy, zz, xy, yz, xz;
 };
 
-GCR_DEV void phase_b_fetch(const GcrPreprocessArgs& a, int idx, PhaseBIn& b) {
-  b.opacity = a.opacities[idx];
-  if (a.colors_precomp == nullptr) {
-    // M == 16 (the degree-3 layout): the 192 contiguous bytes are fetched with 12 dwordx4 loads --
-    // 48 scalar loads with a 192-byte lane stride cost ~11 M cache-line requests per frame.
-    const float* __restrict__ shp = a.shs + (size_t)idx * a.M * 3;
-    if (a.M == 16) {
-      const float4* __restrict__ sh4 = reinterpret_cast<const float4*>(shp);
-#pragma unroll
-      for (int v = 0; v < 12; v++) {
-        const float4 t = sh4[v];
-        b.sh[4 * v] = t.x; b.sh[4 * v + 1] = t.y; b.sh[4 * v + 2] = t.z; b.sh[4 * v + 3] = t.w;
-      }
-    } else {
-      const int nfl = 3 * (a.D + 1) * (a.D + 1);
-#pragma unroll
-      for (int v = 0; v < 48; v++) b.sh[v] = v < nfl ? shp[v] : 0.0f;
-    }
-  } else {
-    b.sh[0] = a.colors_precomp[3 * idx];
-    b.sh[1] = a.colors_precomp[3 * idx + 1];
-    b.sh[2] = a.colors_precomp[3 * idx + 2];
+// term(i) for one channel; the parenthesisation is the reference's left-to-right product
+GCR_DEV float sh_term(int i, const ShDir& d, float s) {
+  switch (i) {
+    case 4: return SH_C2[0] * d.xy * s;
+    case 5: return SH_C2[1] * d.yz * s;
+    case 6: return SH_C2[2] * (2.0f * d.zz - d.xx - d.yy) * s;
+    case 7: return SH_C2[3] * d.xz * s;
+    case 8: return SH_C2[4] * (d.xx - d.yy) * s;
+    case 9: return SH_C3[0] * d.y * (3.0f * d.xx - d.yy) * s;
+    case 10: return SH_C3[1] * d.xy * d.z * s;
+    case 11: return SH_C3[2] * d.y * (4.0f * d.zz - d.xx - d.yy) * s;
+    case 12: return SH_C3[3] * d.z * (2.0f * d.zz - 3.0f * d.xx - 3.0f * d.yy) * s;
+    case 13: return SH_C3[4] * d.x * (4.0f * d.zz - d.xx - d.yy) * s;
+    case 14: return SH_C3[5] * d.z * (d.xx - d.yy) * s;
+    default: return SH_C3[6] * d.x * (d.xx - 3.0f * d.yy) * s;
   }
 }
 
-// Phase B: colour, record, visible-list entry (and tile counts in the global-cursor variant).
+// Adds coefficient i (value s) to a channel's running sum exactly as the reference's expression does.
+GCR_DEV float sh_accumulate(int i, int deg, const ShDir& d, float result, float s) {
+  if (i == 0) return SH_C0 * s;
+  if (i <= 3) {
+    if (deg < 1) return result;
+    if (i == 1) return result - SH_C1 * d.y * s;
+    if (i == 2) return result + SH_C1 * d.z * s;
+    return result - SH_C1 * d.x * s;
+  }
+  if (i <= 8) return deg > 1 ? result + sh_term(i, d, s) : result;
+  return deg > 2 ? result + sh_term(i, d, s) : result;
+}
+
 GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 mean, const Projected& pr,
-                                const PhaseBIn& bin, uint32_t list_pos, uint32_t* __restrict__ vis_list) {
+                                uint32_t list_pos, uint32_t* __restrict__ vis_list) {
+  const float opacity = a.opacities[idx];
   float cr, cg, cb;
   if (a.colors_precomp == nullptr) {
-    // computeColorFromSH, cr/forward.cu:20-66
     const float* __restrict__ cp = a.campos;
     const float ox = mean.x - cp[0], oy = mean.y - cp[1], oz = mean.z - cp[2];
     const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
-    const float x = ox / len, y = oy / len, z = oz / len;
+    ShDir d;
+    d.x = ox / len; d.y = oy / len; d.z = oz / len;
+    d.xx = d.x * d.x; d.yy = d.y * d.y; d.zz = d.z * d.z;
+    d.xy = d.x * d.y; d.yz = d.y * d.z; d.xz = d.x * d.z;
     const int deg = a.D;
-    float res[3];
+    const float* __restrict__ shp = a.shs + (size_t)idx * a.M * 3;
+    float res[3] = {0.0f, 0.0f, 0.0f};
+    if (a.M == 16) {
+      const float4* __restrict__ sh4 = reinterpret_cast<const float4*>(shp);
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-#define GCR_S(i) bin.sh[3 * (i) + ch]
-      float result = SH_C0 * GCR_S(0);
-      if (deg > 0) {
-        result = result - SH_C1 * y * GCR_S(1) + SH_C1 * z * GCR_S(2) - SH_C1 * x * GCR_S(3);
-        if (deg > 1) {
-          const float xx = x * x, yy = y * y, zz = z * z;
-          const float xy = x * y, yz = y * z, xz = x * z;
-          result = result + SH_C2[0] * xy * GCR_S(4) + SH_C2[1] * yz * GCR_S(5) +
-                   SH_C2[2] * (2.0f * zz - xx - yy) * GCR_S(6) + SH_C2[3] * xz * GCR_S(7) +
-                   SH_C2[4] * (xx - yy) * GCR_S(8);
-          if (deg > 2) {
-            result = result + SH_C3[0] * y * (3.0f * xx - yy) * GCR_S(9) + SH_C3[1] * xy * z * GCR_S(10) +
-                     SH_C3[2] * y * (4.0f * zz - xx - yy) * GCR_S(11) +
-                     SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * GCR_S(12) +
-                     SH_C3[4] * x * (4.0f * zz - xx - yy) * GCR_S(13) + SH_C3[5] * z * (xx - yy) * GCR_S(14) +
-                     SH_C3[6] * x * (xx - 3.0f * yy) * GCR_S(15);
-          }
-        }
+      for (int grp = 0; grp < 4; grp++) {  // coefficients 4*grp .. 4*grp+3
+        const float4 v0 = sh4[3 * grp], v1 = sh4[3 * grp + 1], v2 = sh4[3 * grp + 2];
+        const float f[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) res[ch] = sh_accumulate(4 * grp + k, deg, d, res[ch], f[3 * k + ch]);
+        asm volatile("" ::: "memory");
       }
-#undef GCR_S
-      res[ch] = result + 0.5f;
+    } else {
+      const int ncoef = (deg + 1) * (deg + 1);
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if (i < ncoef)
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) res[ch] = sh_accumulate(i, deg, d, res[ch], shp[3 * i + ch]);
     }
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) res[ch] = res[ch] + 0.5f;
     a.clamped[idx] = (uint8_t)((res[0] < 0 ? 1 : 0) | (res[1] < 0 ? 2 : 0) | (res[2] < 0 ? 4 : 0));
     cr = gcr_max(res[0], 0.0f);
     cg = gcr_max(res[1], 0.0f);
     cb = gcr_max(res[2], 0.0f);
   } else {
-    cr = bin.sh[0];
-    cg = bin.sh[1];
-    cb = bin.sh[2];
+    cr = a.colors_precomp[3 * idx];
+    cg = a.colors_precomp[3 * idx + 1];
+    cb = a.colors_precomp[3 * idx + 2];
   }
   float4* __restrict__ rec = a.rec + (size_t)idx * GCR_REC_QUADS;
   rec[0] = make_float4(pr.px, pr.py, pr.conx, pr.cony);
-  rec[1] = make_float4(pr.conz, bin.opacity, cr, cg);
+  rec[1] = make_float4(pr.conz, opacity, cr, cg);
   rec[2] = make_float4(cb, pr.depth, __uint_as_float(pr.rect_x), __uint_as_float(pr.rect_y));
   vis_list[list_pos] = (uint32_t)idx;
   // per-tile instance counts, global-cursor variant only (gcr_binning.hip explains why the
@@ -476,9 +492,7 @@ __global__ __launch_bounds__(256) void k_preprocess_project(const GcrPreprocessA
       lbase = __shfl(lbase, 0, 64);
       if (keep) {
         my_tiles += ((pr.rect_x >> 16) - (pr.rect_x & 0xffffu)) * ((pr.rect_y >> 16) - (pr.rect_y & 0xffffu));
-        PhaseBIn bin;
-        phase_b_fetch(a, idx, bin);
-        preprocess_phase_b(a, idx, in.p, pr, bin, lbase + (uint32_t)__popcll(m & lt_mask), my_list);
+        preprocess_phase_b(a, idx, in.p, pr, lbase + (uint32_t)__popcll(m & lt_mask), my_list);
       }
     }
   }
@@ -603,9 +617,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
           lbase = __shfl(lbase, 0, 64);
           if (keep) {
             my_tiles += ((pr.rect_x >> 16) - (pr.rect_x & 0xffffu)) * ((pr.rect_y >> 16) - (pr.rect_y & 0xffffu));
-            PhaseBIn bin;
-            phase_b_fetch(a, idx, bin);
-            preprocess_phase_b(a, idx, in.p, pr, bin, lbase + (uint32_t)__popcll(mk & lt_mask), my_list);
+            preprocess_phase_b(a, idx, in.p, pr, lbase + (uint32_t)__popcll(mk & lt_mask), my_list);
           }
         }
         done += 256u;
