@@ -460,8 +460,11 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
     return fail(GCR_ERR_OVERFLOW, "num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)");
   info_host->num_rendered = (int64_t)R;
   if (speculate && go) {
-    // longest list: what the most recent scatter kernel of this thread published (a hint for the next guess)
-    info_host->max_tile_instances = (int64_t)((volatile unsigned long long*)rb.pinned)[1];
+    // longest list: what the most recent scatter kernel of this thread published (a hint for the next guess);
+    // before any has (the first speculative frame returns while its own scatter is still queued) the caller's
+    // own expectation is echoed, so that a hint loop does not fall back to "unknown"
+    const unsigned long long seen = ((volatile unsigned long long*)rb.pinned)[1];
+    info_host->max_tile_instances = seen ? (int64_t)seen : tile_list_capacity;
     return 0;
   }
   // retry path: the caller needs the exact longest list of THIS frame to size the sort
