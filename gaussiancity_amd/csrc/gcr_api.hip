@@ -575,10 +575,46 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   const char *gb = (const char*)geom, *bb = (const char*)binning, *ib = (const char*)img;
   const int gx = (cam->img_w + GCR_BLOCK_X - 1) / GCR_BLOCK_X;
   const int gy = (cam->img_h + GCR_BLOCK_Y - 1) / GCR_BLOCK_Y;
+  int nblocks_k1 = 0, chunk_k1 = 0;
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(g_split_preprocess.load() != 0), &nblocks_k1, &chunk_k1);
+
+  // Every output is written here (the reference asks its caller for nine zero-filled tensors,
+  // dgr/rasterize_points.cu:118-126): zeros are streamed over the dense arrays by extra workgroups of the K7
+  // launch, K8 then writes the survivors' values.
+  GcrFillArgs fill;
+  memset(&fill, 0, sizeof(fill));
+  {
+    const unsigned long long P = (unsigned long long)g->P;
+    auto seg = [&](float* p, unsigned long long n) {
+      if (p != nullptr && n != 0) {
+        fill.ptr[fill.nseg] = p;
+        fill.n[fill.nseg++] = n;
+      }
+    };
+    seg(gr->dL_dmeans2D, 3 * P);
+    seg(gr->dL_dcolors, (unsigned long long)GCR_NUM_CHANNELS * P);
+    seg(gr->dL_dopacity, P);
+    seg(gr->dL_dmeans3D, 3 * P);
+    seg(gr->dL_dcov3D, 6 * P);
+    seg(gr->dL_dsh, g->shs ? 3ull * (unsigned long long)g->M * P : 0ull);
+    seg(gr->dL_dscales, 3 * P);
+    seg(gr->dL_drotations, 4 * P);
+    unsigned long long total = 0;
+    for (int i = 0; i < fill.nseg; i++) total += fill.n[i];
+    const unsigned long long want = (total + 4095ull) / 4096ull;  // >= 16 floats per thread
+    fill.blocks = (int)(want < 512ull ? (want ? want : 1ull) : 512ull);  // two workgroups per CU at most
+  }
 
   if (R > 0) {
+    {
+      StageTimer t(s, ST_BLEND_BWD);
+      HIP_TRY(gcr_launch_zero_grad_records(nblocks_k1, chunk_k1, (const uint32_t*)(gb + L.geom_vis_list),
+                                           (const uint32_t*)(gb + L.geom_vis_count), (float4*)gr->dL_dconic, s),
+              "zero gradient records");
+    }
     GcrBlendArgs b;
     memset(&b, 0, sizeof(b));
+    b.fill = fill;
     b.ranges = (const uint32_t*)(ib + L.img_ranges);
     b.list = (const uint32_t*)(bb + L.bin_vals[L.bin_sorted]);
     b.rec = (const float4*)(gb + L.geom_rec);
@@ -591,6 +627,8 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     b.debug_flags = g_k7_skip_flush.load() ? 1 : 0;
     StageTimer t(s, ST_BLEND_BWD);
     HIP_TRY(gcr_launch_blend_bwd(b, g_fast_exp.load() != 0, s), "blend backward");
+  } else {
+    HIP_TRY(gcr_launch_fill(fill, s), "gradient zero fill");
   }
   if (int rc = debug_sync(cam, s, "blend backward")) return rc;
 
@@ -607,7 +645,7 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   a.clamped = (const uint8_t*)(gb + L.geom_clamped);
   a.vis_list = (const uint32_t*)(gb + L.geom_vis_list);
   a.vis_count = (const uint32_t*)(gb + L.geom_vis_count);
-  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(g_split_preprocess.load() != 0), &a.nblocks, &a.chunk);
+  a.nblocks = nblocks_k1; a.chunk = chunk_k1;
   a.grad_rec = (const float4*)gr->dL_dconic;
   a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dcolor = gr->dL_dcolors; a.dL_dopacity = gr->dL_dopacity;
   a.dL_dmean3D = gr->dL_dmeans3D; a.dL_dcov3D = gr->dL_dcov3D; a.dL_dsh = gr->dL_dsh;

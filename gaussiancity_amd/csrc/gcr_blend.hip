@@ -306,7 +306,12 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
   __shared__ float sAcc[CHUNK * 9];  // entry-major: the nine sums of chunk slot j at [9j, 9j+9)
   __shared__ uint32_t sMax[4];
 
-  const int tile = blockIdx.x;
+  if ((int)blockIdx.x < a.fill.blocks) {  // the launch's leading workgroups: zero fill of the dense outputs
+    for (int sgi = 0; sgi < a.fill.nseg; sgi++)
+      gcr_fill_zero_segment(a.fill.ptr[sgi], a.fill.n[sgi], (int)blockIdx.x, a.fill.blocks, (int)threadIdx.x);
+    return;
+  }
+  const int tile = (int)blockIdx.x - a.fill.blocks;
   const int tx = tile % a.gx, ty = tile / a.gx;
   const int tid = threadIdx.x;
   const LaneGeom g = lane_geom(tid, tx, ty);
@@ -529,8 +534,8 @@ hipError_t gcr_launch_blend_bwd(const GcrBlendArgs& a, bool fast_exp, hipStream_
   const int T = a.gx * a.gy;
   if (T <= 0) return hipSuccess;
   if (fast_exp)
-    k_blend_bwd<true><<<T, 256, 0, s>>>(a);
+    k_blend_bwd<true><<<T + a.fill.blocks, 256, 0, s>>>(a);
   else
-    k_blend_bwd<false><<<T, 256, 0, s>>>(a);
+    k_blend_bwd<false><<<T + a.fill.blocks, 256, 0, s>>>(a);
   return hipGetLastError();
 }

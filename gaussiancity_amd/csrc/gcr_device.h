@@ -83,6 +83,26 @@ GCR_DEV void gcr_store_to_host(unsigned long long* p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Workgroup `b` of `nb` (256 threads each) writes its share of zeros over n floats at p: a scalar head up to the
+// first 16-byte boundary, dwordx4 stores, a scalar tail.  Non-temporal: nothing reads these lines soon.
+GCR_DEV void gcr_fill_zero_segment(float* __restrict__ p, unsigned long long n, int b, int nb, int tid) {
+  const unsigned long long mis = ((unsigned long long)(uintptr_t)p >> 2) & 3ull;
+  unsigned long long head = (4ull - mis) & 3ull;
+  if (head > n) head = n;
+  const unsigned long long n4 = (n - head) >> 2;
+  const unsigned long long tail0 = head + (n4 << 2);
+  if (b == 0) {
+    if ((unsigned long long)tid < head) p[tid] = 0.0f;
+    if (tail0 + (unsigned long long)tid < n && tid < 3) p[tail0 + tid] = 0.0f;
+  }
+  typedef float gcr_f4 __attribute__((ext_vector_type(4)));
+  gcr_f4* __restrict__ q = (gcr_f4*)(p + head);
+  const gcr_f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (unsigned long long i = (unsigned long long)b * 256ull + (unsigned long long)tid; i < n4;
+       i += (unsigned long long)nb * 256ull)
+    __builtin_nontemporal_store(z, q + i);
+}
+
 // ---- wave64 primitives -------------------------------------------------------------------
 // DPP butterfly: after the four in-row steps every lane of a 16-lane row holds its row sum;
 // row_bcast:15 / row_bcast:31 then chain the rows so that lanes 48..63 hold the wave sum.

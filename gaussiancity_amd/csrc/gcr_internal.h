@@ -70,6 +70,17 @@ struct GcrPreprocessBwdArgs {
 // K8 reads the record with three dwordx4 loads and writes the API's dL_dmeans2D / dL_dcolors / dL_dopacity.
 #define GCR_GRAD_REC_FLOATS 16
 
+// The dense zero fill of the backward's outputs (every Gaussian K8 does not visit keeps gradient 0): up to eight
+// float arrays, streamed by the first `blocks` workgroups of the K7 launch while its tile workgroups -- which
+// are VALU-bound and leave HBM idle -- walk their lists.
+#define GCR_FILL_SEGMENTS 8
+struct GcrFillArgs {
+  float* ptr[GCR_FILL_SEGMENTS];
+  unsigned long long n[GCR_FILL_SEGMENTS];  // floats
+  int nseg;
+  int blocks;  // workgroups of 256 threads that share the fill
+};
+
 struct GcrBlendArgs {
   const uint32_t* ranges;  // [T][2]
   const uint32_t* list;    // sorted instance -> Gaussian
@@ -83,7 +94,8 @@ struct GcrBlendArgs {
   float* out_color;         // fwd
   const unsigned long long* frame;  // optional device guard: frame[2]==0 -> kernel does nothing
   const float* dL_dpix;     // bwd
-  float* grad_rec;          // bwd: [P][GCR_GRAD_REC_FLOATS] accumulation records (zero-filled by the caller)
+  float* grad_rec;          // bwd: [P][GCR_GRAD_REC_FLOATS] accumulation records (zeroed for K1's survivors)
+  GcrFillArgs fill;         // bwd: blockIdx.x < fill.blocks streams zeros, the rest are the tiles
   int debug_flags;  // experiments only (gcr_set_option "k7_skip_flush"): bit 0 = K7 drops its global atomics
 };
 
@@ -91,6 +103,10 @@ struct GcrBlendArgs {
 hipError_t gcr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present,
                                    hipStream_t s);
 hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, bool split, hipStream_t s);
+// zero the K7 accumulation records of K1's survivors / stream zeros over the backward's outputs (R == 0 frames)
+hipError_t gcr_launch_zero_grad_records(int nblocks, int chunk, const uint32_t* vis_list, const uint32_t* vis_count,
+                                        float4* grad_rec, hipStream_t s);
+hipError_t gcr_launch_fill(const GcrFillArgs& f, hipStream_t s);
 hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long long* total,
                                       hipStream_t s);
 // fallback binning: per-Gaussian tile counts from radii + record rect, then emit in index order

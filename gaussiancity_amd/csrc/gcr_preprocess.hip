@@ -1052,6 +1052,40 @@ hipError_t gcr_launch_scan_tiles(uint32_t* tile_cursor, int stride, uint32_t* ra
   return hipGetLastError();
 }
 
+namespace {
+// K7 adds into the records of the Gaussians in its tile lists, all of them survivors of K1: those are the only
+// records that have to start at zero (and the only ones K8 reads).
+__global__ __launch_bounds__(256) void k_zero_grad_records(int chunk, const uint32_t* __restrict__ vis_list,
+                                                           const uint32_t* __restrict__ vis_count,
+                                                           float4* __restrict__ grad_rec) {
+  const uint32_t nvis = vis_count[blockIdx.x];
+  const uint32_t* __restrict__ my_list = vis_list + (size_t)blockIdx.x * chunk;
+  const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  // four lanes per record: one 64-byte line per quad of lanes
+  for (uint32_t it = threadIdx.x; it < nvis * (GCR_GRAD_REC_FLOATS / 4); it += 256)
+    grad_rec[(size_t)my_list[it / (GCR_GRAD_REC_FLOATS / 4)] * (GCR_GRAD_REC_FLOATS / 4) +
+             (it % (GCR_GRAD_REC_FLOATS / 4))] = z;
+}
+
+__global__ __launch_bounds__(256) void k_fill_zero(const GcrFillArgs f) {
+  for (int sgi = 0; sgi < f.nseg; sgi++)
+    gcr_fill_zero_segment(f.ptr[sgi], f.n[sgi], (int)blockIdx.x, f.blocks, (int)threadIdx.x);
+}
+}  // namespace
+
+hipError_t gcr_launch_zero_grad_records(int nblocks, int chunk, const uint32_t* vis_list, const uint32_t* vis_count,
+                                        float4* grad_rec, hipStream_t s) {
+  if (nblocks <= 0) return hipSuccess;
+  k_zero_grad_records<<<nblocks, 256, 0, s>>>(chunk, vis_list, vis_count, grad_rec);
+  return hipGetLastError();
+}
+
+hipError_t gcr_launch_fill(const GcrFillArgs& f, hipStream_t s) {
+  if (f.blocks <= 0 || f.nseg <= 0) return hipSuccess;
+  k_fill_zero<<<f.blocks, 256, 0, s>>>(f);
+  return hipGetLastError();
+}
+
 hipError_t gcr_launch_preprocess_bwd(const GcrPreprocessBwdArgs& a, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
   k_preprocess_bwd<<<a.nblocks, 256, 0, s>>>(a);

@@ -196,7 +196,9 @@ class GaussianRasterizerWrapper(torch.nn.Module):
     def _get_gaussian_rasterization_settings(self, cam_position, cam_quaternion):
         # dgr/__init__.py:382-402: row-vector (transposed) matrices, black background,
         # sh_degree 0, unit scale modifier.
-        view = self._get_w2c_matrix(cam_position, cam_quaternion).transpose(0, 1)
+        # .contiguous(): same values; the native module would otherwise copy the 16 floats of a strided matrix
+        # on every forward and backward call (a 2-4 us kernel in the frame's dependency chain each time)
+        view = self._get_w2c_matrix(cam_position, cam_quaternion).transpose(0, 1).contiguous()
         proj_t = self.P.transpose(0, 1)
         return GaussianRasterizationSettings(
             img_h=self.sensor_size[1],
@@ -206,9 +208,9 @@ class GaussianRasterizerWrapper(torch.nn.Module):
             bg=torch.tensor([0.0, 0.0, 0.0], dtype=torch.float32, device=self.device),
             scale_modifier=1.0,
             view_matrix=view,
-            proj_matrix=view @ proj_t,
+            proj_matrix=(view @ proj_t).contiguous(),
             sh_degree=0,
-            campos=view.inverse()[3, :3],
+            campos=view.inverse()[3, :3].contiguous(),
             prefiltered=False,
             debug=False,
         )

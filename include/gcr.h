@@ -83,13 +83,15 @@ typedef struct gcr_gaussians {
   const float *cov3D_precomp;  /* [P,6]   or NULL  (exactly one of scales+rotations/cov3D) */
 } gcr_gaussians;
 
-/* Gradient outputs (cr/rasterizer.h:39-48); every array must be ZERO-FILLED by the caller,
- * as dgr/rasterize_points.cu:118-126 does with torch::zeros.  dL_dmeans2D / dL_dcolors / dL_dopacity
- * are written by the preprocess-backward kernel from the accumulation records (Gaussians that were
- * not rendered keep the caller's zeros). */
+/* Gradient outputs (cr/rasterizer.h:39-48).  The arrays may be UNINITIALISED memory: gcr_backward writes every
+ * element of every output (zeros for Gaussians that were not rendered), where the reference asks its caller for
+ * zero-filled tensors (dgr/rasterize_points.cu:118-126, torch::zeros) -- handing in zeroed arrays is harmless.
+ * dL_dmeans2D / dL_dcolors / dL_dopacity are written by the preprocess-backward kernel from the accumulation
+ * records. */
 typedef struct gcr_grads {
   float *dL_dmeans2D;   /* [P,3] (x,y used) */
-  float *dL_dconic;     /* [P, gcr_grad_record_floats() = 16] scratch, 64-byte aligned: the role of the
+  float *dL_dconic;     /* [P, gcr_grad_record_floats() = 16] scratch (contents undefined on return), 64-byte
+                           aligned: the role of the
                            reference's dL_dconic [P,2,2] (dgr/rasterize_points.cu:121), widened to one
                            64-byte accumulation record per Gaussian (colour 3, opacity 1, mean2D 2,
                            conic 3, pad) so that K7's nine atomics per (tile, Gaussian) share a cache line */

@@ -27,4 +27,6 @@ def cuda_device():
         pytest.fail("this test is marked gpu and needs a GPU; none is visible")
     from gaussiancity_amd import _native
     _native.lib()  # fail loudly if libgcr_hip.so is not built
+    from gaussiancity_amd import ext
+    ext.poison_outputs = True  # gcr_backward must write every gradient element itself (include/gcr.h)
     return torch.device("cuda:0")
