@@ -196,9 +196,11 @@ class GaussianRasterizerWrapper(torch.nn.Module):
     def _get_gaussian_rasterization_settings(self, cam_position, cam_quaternion):
         # dgr/__init__.py:382-402: row-vector (transposed) matrices, black background,
         # sh_degree 0, unit scale modifier.
-        # .contiguous(): same values; the native module would otherwise copy the 16 floats of a strided matrix
-        # on every forward and backward call (a 2-4 us kernel in the frame's dependency chain each time)
-        view = self._get_w2c_matrix(cam_position, cam_quaternion).transpose(0, 1).contiguous()
+        # The arithmetic is done on the strided transposes exactly as upstream does it (inverse() of a strided
+        # matrix rounds differently from inverse() of its contiguous copy); what is handed out is .contiguous():
+        # same values, but the native module would otherwise copy the 16 floats of a strided matrix on every
+        # forward and backward call (a 2-4 us kernel in the frame's dependency chain each time).
+        view = self._get_w2c_matrix(cam_position, cam_quaternion).transpose(0, 1)
         proj_t = self.P.transpose(0, 1)
         return GaussianRasterizationSettings(
             img_h=self.sensor_size[1],
@@ -207,7 +209,7 @@ class GaussianRasterizerWrapper(torch.nn.Module):
             tanfovy=math.tan(self.fov_y * 0.5),
             bg=torch.tensor([0.0, 0.0, 0.0], dtype=torch.float32, device=self.device),
             scale_modifier=1.0,
-            view_matrix=view,
+            view_matrix=view.contiguous(),
             proj_matrix=(view @ proj_t).contiguous(),
             sh_degree=0,
             campos=view.inverse()[3, :3].contiguous(),
