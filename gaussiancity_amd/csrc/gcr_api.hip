@@ -606,12 +606,10 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   }
 
   if (R > 0) {
-    {
-      StageTimer t(s, ST_BLEND_BWD);
-      HIP_TRY(gcr_launch_zero_grad_records(nblocks_k1, chunk_k1, (const uint32_t*)(gb + L.geom_vis_list),
-                                           (const uint32_t*)(gb + L.geom_vis_count), (float4*)gr->dL_dconic, s),
-              "zero gradient records");
-    }
+    StageTimer t(s, ST_BLEND_BWD);  // one slot per stage: a second timer of the same stage would halve the average
+    HIP_TRY(gcr_launch_zero_grad_records(nblocks_k1, chunk_k1, (const uint32_t*)(gb + L.geom_vis_list),
+                                         (const uint32_t*)(gb + L.geom_vis_count), (float4*)gr->dL_dconic, s),
+            "zero gradient records");
     GcrBlendArgs b;
     memset(&b, 0, sizeof(b));
     b.fill = fill;
@@ -625,7 +623,6 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     b.dL_dpix = dL_dpix;
     b.grad_rec = gr->dL_dconic;  // [P][GCR_GRAD_REC_FLOATS] accumulation records (include/gcr.h)
     b.debug_flags = g_k7_skip_flush.load() ? 1 : 0;
-    StageTimer t(s, ST_BLEND_BWD);
     HIP_TRY(gcr_launch_blend_bwd(b, g_fast_exp.load() != 0, s), "blend backward");
   } else {
     HIP_TRY(gcr_launch_fill(fill, s), "gradient zero fill");
