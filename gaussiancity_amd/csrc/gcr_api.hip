@@ -602,7 +602,12 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     unsigned long long total = 0;
     for (int i = 0; i < fill.nseg; i++) total += fill.n[i];
     const unsigned long long want = (total + 4095ull) / 4096ull;  // >= 16 floats per thread
-    fill.blocks = (int)(want < 512ull ? (want ? want : 1ull) : 512ull);  // two workgroups per CU at most
+    // Few workgroups on purpose.  Measured backward wall time with 32 / 64 / 128 / 256 / 512 / 1024 of them:
+    // C2 (142 MB of zeros) - / 118 / 117 / 121 / 128 / 136 us, 5M Gaussians at 1920x1080 (1.4 GB) 0.78 / 0.77 / 0.89 /
+    // 0.98 / 1.01 / - ms: more of them only take issue slots and memory queues away from the tile workgroups.
+    unsigned long long cap = 64ull;
+    if (const char* e = getenv("GCR_FILL_BLOCKS")) cap = (unsigned long long)atoi(e);  // experiments only
+    fill.blocks = (int)(want < cap ? (want ? want : 1ull) : cap);
   }
 
   if (R > 0) {

@@ -100,7 +100,7 @@ GCR_DEV void gcr_fill_zero_segment(float* __restrict__ p, unsigned long long n, 
   const gcr_f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
   for (unsigned long long i = (unsigned long long)b * 256ull + (unsigned long long)tid; i < n4;
        i += (unsigned long long)nb * 256ull)
-    __builtin_nontemporal_store(z, q + i);
+    __builtin_nontemporal_store(z, q + i);  // measured: plain stores make the C2 backward 5 % slower
 }
 
 // ---- wave64 primitives -------------------------------------------------------------------
