@@ -14,12 +14,12 @@ mkdir -p $O
 
 # ---- rasterizer (headline path) ----------------------------------------------------------------------------
 B="python $R/bench.py --no-cpu-baseline --no-secondary"
-rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_kt -o k -- $B > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_kt -o k -- $B > /dev/null 2>&1 < /dev/null
 python $R/tools/rocpd_stats.py /tmp/${TAG}_kt/k_results.db $O/${TAG}_kernel_trace_stats.txt > /dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_f -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_w -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
-  --kernel-trace -d /tmp/${TAG}_sq -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_f -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_w -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
+  --kernel-trace -d /tmp/${TAG}_sq -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
 python $R/tools/rocpd_pmc.py /tmp/${TAG}_f/p_results.db $O/${TAG}_pmc_fetch.txt > /dev/null
 python $R/tools/rocpd_pmc.py /tmp/${TAG}_w/p_results.db $O/${TAG}_pmc_write.txt > /dev/null
 python $R/tools/rocpd_pmc.py /tmp/${TAG}_sq/p_results.db $O/${TAG}_pmc_sq.txt > /dev/null
@@ -27,12 +27,12 @@ python $R/tools/make_traffic.py /tmp/${TAG}_f/p_results.db /tmp/${TAG}_w/p_resul
 
 # ---- C2 forward + backward (BASELINE metric's second half): kernel trace + counters for K7 / K8 ---------------
 B="python $R/bench.py --config C2 --backward --no-cpu-baseline --no-secondary"
-rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_c2_kt -o k -- $B --steps 200 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_c2_kt -o k -- $B --steps 200 > /dev/null 2>&1 < /dev/null
 python $R/tools/rocpd_stats.py /tmp/${TAG}_c2_kt/k_results.db $O/${TAG}_c2_bwd_kernel_trace_stats.txt > /dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_c2_f -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_c2_w -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
-  --kernel-trace -d /tmp/${TAG}_c2_sq -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_c2_f -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_c2_w -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
+  --kernel-trace -d /tmp/${TAG}_c2_sq -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
 python $R/tools/rocpd_pmc.py /tmp/${TAG}_c2_f/p_results.db $O/${TAG}_c2_bwd_pmc_fetch.txt > /dev/null
 python $R/tools/rocpd_pmc.py /tmp/${TAG}_c2_w/p_results.db $O/${TAG}_c2_bwd_pmc_write.txt > /dev/null
 python $R/tools/rocpd_pmc.py /tmp/${TAG}_c2_sq/p_results.db $O/${TAG}_c2_bwd_pmc_sq.txt > /dev/null
@@ -44,10 +44,10 @@ python $R/tools/make_traffic.py /tmp/${TAG}_c2_f/p_results.db /tmp/${TAG}_c2_w/p
 for P in visibility grid-encoder; do
   N=${P/-/_}
   B="python $R/bench.py --path $P --no-cpu-baseline"
-  rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_${N}_kt -o k -- $B --steps 24 --warmup 3 > /dev/null 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_${N}_kt -o k -- $B --steps 24 --warmup 3 > /dev/null 2>&1 < /dev/null
   python $R/tools/rocpd_stats.py /tmp/${TAG}_${N}_kt/k_results.db $O/${TAG}_${N}_kernel_trace_stats.txt > /dev/null
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_${N}_f -o p -- $B --steps 6 --warmup 2 > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_${N}_w -o p -- $B --steps 6 --warmup 2 > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_${N}_f -o p -- $B --steps 6 --warmup 2 > /dev/null 2>&1 < /dev/null
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_${N}_w -o p -- $B --steps 6 --warmup 2 > /dev/null 2>&1 < /dev/null
   python $R/tools/rocpd_pmc.py /tmp/${TAG}_${N}_f/p_results.db $O/${TAG}_${N}_pmc_fetch.txt > /dev/null
   python $R/tools/rocpd_pmc.py /tmp/${TAG}_${N}_w/p_results.db $O/${TAG}_${N}_pmc_write.txt > /dev/null
 done

@@ -16,7 +16,7 @@ STAGES = {
     "emit": ("k_tile_table<true>", "k_tile_table<1>", "k_tile_tableILb1"),
     "sort": ("k_tile_sort",),
     "blend_fwd": ("k_blend_fwd",),
-    "blend_bwd": ("k_blend_bwd",),
+    "blend_bwd": ("k_blend_bwd", "k_zero_grad_records"),
     "preprocess_bwd": ("k_preprocess_bwd",),
 }
 SQ_COUNTERS = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
