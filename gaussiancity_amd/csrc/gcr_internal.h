@@ -44,6 +44,10 @@ static inline void gcr_preprocess_grid(int P, int max_blocks, int* nblocks, int*
   long long c = ((long long)P + nb - 1) / nb;
   c = (c + 255) / 256 * 256;
   if (c < 256) c = 256;
+  // two streaming iterations per block once that still leaves >= 512 blocks: a block's one processing pass then
+  // finds twice the candidates (C2, 17 % visible: 41 -> 82 of 256 lanes busy; forward 75.8 -> 70.7 us, the
+  // backward's walk over fewer, longer lists 117.8 -> 119.0 us)
+  if (c < 512 && (long long)P >= 512ll * 512ll) c = 512;
   *chunk = (int)c;
   *nblocks = (int)(((long long)P + c - 1) / c);
   if (*nblocks < 1) *nblocks = 1;
