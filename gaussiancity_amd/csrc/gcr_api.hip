@@ -43,46 +43,52 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // threshold leaves room for the longest list to grow from one frame to the next.
 constexpr int64_t GCR_SORT_IN_BLEND_MAX = 384;
 
-// Stage timer: a pair of hipEvents per stage recorded on the caller's stream.  Non-blocking:
-// the previous recording of a stage is resolved when the stage is recorded again (by then it
-// has completed: same stream, and every forward has a host sync in the middle), so timing can
-// stay enabled inside a benchmark's timed region.  gcr_get_stage_ms() resolves what is
-// pending and reports the average per stage since the last call.
+// Stage timer: pairs of hipEvents per stage recorded on the caller's stream, a ring of STAGE_RING pairs per stage.
+// Non-blocking in practice: a pair is resolved when its ring slot comes round again, STAGE_RING frames later, and no
+// caller keeps that many frames in flight (one pair per stage made the host wait for the PREVIOUS frame's stage
+// before it could enqueue this frame's -- with three frames in flight that wait thinned out the overlap and the
+// timed kernels looked a third shorter than a rocprofv3 trace of the uninstrumented loop shows them).
+// gcr_get_stage_ms() resolves what is pending and reports the average per stage since the last call.
+constexpr int STAGE_RING = 8;
 struct StageSlot {
-  hipEvent_t a = nullptr, b = nullptr;
-  bool pending = false;
+  hipEvent_t a[STAGE_RING] = {}, b[STAGE_RING] = {};
+  bool pending[STAGE_RING] = {};
+  int next = 0;
   double sum_ms = 0.0;
   long count = 0;
 };
 thread_local StageSlot g_slots[ST_COUNT];
 
-void stage_resolve(StageSlot& sl) {
-  if (!sl.pending) return;
+void stage_resolve(StageSlot& sl, int i) {
+  if (!sl.pending[i]) return;
   float ms = 0;
-  if (hipEventSynchronize(sl.b) == hipSuccess && hipEventElapsedTime(&ms, sl.a, sl.b) == hipSuccess) {
+  if (hipEventSynchronize(sl.b[i]) == hipSuccess && hipEventElapsedTime(&ms, sl.a[i], sl.b[i]) == hipSuccess) {
     sl.sum_ms += ms;
     sl.count += 1;
   }
-  sl.pending = false;
+  sl.pending[i] = false;
 }
 
 struct StageTimer {
   hipStream_t s;
   StageSlot* sl = nullptr;
+  int i = 0;
   StageTimer(hipStream_t s_, int stage) : s(s_) {
     if (g_timing.load() == 0) return;
     sl = &g_slots[stage];
-    if (!sl->a) {
-      (void)hipEventCreate(&sl->a);
-      (void)hipEventCreate(&sl->b);
+    i = sl->next;
+    sl->next = (i + 1) % STAGE_RING;
+    if (!sl->a[i]) {
+      (void)hipEventCreate(&sl->a[i]);
+      (void)hipEventCreate(&sl->b[i]);
     }
-    stage_resolve(*sl);
-    (void)hipEventRecord(sl->a, s);
+    stage_resolve(*sl, i);
+    (void)hipEventRecord(sl->a[i], s);
   }
   ~StageTimer() {
     if (!sl) return;
-    (void)hipEventRecord(sl->b, s);
-    sl->pending = true;
+    (void)hipEventRecord(sl->b[i], s);
+    sl->pending[i] = true;
   }
 };
 
@@ -208,7 +214,7 @@ int gcr_get_stage_ms(float* ms_out, int capacity) {
   int n = capacity < (int)ST_COUNT ? capacity : (int)ST_COUNT;
   for (int i = 0; i < n; i++) {
     StageSlot& sl = g_slots[i];
-    stage_resolve(sl);
+    for (int k = 0; k < STAGE_RING; k++) stage_resolve(sl, k);
     ms_out[i] = sl.count ? (float)(sl.sum_ms / (double)sl.count) : 0.0f;
     sl.sum_ms = 0.0;
     sl.count = 0;

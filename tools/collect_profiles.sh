@@ -16,6 +16,10 @@ mkdir -p $O
 B="python $R/bench.py --no-cpu-baseline --no-secondary"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_kt -o k -- $B > /dev/null 2>&1 < /dev/null
 python $R/tools/rocpd_stats.py /tmp/${TAG}_kt/k_results.db $O/${TAG}_kernel_trace_stats.txt > /dev/null
+# the same command on ONE stream: every kernel alone on the GPU -- the durations bench.py's `roofline.launch_ms` and
+# `stages_ms[*].ms_single_stream` report (the default command's trace above shows them stretched by the frames in flight)
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_kt1 -o k -- $B --streams 1 > /dev/null 2>&1 < /dev/null
+python $R/tools/rocpd_stats.py /tmp/${TAG}_kt1/k_results.db $O/${TAG}_kernel_trace_stats_one_stream.txt > /dev/null
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_f -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_w -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
