@@ -184,6 +184,23 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return R, out_color, radii, geom, binning, img
 
 
+def _gradient_buffers(P, M, device):
+    """The reference allocates nine torch::zeros tensors (dgr/rasterize_points.cu:118-126); here they are nine views
+    of ONE uninitialised buffer: gcr_backward writes every element of every output itself (include/gcr.h).
+    dL_dconic is the native side's accumulation scratch: one 64-byte record per Gaussian.
+    Order: dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations."""
+    shapes = ((P, 3), (P, 3), (P, NUM_CHANNELS), (P, N.GRAD_REC_FLOATS), (P, 1), (P, 6), (P, M, 3), (P, 3), (P, 4))
+    sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+    starts, off = [], 0
+    for n in sizes:  # every view starts 256-byte aligned (dL_dconic and dL_drotations are accessed as float4)
+        starts.append(off)
+        off += (n + 63) // 64 * 64
+    flat = (torch.empty if P != 0 else torch.zeros)((off,), dtype=torch.float32, device=device)
+    if poison_outputs and P != 0:
+        flat.fill_(float("nan"))
+    return [flat[st:st + n].view(sh) for st, n, sh in zip(starts, sizes, shapes)]
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations,
                                  scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
                                  tan_fovy, dL_dout_color, sh, degree, campos, geomBuffer, R,
@@ -199,21 +216,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
-    # The reference allocates nine torch::zeros tensors (dgr/rasterize_points.cu:118-126); here they are nine
-    # views of ONE uninitialised buffer: gcr_backward writes every element of every output itself (include/gcr.h).
-    # dL_dconic is the native side's accumulation scratch: one 64-byte record per Gaussian
-    shapes = ((P, 3), (P, 3), (P, NUM_CHANNELS), (P, N.GRAD_REC_FLOATS), (P, 1), (P, 6), (P, M, 3), (P, 3), (P, 4))
-    sizes = [int(torch.Size(sh).numel()) for sh in shapes]
-    starts, off = [], 0
-    for n in sizes:  # every view starts 256-byte aligned (the kernels use float4 stores)
-        starts.append(off)
-        off += (n + 63) // 64 * 64
-    flat = (torch.empty if P != 0 else torch.zeros)((off,), dtype=torch.float32, device=device)
-    if poison_outputs and P != 0:
-        flat.fill_(float("nan"))
-    views = [flat[st:st + n].view(sh) for st, n, sh in zip(starts, sizes, shapes)]
     (dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales,
-     dL_drotations) = views
+     dL_drotations) = _gradient_buffers(P, M, device)
     if P != 0:
         with _on_device(device):
             cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,

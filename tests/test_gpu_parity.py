@@ -230,6 +230,48 @@ def test_both_preprocess_variants(oracle_mod, cuda_device, split):
         N.set_option("split_preprocess", 0)
 
 
+def test_backward_fills_unaligned_uninitialised_outputs(oracle_mod, cuda_device, monkeypatch):
+    """gcr_backward writes every element of every gradient output itself (include/gcr.h): here the eight arrays are
+    separate NaN-filled allocations whose base addresses are only 4-, 8- or 12-byte aligned where the ABI allows it
+    (the zero fill's scalar head / dwordx4 body / scalar tail), with NaN guard words on both sides that must survive.
+    dL_dconic and dL_drotations keep their float4 alignment.  Also the frame in which nothing is rendered (the fill
+    then runs as its own kernel)."""
+    from gaussiancity_amd import _native as N, ext
+    P, W, H = 5000, 112, 80
+    guards = []
+
+    def buffers(P_, M_, device):
+        shapes = ((P_, 3), (P_, 3), (P_, 3), (P_, N.GRAD_REC_FLOATS), (P_, 1), (P_, 6), (P_, M_, 3), (P_, 3), (P_, 4))
+        shift = (1, 2, 3, 0, 1, 3, 0, 2, 0)  # floats past a 256-byte boundary
+        out = []
+        for sh, k in zip(shapes, shift):
+            n = int(torch.Size(sh).numel())
+            raw = torch.full((n + 128,), float("nan"), dtype=torch.float32, device=device)
+            guards.append((raw, 64 + k, n))
+            out.append(raw[64 + k:64 + k + n].view(sh))
+        return out
+
+    monkeypatch.setattr(ext, "_gradient_buffers", buffers)
+    for far in (False, True):
+        guards.clear()
+        rs = scenes.camera(W, H, pose_index=3)._replace(sh_degree=2)
+        sc = scenes.blob_scene(P, 33, 2)
+        if far:
+            sc["means3D"][:, 2] += 10000.0  # behind the camera: R == 0
+        fr = _frame(oracle_mod, rs, sc)
+        args, out = G.run_forward(rs, sc, cuda_device)
+        assert (out[0] == 0) == far
+        dpix = np.random.default_rng(4).normal(size=(3, H, W)).astype(np.float32)
+        ggpu = G.run_backward(args, out, dpix, cuda_device)
+        _check_grads(fr.backward(dpix), ggpu, ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D",
+                                               "dL_dscale", "dL_drot", "dL_dsh"])
+        for i, (raw, lo, n) in enumerate(guards):
+            r = raw.cpu().numpy()
+            assert np.isnan(r[:lo]).all() and np.isnan(r[lo + n:]).all(), "output %d: guard words overwritten" % i
+            if i != 3:  # dL_dconic is scratch
+                assert not np.isnan(r[lo:lo + n]).any(), "output %d: element left unwritten" % i
+
+
 def test_fused_preprocess_with_many_passes_per_block(cuda_device):
     """The fused K1 kernel's mid-chunk processing passes: with the grid forced down to 12 blocks (GCR_K1_BLOCKS, read
     once per process -> a subprocess) every block streams ~3400 mostly visible Gaussians, so 256 candidates are
