@@ -752,16 +752,51 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ curs
 // the same order: cov2D part, + projection part, + SH part.
 __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdArgs a) {
   // dense walk over K1's survivors (== the Gaussians with radii > 0 upstream, cr/backward.cu:151,387)
+  // There are only P_v threads of work here (C2: 84 k = 1.3 waves per SIMD), so the kernel lasts as long as one
+  // thread's chain of memory round trips.  Left to the compiler that chain was nine deep (index; mean/cov/record;
+  // the camera matrices re-fetched with vector loads every iteration because the stores could alias them; SH
+  // coefficients degree by degree behind each `deg >` branch; scale and rotation at the very end).  Here: matrices
+  // once per kernel into SGPRs, and every per-Gaussian input requested right after the index -- two round trips.
+  float vm[16], proj[16], cp[3];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    vm[i] = gcr_uniform(a.view[i]);
+    proj[i] = gcr_uniform(a.proj[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) cp[i] = gcr_uniform(a.campos[i]);
   const uint32_t nvis = a.vis_count[blockIdx.x];
   const uint32_t* __restrict__ my_list = a.vis_list + (size_t)blockIdx.x * a.chunk;
   for (uint32_t it = threadIdx.x; it < nvis; it += 256) {
   const int idx = (int)my_list[it];
-  const float* __restrict__ vm = a.view;
-  const float* __restrict__ proj = a.proj;
   const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
   float cv[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) cv[i] = a.cov3D[6 * (size_t)idx + i];
+  float shv[48];  // SH coefficients [i][channel] (zeros beyond M)
+  uint8_t cl = 0;
+  if (a.shs != nullptr) {
+    const float* __restrict__ shp = a.shs + (size_t)idx * a.M * 3;
+    if (a.M == 16) {
+      const float4* __restrict__ sh4 = reinterpret_cast<const float4*>(shp);
+#pragma unroll
+      for (int q = 0; q < 12; q++) {
+        const float4 v = sh4[q];
+        shv[4 * q] = v.x; shv[4 * q + 1] = v.y; shv[4 * q + 2] = v.z; shv[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 48; q++) shv[q] = q < 3 * a.M ? shp[q] : 0.0f;
+    }
+    cl = a.clamped[idx];
+  }
+  float4 rot = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float scl[3] = {0.0f, 0.0f, 0.0f};
+  if (a.scales != nullptr) {
+    rot = reinterpret_cast<const float4*>(a.rotations)[idx];
+#pragma unroll
+    for (int i = 0; i < 3; i++) scl[i] = a.scales[3 * idx + i];
+  }
   // K7's accumulation record of this Gaussian (gcr_internal.h); the API's per-Gaussian outputs of the
   // blend gradient are written from it here
   const float4 g0 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 0];  // dcolor.rgb, dopacity
@@ -851,20 +886,17 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
 
   // ---- K8b: SH backward (cr/backward.cu:20-138)
   if (a.shs != nullptr) {
-    const float* __restrict__ cp = a.campos;
     const float ox = mean.x - cp[0], oy = mean.y - cp[1], oz = mean.z - cp[2];
     const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
     const float x = ox / len, y = oy / len, z = oz / len;
-    const float* __restrict__ sh = a.shs + (size_t)idx * a.M * 3;
     float* __restrict__ dsh = a.dL_dsh + (size_t)idx * a.M * 3;
-    const uint8_t cl = a.clamped[idx];
     float dRGB[3];
     const float dcol[3] = {g0.x, g0.y, g0.z};
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) dRGB[ch] = dcol[ch] * (((cl >> ch) & 1) ? 0.f : 1.f);
     float gdx[3] = {0, 0, 0}, gdy[3] = {0, 0, 0}, gdz[3] = {0, 0, 0};
     const int deg = a.D;
-#define SHV(i) sh[3 * (i) + ch]
+#define SHV(i) shv[3 * (i) + ch]
 #define DSH(i, w)                  \
   _Pragma("unroll") for (int ch = 0; ch < 3; ch++) dsh[3 * (i) + ch] = (w) * dRGB[ch]
     DSH(0, SH_C0);
@@ -945,14 +977,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
 
   // ---- K8b: cov3D -> scale / rotation (cr/backward.cu:297-373)
   if (a.scales != nullptr) {
-    const float4 rot = reinterpret_cast<const float4*>(a.rotations)[idx];
     const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
     const float Rm[3][3] = {
         {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
         {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
         {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
-    const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
-                        a.scale_modifier * a.scales[3 * idx + 2]};
+    const float s[3] = {a.scale_modifier * scl[0], a.scale_modifier * scl[1], a.scale_modifier * scl[2]};
     float M2[3][3];
 #pragma unroll
     for (int cidx = 0; cidx < 3; cidx++)
