@@ -399,6 +399,19 @@ def main():
                          "alpha_blend": {"kernel": "blend_fwd", "hbm_achieved_GBps": round(blend_ach, 1),
                                          "hbm_frac": round(blend_ach / HBM_PEAK_GBS, 4),
                                          "launch_ms": round(blend_ms, 4)}})
+        # the frame's HBM-bound kernel (K1: streaming cull + exact pass), priced the same way: alone on the GPU,
+        # algorithmic bytes of SURVEY 8d and the counted traffic of the committed --pmc passes
+        k1_ms = stage_alone.get("preprocess", 0.0) or stage.get("preprocess", 0.0)
+        tk1 = tdoc["kernels"].get("preprocess") if tdoc else None
+        if k1_ms > 0:
+            k1_traffic = int((2 * tk1["FETCH_SIZE_KB"] + tk1["WRITE_SIZE_KB"]) * 1024) if tk1 else None
+            k1_alg = ab["preprocess"] / 1e9 / (k1_ms / 1e3)
+            roofline["hbm_kernel"] = {
+                "kernel": "preprocess", "bound": "hbm", "launch_ms": round(k1_ms, 4),
+                "alg_bytes_per_launch": int(ab["preprocess"]), "achieved": round(k1_alg, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(k1_alg / HBM_PEAK_GBS, 4), "traffic": k1_traffic,
+                "traffic_GBps": round(k1_traffic / 1e9 / (k1_ms / 1e3), 1) if k1_traffic else None,
+                "traffic_frac_of_copy_ceiling": round(k1_traffic / 1e9 / (k1_ms / 1e3) / ceiling, 4) if k1_traffic else None}
         T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
         sort_passes = (32 + higher_msb(T_tiles) + 7) // 8
         if blend_like:
