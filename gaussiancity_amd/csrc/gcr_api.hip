@@ -147,6 +147,8 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
 int check_inputs(const gcr_camera* cam, const gcr_gaussians* g, bool need_opacity = true) {
   if (!cam || !g) return fail(GCR_ERR_INVALID_ARGUMENT, "null camera/gaussians record");
   if (g->P < 0) return fail(GCR_ERR_INVALID_ARGUMENT, "P must be >= 0");
+  if (g->P > 700000000)  // the kernels index [3 * i + 2] in 32-bit arithmetic (7e8 Gaussians = 165 GB of inputs at SH0)
+    return fail(GCR_ERR_INVALID_ARGUMENT, "P above 700 000 000 is not supported");
   if (cam->img_w <= 0 || cam->img_h <= 0) return fail(GCR_ERR_INVALID_ARGUMENT, "image size must be positive");
   if (cam->img_w > 16 * 65535 || cam->img_h > 16 * 65535)
     return fail(GCR_ERR_INVALID_ARGUMENT, "image too large for 16-bit tile coordinates");

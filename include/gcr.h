@@ -72,7 +72,7 @@ typedef struct gcr_camera {
 
 /* Per-Gaussian inputs (argument list of cr/rasterizer.h:25-37) */
 typedef struct gcr_gaussians {
-  int32_t P;                   /* number of Gaussians */
+  int32_t P;                   /* number of Gaussians, <= 700 000 000 (32-bit index arithmetic in the kernels) */
   int32_t M;                   /* SH coefficients per Gaussian (sh.size(1)); 0 without SH */
   const float *means3D;        /* [P,3] */
   const float *opacities;      /* [P] */

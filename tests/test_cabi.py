@@ -83,6 +83,10 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     # geometry buffer too small -> -2, before any launch
     g = N.Gaussians(4, 0, p, p, None, p, p, p, None)
     assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), p, 8, p, 8, p, C.byref(R), None) == -2
+    # P beyond what 32-bit index arithmetic covers is refused, not wrapped
+    gbig = N.Gaussians(800_000_000, 0, p, p, None, p, p, p, None)
+    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(gbig), p, 8, p, 8, p, C.byref(R), None) == -1
+    assert b"700 000 000" in lib.gcr_last_error()
     # P == 0 short-circuits successfully (dgr/rasterize_points.cu:71)
     g0 = N.Gaussians(0, 0, None, None, None, None, None, None, None)
     assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g0), None, 0, None, 0, None, C.byref(R), None) == 0
