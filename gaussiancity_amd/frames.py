@@ -160,17 +160,18 @@ class InferenceLoop:
     """Shape of the reference's render loop (scripts/inference.py:655-667) around the rasterizer only: for
     every pose, points [N,14] -> image -> uint8 HWC frame on the host.  The reference does this on the
     legacy default stream with a blocking `tensor_to_image(...).cpu()` per frame; here frames alternate
-    over two side streams and land in two pinned host buffers, so frame f's device->host copy and the
-    host-side consumer overlap frame f+1's render.  `render_fn(points, cam_pos, cam_quat) -> [3,H,W]`
+    over `n_streams` side streams (default 3: the measured optimum of the frame loop, bench.py) and land in as
+    many pinned host buffers, so frame f's device->host copy and the host-side consumer overlap the next
+    frames' renders.  `render_fn(points, cam_pos, cam_quat) -> [3,H,W]`
     is the rasterizer wrapper (or any stand-in on CPU, which degrades to a plain loop)."""
 
-    def __init__(self, render_fn, device=None):
+    def __init__(self, render_fn, device=None, n_streams=3):
         self.render_fn = render_fn
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.cuda = self.device.type == "cuda"
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(2)] if self.cuda else [None, None]
-        self._pinned = [None, None]
-        self._events = [None, None]
+        self.n = max(1, int(n_streams))
+        self.streams = [torch.cuda.Stream(device=self.device) if self.cuda else None for _ in range(self.n)]
+        self._pinned = [None] * self.n
 
     @staticmethod
     def to_uint8_hwc(img):
@@ -180,9 +181,9 @@ class InferenceLoop:
 
     def run(self, points, poses, consume=None):
         """Renders every (cam_pos, cam_quat) of `poses`; returns the list of uint8 [H,W,3] numpy frames, or
-        calls `consume(index, frame)` per frame (the frame buffer is reused two frames later)."""
+        calls `consume(index, frame)` per frame (the frame buffer is reused `n_streams` frames later)."""
         out = []
-        pending = [None, None]  # (index, event) per slot
+        pending = [None] * self.n  # (index, event) per slot
 
         def drain(slot):
             if pending[slot] is None:
@@ -199,7 +200,7 @@ class InferenceLoop:
 
         caller = torch.cuda.current_stream(self.device) if self.cuda else None
         for i, (cam_pos, cam_quat) in enumerate(poses):
-            slot = i & 1
+            slot = i % self.n
             drain(slot)  # the buffer this frame will land in must have been consumed
             if self.cuda:
                 # `points` is normally produced on the caller's stream just before run(): the side
@@ -221,8 +222,8 @@ class InferenceLoop:
                 self._pinned[slot] = frame.contiguous()
                 pending[slot] = (i, None)
         n = len(poses)
-        for slot in ((n & 1), 1 - (n & 1)):  # oldest first
-            drain(slot)
+        for k in range(self.n):  # oldest first
+            drain((n + k) % self.n)
         if self.cuda:  # whatever the caller does next with `points` is ordered after the last frame
             for st in self.streams:
                 caller.wait_stream(st)

@@ -113,3 +113,8 @@ def test_train_step_harness_optimizer_and_inference_loop():
     seen = []
     loop.run(None, poses, consume=lambda i, f: seen.append((i, int(f[0, 0, 0]))))
     assert seen == [(0, 0), (1, 63), (2, 127), (3, 191), (4, 255)]
+    for ns in (1, 2, 4, 7):  # any ring size keeps the order, also one longer than the pose list
+        seen = []
+        frames.InferenceLoop(lambda p, cp, cq: torch.full((3, 2, 2), float(cp[0]) / 2 - 1.0), n_streams=ns).run(
+            None, poses, consume=lambda i, f: seen.append((i, int(f[0, 0, 0]))))
+        assert seen == [(0, 0), (1, 63), (2, 127), (3, 191), (4, 255)], ns

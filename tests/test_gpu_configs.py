@@ -237,8 +237,8 @@ def test_c4_train_step_harness_with_the_real_rasterizer(oracle_mod, cuda_device)
 
 
 def test_inference_loop_frames_equal_the_oracle(oracle_mod, cuda_device):
-    """frames.InferenceLoop (scripts/inference.py:655-667 shape: pose list -> wrapper -> uint8 HWC frames, two
-    streams, pinned double buffer) against the ORACLE's frames, not against the HIP path itself; `points` is
+    """frames.InferenceLoop (scripts/inference.py:655-667 shape: pose list -> wrapper -> uint8 HWC frames, three
+    side streams, ring of pinned buffers) against the ORACLE's frames, not against the HIP path itself; `points` is
     produced on the caller's stream immediately before run() (the ordering ADVICE r01 flagged)."""
     from gaussiancity_amd import frames
     from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper

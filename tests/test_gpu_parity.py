@@ -509,7 +509,7 @@ def test_full_size_properties(cuda_device):
 
 
 def test_inference_loop_matches_sequential_rendering(cuda_device):
-    """frames.InferenceLoop (two streams, pinned double buffer) returns exactly the frames a plain
+    """frames.InferenceLoop (side streams, ring of pinned buffers) returns exactly the frames a plain
     sequential loop over the wrapper produces (scripts/inference.py:655-667)."""
     from gaussiancity_amd import frames, synth
     from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper
