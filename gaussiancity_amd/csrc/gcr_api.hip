@@ -17,7 +17,9 @@ std::atomic<int> g_force_radix{0};
 std::atomic<int> g_force_global_cursor{0};
 std::atomic<int> g_sort_in_blend{0};     // 1: the forward blend sorts short tile lists itself (lower frame latency, lower throughput)
 std::atomic<int> g_split_preprocess{0};  // 1: K1 as two kernels (streaming cull, then exact pass) instead of the fused one
-std::atomic<int> g_k7_skip_flush{0};  // timing experiment only: results are wrong when set
+#ifdef GCR_EXPERIMENTS  // make EXTRA=-DGCR_EXPERIMENTS: timing experiments, never in the shipping library
+std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results are wrong when set
+#endif
 
 enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PRE_BWD, ST_COUNT };
 
@@ -36,6 +38,15 @@ int fail_hip(hipError_t e, const char* where) {
   } while (0)
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// spin-wait hint for the polling loop of gcr_forward
+inline void gcr_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#endif
+}
 
 // Longest tile list (the caller's expectation, or the exact maximum on the staged path) up to which the forward
 // blend sorts its tiles itself.  Its fast path covers lists of one blend chunk (256); a somewhat longer list is
@@ -206,7 +217,9 @@ int gcr_set_option(const char* name, int value) {
   if (!strcmp(name, "timing")) return g_timing.exchange(value);
   if (!strcmp(name, "force_radix")) return g_force_radix.exchange(value);
   if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.exchange(value);
+#ifdef GCR_EXPERIMENTS
   if (!strcmp(name, "k7_skip_flush")) return g_k7_skip_flush.exchange(value);
+#endif
   if (!strcmp(name, "split_preprocess")) return g_split_preprocess.exchange(value);
   if (!strcmp(name, "sort_in_blend")) return g_sort_in_blend.exchange(value);
   return -1;
@@ -385,8 +398,10 @@ struct FrameReadback {
   unsigned int seq = 0;
   int ensure() {
     if (!pinned) {
-      if (hipHostMalloc((void**)&pinned, 8 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) !=
-          hipSuccess)
+      // Portable: the same host thread may render on another device later (ext._on_device) and that device's
+      // kernels store into the same word
+      if (hipHostMalloc((void**)&pinned, 8 * sizeof(unsigned long long),
+                        hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
         return fail(GCR_ERR_DEVICE, "hipHostMalloc for the frame read-back failed");
       for (int i = 0; i < 8; i++) pinned[i] = 0ull;
     }
@@ -453,7 +468,7 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
   volatile unsigned long long* word = rb.pinned;
   unsigned long long v = *word;
   for (unsigned long spins = 0; (unsigned int)(v >> 32) != seq; v = *word) {
-    __builtin_ia32_pause();
+    gcr_cpu_relax();
     if ((++spins & 0xffffu) == 0) {  // every ~65k polls: make sure the stream is still alive
       const hipError_t q = hipStreamQuery(s);
       if (q != hipSuccess && q != hipErrorNotReady) return fail_hip(q, "frame info wait");
@@ -572,6 +587,11 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   if (!gr->dL_dmeans2D || !gr->dL_dconic || !gr->dL_dopacity || !gr->dL_dcolors || !gr->dL_dmeans3D ||
       !gr->dL_dcov3D || (g->shs && !gr->dL_dsh) || (g->scales && (!gr->dL_dscales || !gr->dL_drotations)))
     return fail(GCR_ERR_INVALID_ARGUMENT, "a required gradient output is null");
+  // the accumulation records are read and written as 16-byte quads of 64-byte records, dL_drotations as float4
+  if ((uintptr_t)gr->dL_dconic & 63u)
+    return fail(GCR_ERR_INVALID_ARGUMENT, "dL_dconic (the gradient records) must be 64-byte aligned");
+  if (g->scales && ((uintptr_t)gr->dL_drotations & 15u))
+    return fail(GCR_ERR_INVALID_ARGUMENT, "dL_drotations must be 16-byte aligned");
   if (R < 0 || R > 0x7fffffffll) return fail(GCR_ERR_INVALID_ARGUMENT, "R out of range");
   gcr_layout L;
   compute_layout(g->P, cam->img_w, cam->img_h, R, &L);
@@ -635,7 +655,9 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
     b.dL_dpix = dL_dpix;
     b.grad_rec = gr->dL_dconic;  // [P][GCR_GRAD_REC_FLOATS] accumulation records (include/gcr.h)
+#ifdef GCR_EXPERIMENTS
     b.debug_flags = g_k7_skip_flush.load() ? 1 : 0;
+#endif
     HIP_TRY(gcr_launch_blend_bwd(b, g_fast_exp.load() != 0, s), "blend backward");
   } else {
     HIP_TRY(gcr_launch_fill(fill, s), "gradient zero fill");

@@ -496,7 +496,10 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
 #undef GCR_BWD_STEP
 #undef GCR_BWD_LOAD
     __syncthreads();
-    if (!(a.debug_flags & 1)) {
+#ifdef GCR_EXPERIMENTS
+    if (!(a.debug_flags & 1))
+#endif
+    {
       // lane = (entry within a group of 16) * 16 + component: the nine sums of an entry go out from nine
       // adjacent lanes into one 64-byte record
       const int comp = tid & 15;

@@ -34,9 +34,9 @@ struct GcrPreprocessArgs {
 };
 
 // Persistent-grid geometry of K1 (also used by the kernels that walk its visible lists):
-// as many blocks as are co-resident (one round, no tail), at most GCR_K1_MAX_BLOCKS.
+// 8 workgroups per CU (a measured constant, see gcr_preprocess_resident_blocks), at most GCR_K1_MAX_BLOCKS.
 #define GCR_K1_MAX_BLOCKS 2048
-int gcr_preprocess_resident_blocks(bool split);  // occupancy x CUs of the current device (cached)
+int gcr_preprocess_resident_blocks(bool split);  // 8 x CUs of the current device (cached)
 static inline void gcr_preprocess_grid(int P, int max_blocks, int* nblocks, int* chunk) {
   int nb = (P + 255) / 256;
   if (nb > max_blocks) nb = max_blocks;

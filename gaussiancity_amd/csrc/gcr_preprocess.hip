@@ -527,6 +527,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
   __shared__ uint32_t sIdx[FUSED_CAP];
   __shared__ float sIn[10][FUSED_CAP];
   __shared__ uint32_t cand_tail, vis_tail;
+  __shared__ uint32_t wave_new[2][4];  // candidates each wave found in this iteration, double-buffered by parity
   __shared__ unsigned long long blk_tiles;
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) {
@@ -560,12 +561,21 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   uint32_t my_tiles = 0;
 
+  // `waiting` = candidates in the LDS queue.  It must be block-uniform (it decides whether the workgroup enters a
+  // processing pass with its barriers), so it is NOT read back from cand_tail -- on an iteration without a pass no
+  // barrier separates that read from the next iteration's atomicAdd of a faster wave -- but kept in a
+  // register: every wave publishes how many candidates it appended (slot parity = iteration parity, so the next
+  // iteration's writes cannot overtake a slow reader; the one after that is behind the next barrier) and every
+  // thread adds up the four counts after the barrier.
+  uint32_t waiting = 0;
+  uint32_t parity = 0;
+
   PhaseAIn cur, nxt, nx2;
   long long idx64 = chunk_begin + tid;
   const long long last = (long long)a.P - 1;
   phase_a_load<PRECOMP_COV>(a, idx64 < last ? idx64 : last, cur);
   phase_a_load<PRECOMP_COV>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);
-  for (long long base = chunk_begin; base < chunk_end; base += 256) {
+  for (long long base = chunk_begin; base < chunk_end; base += 256, parity ^= 1u) {
     idx64 = base + tid;
     phase_a_load<PRECOMP_COV>(a, idx64 + 512 < last ? idx64 + 512 : last, nx2);  // prefetch, two iterations ahead
     bool candidate = false;
@@ -574,6 +584,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
       if (!candidate) a.radii[idx64] = 0;
     }
     const uint64_t m = __ballot(candidate);
+    if (lane == 0) wave_new[parity][tid >> 6] = (uint32_t)__popcll(m);
     if (m != 0ull) {
       uint32_t wbase = 0;
       if (lane == 0) wbase = atomicAdd(&cand_tail, (uint32_t)__popcll(m));
@@ -590,7 +601,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
     cur = nxt;
     nxt = nx2;
     __syncthreads();
-    const uint32_t waiting = cand_tail;  // block-uniform
+    waiting += wave_new[parity][0] + wave_new[parity][1] + wave_new[parity][2] + wave_new[parity][3];
     const bool last_iter = base + 256 >= chunk_end;
     if (waiting >= 256u || (last_iter && waiting > 0u)) {
       // ---- processing passes over the waiting candidates: full 256-lane passes, plus the remainder at the end
@@ -640,6 +651,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
         for (int k = 0; k < 10; k++) sIn[k][tid] = mv[k];
       }
       if (tid == 0) cand_tail = left;
+      waiting = left;
       __syncthreads();
     }
   }
@@ -1027,22 +1039,22 @@ hipError_t gcr_launch_mark_visible(int P, const float* means3D, const float* vie
   return hipGetLastError();
 }
 
-// Blocks of the K1 grid (every block owns one contiguous chunk of the Gaussians and one candidate / visible list):
-// as many as the streaming cull can keep co-resident (8 per CU -> 2048 on MI355X).  The fused kernel keeps fewer
-// co-resident (3 per CU) but is launched with the same number: measured, many short blocks co-schedule better with
-// the other frame's blend than one resident round of long ones (4 660 vs 4 470 frames/s), and the geometry does not
-// depend on the "split_preprocess" option.
+// Grid of the persistent K1 kernels (and of every kernel that walks K1's per-block survivor lists).
+// A MEASURED constant, not an occupancy premise: 8 workgroups per CU, at most GCR_K1_MAX_BLOCKS.  That is one
+// resident round of the register-light streaming cull (split mode) and TWO rounds of the fused kernel (119 VGPRs,
+// 22.5 KB LDS: four workgroups per CU) -- for the fused kernel many short blocks measured better than one resident
+// round (4 660 vs 4 470 frames/s at C3: short blocks co-schedule with the other frames' blend workgroups, and a
+// block's latency-bound processing pass is covered by its neighbours' streaming).  Both modes use the same grid so
+// that the survivor-list layout in the geometry buffer does not depend on the mode (the backward re-derives it).
 int gcr_preprocess_resident_blocks(bool split) {
   (void)split;
   static int cached = [] {
-    int dev = 0, cus = 256, per_cu = 4;
+    int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_preprocess_cull<false>, 256, 0) != hipSuccess || per_cu < 1)
-      per_cu = 4;
-    int n = per_cu * cus;
+    int n = 8 * cus;
     if (const char* e = getenv("GCR_K1_BLOCKS")) n = atoi(e);  // experiments only
     return n > GCR_K1_MAX_BLOCKS ? GCR_K1_MAX_BLOCKS : (n < 1 ? 1 : n);
   }();

@@ -68,49 +68,64 @@ def save_checkpoint(path, cfg, epoch_index, gaussian_g, gaussian_d=None):
     torch.save(ckpt, path)
 
 
-def _ensure_easydict():
-    """Upstream checkpoints pickle their `cfg` as easydict.EasyDict (config.py:10, core/train.py:376-380).  When that
-    package is not installed, a minimal attribute-access dict under the same module/class name lets them unpickle."""
-    import sys
-    try:
-        import easydict  # noqa: F401
-        return
-    except ImportError:
-        pass
-    import types
+class _EasyDict(dict):
+    """Attribute-access dict standing in for easydict.EasyDict while a checkpoint is unpickled on a machine without
+    that package (upstream pickles its `cfg` as one: config.py:10, core/train.py:376-380)."""
 
-    class EasyDict(dict):
-        def __init__(self, d=None, **kw):
-            super().__init__()
-            for k, v in dict(d or {}, **kw).items():
-                self[k] = v
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = v
 
-        def __setitem__(self, k, v):
-            if isinstance(v, dict) and not isinstance(v, EasyDict):
-                v = EasyDict(v)
-            super().__setitem__(k, v)
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, _EasyDict):
+            v = _EasyDict(v)
+        super().__setitem__(k, v)
 
-        __setattr__ = __setitem__
+    __setattr__ = __setitem__
 
-        def __getattr__(self, k):
-            try:
-                return self[k]
-            except KeyError:
-                raise AttributeError(k)
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
 
-    EasyDict.__module__ = "easydict"
-    EasyDict.__qualname__ = "EasyDict"
-    mod = types.ModuleType("easydict")
-    mod.EasyDict = EasyDict
-    sys.modules["easydict"] = mod
+
+class _CheckpointPickle:
+    """`pickle_module` for torch.load: the stock pickle machinery, except that the global `easydict.EasyDict`
+    resolves to the installed class or, without the package, to the stand-in above.  Nothing is registered in
+    sys.modules, so a later `import easydict` elsewhere in the process still fails (or finds the real package)
+    instead of silently receiving a partial shim."""
+    import pickle as _p
+    __name__ = "pickle"
+    load = staticmethod(_p.load)
+    loads = staticmethod(_p.loads)
+    dump = staticmethod(_p.dump)
+    dumps = staticmethod(_p.dumps)
+    Pickler = _p.Pickler
+    HIGHEST_PROTOCOL = _p.HIGHEST_PROTOCOL
+    DEFAULT_PROTOCOL = _p.DEFAULT_PROTOCOL
+    UnpicklingError = _p.UnpicklingError
+    PicklingError = _p.PicklingError
+
+    class Unpickler(_p.Unpickler):
+        def find_class(self, module, name):
+            if module == "easydict" and name == "EasyDict":
+                try:
+                    import easydict
+                    return easydict.EasyDict
+                except ImportError:
+                    return _EasyDict
+            return super().find_class(module, name)
 
 
 def load_checkpoint(path, map_location="cpu"):
     """Returns the dict; `gaussian_g` is the generator's state_dict -- its `pos_encoder.embeddings` /
-    `pos_encoder.offsets` entries load into gaussiancity_amd.grid_encoder.GridEncoder unchanged."""
+    `pos_encoder.offsets` entries load into gaussiancity_amd.grid_encoder.GridEncoder unchanged.
+    Upstream checkpoints carry an EasyDict `cfg`, i.e. arbitrary pickled globals: load files you trust
+    (weights_only=False, as upstream's own torch.load calls)."""
     import torch
-    _ensure_easydict()
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    ckpt = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_CheckpointPickle)
     for k in ("cfg", "epoch_index", "gaussian_g"):
         if k not in ckpt:
             raise KeyError("%s: not a GaussianCity checkpoint (missing %r)" % (path, k))

@@ -101,7 +101,9 @@ typedef struct gcr_grads {
   float *dL_dcov3D;     /* [P,6] */
   float *dL_dsh;        /* [P,M,3] (unused when shs==NULL) */
   float *dL_dscales;    /* [P,3] (unused when scales==NULL) */
-  float *dL_drotations; /* [P,4] (unused when scales==NULL) */
+  float *dL_drotations; /* [P,4] (unused when scales==NULL); 16-byte aligned (stored as float4) --
+                           gcr_backward rejects a misaligned dL_dconic / dL_drotations with
+                           GCR_ERR_INVALID_ARGUMENT */
 } gcr_grads;
 
 /* Byte offsets of the sub-arrays carved from the three opaque scratch buffers.  Exposed so

@@ -95,6 +95,25 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     assert lib.gcr_set_option(b"no_such_option", 1) < 0
 
 
+def test_backward_rejects_misaligned_gradient_records_and_experiment_options_are_compiled_out():
+    """dL_dconic is accessed as 64-byte records, dL_drotations as float4 -- a misaligned pointer must come
+    back as GCR_ERR_INVALID_ARGUMENT, not as a memory fault.  And the shipping library must not know the
+    results-are-wrong timing option `k7_skip_flush`."""
+    lib = N.lib()
+    buf = (C.c_float * 256)()
+    p = (C.addressof(buf) + 63) // 64 * 64
+    cam = N.Camera(16, 16, 0.3, 0.3, 1.0, 0, 0, 0, p, p, p, p)
+    g = N.Gaussians(1, 0, p, None, None, p, p, p, None)
+
+    def call(conic, rot):
+        gr = N.Grads(p, conic, p, p, p, p, None, p, rot)
+        return lib.gcr_backward(C.byref(cam), C.byref(g), p, p, 1 << 30, None, 0, p, 1 << 30, 0, p, C.byref(gr), None)
+
+    assert call(p + 4, p) == -1 and b"64-byte" in lib.gcr_last_error()
+    assert call(p, p + 4) == -1 and b"16-byte" in lib.gcr_last_error()
+    assert lib.gcr_set_option(b"k7_skip_flush", 1) < 0
+
+
 def _gcv_header_functions():
     src = open(os.path.join(ROOT, "include", "gcv.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)

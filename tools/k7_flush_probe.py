@@ -1,3 +1,6 @@
+"""K7 with / without its global flush (timing experiment).  Needs an experiment build of the library:
+    make -C gaussiancity_amd/csrc clean all EXTRA=-DGCR_EXPERIMENTS
+(the shipping library does not know the option `k7_skip_flush`)."""
 import sys, time, json
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
