@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libgcr_hip.so")
+# GCR_LIB_PATH: tools/ point it at the experiment build (make -C csrc experiments); nothing else sets it
+LIB_PATH = os.environ.get("GCR_LIB_PATH") or os.path.join(_CSRC, "libgcr_hip.so")
 
 # Every symbol include/gcr.h declares; tests check that the built library exports all of them.
 EXPORTED_SYMBOLS = (
@@ -60,7 +61,8 @@ class Layout(C.Structure):
         ("img_final_T", C.c_size_t), ("img_n_contrib", C.c_size_t), ("img_ranges", C.c_size_t),
         ("img_tile_cursor", C.c_size_t), ("img_tile_table", C.c_size_t), ("img_total", C.c_size_t),
         ("bin_keys", C.c_size_t * 2), ("bin_vals", C.c_size_t * 2), ("bin_hist", C.c_size_t),
-        ("bin_sorted", C.c_size_t), ("bin_total", C.c_size_t),
+        ("bin_sorted", C.c_size_t), ("bin_work", C.c_size_t), ("bin_ckpt", C.c_size_t),
+        ("bin_total", C.c_size_t),
     ]
 
 
@@ -68,7 +70,7 @@ class FrameInfo(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("max_tile_instances", C.c_int64)]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 _lib = None

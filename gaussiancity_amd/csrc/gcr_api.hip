@@ -17,8 +17,10 @@ std::atomic<int> g_force_radix{0};
 std::atomic<int> g_force_global_cursor{0};
 std::atomic<int> g_sort_in_blend{0};     // 1: the forward blend sorts short tile lists itself (lower frame latency, lower throughput)
 std::atomic<int> g_split_preprocess{0};  // 1: K1 as two kernels (streaming cull, then exact pass) instead of the fused one
+std::atomic<int> g_bwd_piece{GCR_PIECE_MAX};  // entries per backward piece (gcr_internal.h "backward pieces")
 #ifdef GCR_EXPERIMENTS  // make EXTRA=-DGCR_EXPERIMENTS: timing experiments, never in the shipping library
 std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results are wrong when set
+std::atomic<unsigned long long*> g_clock_buf{nullptr};  // K7 per-wave phase clocks (gcr_debug_set_clock_buffer)
 #endif
 
 enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PRE_BWD, ST_COUNT };
@@ -122,7 +124,7 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   L->geom_block_sums = o;     o = align_up(o + (nblk + 1) * sizeof(uint32_t));
   L->geom_vis_list = o;       o = align_up(o + p * sizeof(uint32_t));
   L->geom_vis_count = o;      o = align_up(o + (nblk + 1) * sizeof(uint32_t));
-  L->geom_num_rendered = o;   o = align_up(o + 4 * sizeof(uint64_t));  // {R, longest tile list, go flag}
+  L->geom_num_rendered = o;   o = align_up(o + 8 * sizeof(uint64_t));  // frame words (gcr_internal.h: GCR_FRAME_*)
   L->geom_block_tiles = o;    o = align_up(o + GCR_K1_MAX_BLOCKS * sizeof(uint64_t));  // K1 blocks' shares of R
   L->geom_total = o;
 
@@ -152,6 +154,10 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   L->bin_keys[0] = o;  o = align_up(o + r * sizeof(uint64_t));
   L->bin_keys[1] = o;  o = align_up(o + r * sizeof(uint64_t));
   L->bin_hist = o;     o = align_up(o + gcr_sort_hist_bytes((int64_t)r, end_bit));
+  // (tile, piece) slots of the backward blend, sized for the smallest piece the option "bwd_piece" admits
+  const size_t slots = r ? (size_t)gcr_piece_slots(r, T, GCR_PIECE_MIN) : 0;
+  L->bin_work = o;       o = align_up(o + slots * 16);
+  L->bin_ckpt = o;       o = align_up(o + slots * (size_t)GCR_CKPT_BYTES);
   L->bin_total = o;
 }
 
@@ -185,6 +191,11 @@ int check_inputs(const gcr_camera* cam, const gcr_gaussians* g, bool need_opacit
 }  // namespace
 
 extern "C" {
+
+#ifdef GCR_EXPERIMENTS
+// experiment builds only, not declared in include/gcr.h: device buffer of (grid x 4 x 10) u64 for K7's phase clocks
+void gcr_debug_set_clock_buffer(void* dev_ptr) { g_clock_buf.store((unsigned long long*)dev_ptr); }
+#endif
 
 int gcr_abi_version(void) { return GCR_ABI_VERSION; }
 int gcr_grad_record_floats(void) { return GCR_GRAD_REC_FLOATS; }
@@ -222,6 +233,10 @@ int gcr_set_option(const char* name, int value) {
 #endif
   if (!strcmp(name, "split_preprocess")) return g_split_preprocess.exchange(value);
   if (!strcmp(name, "sort_in_blend")) return g_sort_in_blend.exchange(value);
+  if (!strcmp(name, "bwd_piece")) {
+    const int v = value < GCR_PIECE_MIN ? GCR_PIECE_MIN : (value > GCR_PIECE_MAX ? GCR_PIECE_MAX : value);
+    return g_bwd_piece.exchange(v);
+  }
   return -1;
 }
 
@@ -310,6 +325,18 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
   return 0;
 }
 
+// Where the forward blend leaves its checkpoints (gcr_internal.h "backward pieces").  `binning` may be null when
+// nothing can be rendered (R_layout == 0): the tiles are empty then and the backward never launches its blend.
+static void set_piece_args(GcrBlendArgs& b, const gcr_layout& L, void* binning, void* geom) {
+  char* bb = (char*)binning;
+  b.piece = g_bwd_piece.load();
+  b.ckpt = bb ? (float4*)(bb + L.bin_ckpt) : nullptr;
+  b.work = bb ? (uint4*)(bb + L.bin_work) : nullptr;
+  b.ckpt_off = L.bin_ckpt;
+  b.work_off = L.bin_work;
+  b.frame_out = (unsigned long long*)((char*)geom + L.geom_num_rendered);
+}
+
 // Enqueues scatter + per-tile LDS sort + forward blend (the default binning path).
 // `frame_guard` (device {R, max, go}) makes the three kernels no-ops when go == 0.
 static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, void* geom, void* binning, void* img,
@@ -378,6 +405,7 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   b.frame = frame_guard;
   b.pairs = pairs;
   b.list_out = list;
+  set_piece_args(b, L, R_layout > 0 ? binning : nullptr, geom);
   {
     StageTimer t(s, ST_BLEND_FWD);
     HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, sort_in_blend, s), "blend forward");
@@ -568,6 +596,7 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   b.final_T = (float*)(ib + L.img_final_T);
   b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
   b.out_color = out_color;
+  set_piece_args(b, L, binning, geom);
   {
     StageTimer t(s, ST_BLEND_FWD);
     HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, false, s), "blend forward");
@@ -655,8 +684,12 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
     b.dL_dpix = dL_dpix;
     b.grad_rec = gr->dL_dconic;  // [P][GCR_GRAD_REC_FLOATS] accumulation records (include/gcr.h)
+    b.binning_base = bb;
+    b.frame_in = (const unsigned long long*)(gb + L.geom_num_rendered);
+    // (the kernel takes the piece size, the checkpoints and its work list from what the forward left in frame_in)
 #ifdef GCR_EXPERIMENTS
-    b.debug_flags = g_k7_skip_flush.load() ? 1 : 0;
+    b.debug_flags = g_k7_skip_flush.load();  // bit 0: no global flush, bit 1: no zero fill, bit 2: no LDS adds
+    b.clock_buf = g_clock_buf.load();
 #endif
     HIP_TRY(gcr_launch_blend_bwd(b, g_fast_exp.load() != 0, s), "blend backward");
   } else {

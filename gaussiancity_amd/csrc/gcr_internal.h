@@ -85,6 +85,40 @@ struct GcrFillArgs {
   int blocks;  // workgroups of 256 threads that share the fill
 };
 
+// ---- backward pieces -------------------------------------------------------------------------------------
+// The forward blend walks a tile's list in PIECES of equal size (<= P entries, P = option "bwd_piece") and leaves,
+// at every piece boundary it crosses, a CHECKPOINT of the per-pixel state (T, prefix colour) -- 16 bytes x 256
+// pixels -- plus the final state once it has crossed one.  The backward blend then works on (tile, piece) ITEMS
+// instead of whole tiles: a piece that is not the pixel's last starts from the checkpoint behind it (T from the
+// forward, accum_rec = (C_final - C_prefix) / T) instead of walking everything behind it first
+// (cr/backward.cu:495-580 walks the whole list per tile).
+// Checkpoint slots: tile t's pieces own the slots from
+//   slot_base(t) = floor(ranges[t].start / P) + t,   slot_base(t) + ceil(len / P) <= slot_base(t + 1),
+// so neither a prefix sum over tiles nor a host-side count is needed; total slots = floor(R / P) + T.  Slot
+// slot_base(t) + k holds the checkpoint at boundary k + 1 (k < pieces - 1); the tile's LAST slot holds the final state.
+// Work list: every forward workgroup appends one 16-byte item {tile, list start, list length, piece} per piece it
+// walked into (one returning atomic per tile on the frame word GCR_FRAME_NWORK); the backward's persistent
+// workgroups stride over that dense list.
+#define GCR_PIECE_MIN 64
+#define GCR_PIECE_MAX 256
+#define GCR_CKPT_BYTES 4096  // 256 pixels x float4
+static inline __host__ __device__ uint32_t gcr_piece_count(uint32_t len, uint32_t P) { return (len + P - 1u) / P; }
+static inline __host__ __device__ uint32_t gcr_piece_size(uint32_t len, uint32_t P) {
+  const uint32_t n = gcr_piece_count(len, P);
+  return n ? (len + n - 1u) / n : 0u;  // equal pieces: 273 entries at P = 128 -> 3 x 91, not 128 + 128 + 17
+}
+static inline __host__ __device__ unsigned long long gcr_piece_slots(unsigned long long R, unsigned long long T,
+                                                                     unsigned long long P) {
+  return R / P + T;
+}
+// device frame words (geometry buffer, gcr_layout.geom_num_rendered): [0] R, [1] longest list, [2] go flag,
+// [3] piece size the forward used, [4] / [5] byte offsets of the checkpoints / the work list in the binning buffer,
+// [6] number of work items (zeroed by the kernel that publishes R, bumped by the forward blend)
+#define GCR_FRAME_PIECE 3
+#define GCR_FRAME_CKPT_OFF 4
+#define GCR_FRAME_WORK_OFF 5
+#define GCR_FRAME_NWORK 6
+
 struct GcrBlendArgs {
   const uint32_t* ranges;  // [T][2]
   const uint32_t* list;    // sorted instance -> Gaussian
@@ -99,8 +133,19 @@ struct GcrBlendArgs {
   const unsigned long long* frame;  // optional device guard: frame[2]==0 -> kernel does nothing
   const float* dL_dpix;     // bwd
   float* grad_rec;          // bwd: [P][GCR_GRAD_REC_FLOATS] accumulation records (zeroed for K1's survivors)
-  GcrFillArgs fill;         // bwd: blockIdx.x < fill.blocks streams zeros, the rest are the tiles
-  int debug_flags;  // experiments only (gcr_set_option "k7_skip_flush"): bit 0 = K7 drops its global atomics
+  GcrFillArgs fill;         // bwd: zero fill of the dense outputs, streamed in slices between the work items
+  int debug_flags;  // experiment builds only (GCR_EXPERIMENTS, "k7_skip_flush"): bit 0 = K7 drops its global atomics
+  // pieces / checkpoints (above)
+  int piece;                       // fwd: piece size P
+  float4* ckpt;                    // fwd: [slots][256] checkpoints
+  uint4* work;                     // fwd: [slots] work items {tile, list start, list length, piece}
+  unsigned long long* frame_out;   // fwd: device frame words; [3..5] published by the first tile, [6] bumped by all
+  unsigned long long ckpt_off, work_off;  // fwd: what it publishes (byte offsets in the binning buffer)
+  const char* binning_base;        // bwd: checkpoints / work list are found through the frame words
+  const unsigned long long* frame_in;  // bwd
+#ifdef GCR_EXPERIMENTS
+  unsigned long long* clock_buf;   // bwd: [grid][4 waves][10] phase clocks (gcr_debug_set_clock_buffer), or null
+#endif
 };
 
 // launchers (each enqueues on `s`, returns hipGetLastError())

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GCR_ABI_VERSION 4
+#define GCR_ABI_VERSION 5
 #define GCR_BLOCK_X 16 /* cr/config.h:16 */
 #define GCR_BLOCK_Y 16 /* cr/config.h:17 */
 #define GCR_NUM_CHANNELS 3 /* cr/config.h:15 */
@@ -118,7 +118,8 @@ typedef struct gcr_layout {
   size_t geom_block_sums;    /* uint32 per 256-Gaussian block (radix fallback path only) */
   size_t geom_vis_list;      /* uint32 per Gaussian: K1 block b's survivors, packed at b*chunk */
   size_t geom_vis_count;     /* uint32 per K1 block */
-  size_t geom_num_rendered;  /* uint64 {num_rendered, longest tile list, go flag} */
+  size_t geom_num_rendered;  /* uint64 {num_rendered, longest tile list, go flag, backward piece size,
+                                byte offsets of bin_ckpt / bin_work as the forward carved them, number of work items} */
   size_t geom_block_tiles;   /* uint64 per K1 block: its share of num_rendered */
   size_t geom_total;
   /* image buffer */
@@ -134,6 +135,10 @@ typedef struct gcr_layout {
   size_t bin_vals[2]; /* uint32 per instance, ping/pong */
   size_t bin_hist;    /* radix-sort histogram table */
   size_t bin_sorted;  /* 0 or 1: which ping/pong half holds the sorted list */
+  size_t bin_work;      /* 16 B per (tile, piece) slot: work items of the backward blend {tile, list start, list
+                           length, piece}, appended by the forward blend for every piece it walked into */
+  size_t bin_ckpt;      /* 4096 B per slot: per-pixel (T, prefix colour) at the piece boundaries the forward
+                           blend crossed -- what lets the backward blend start in the middle of a tile list */
   size_t bin_total;
 } gcr_layout;
 
