@@ -187,19 +187,20 @@ def main():
         t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items() if isinstance(v, np.ndarray)}
         empty = torch.Tensor([])
 
-        def fwd(pose):
+        def fwd(pose, for_backward=False):
             rs = cams[pose % len(cams)]
             a = (rs.bg, t["means3D"], empty if use_sh else t["colors_precomp"], t["opacities"],
                  t["scales"], t["rotations"], rs.scale_modifier, empty, rs.view_matrix, rs.proj_matrix,
                  rs.tanfovx, rs.tanfovy, rs.img_h, rs.img_w, t["shs"] if use_sh else empty,
                  rs.sh_degree, rs.campos, False, False)
-            return a, ext.rasterize_gaussians(*a)
+            # `for_backward`: the hint RasterizeGaussiansFunction gives the native side when an input requires a gradient
+            return a, ext.rasterize_gaussians(*a, _for_backward=for_backward)
 
         return cfg, sc, cams, use_sh, fwd
 
     def make_fwd_bwd(fwd_fn, dpix):
         def fb(pose):
-            a, o = fwd_fn(pose)
+            a, o = fwd_fn(pose, True)
             (bg, m3, col, opa, scl, rot, smod, cov, view, proj, tfx, tfy, h, w, sh, deg, campos, _, _) = a
             R, color, radii, geom, binning, img = o
             g = ext.rasterize_gaussians_backward(bg, m3, radii, col, scl, rot, smod, cov, view, proj, tfx, tfy,

@@ -34,6 +34,7 @@ class Camera(C.Structure):
         ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("bg", C.c_void_p), ("view_matrix", C.c_void_p),
         ("proj_matrix", C.c_void_p), ("campos", C.c_void_p),
+        ("backward", C.c_int32),  # hint: a backward call will follow (sizes the forward's checkpoint pieces)
     ]
 
 
@@ -61,7 +62,7 @@ class Layout(C.Structure):
         ("img_final_T", C.c_size_t), ("img_n_contrib", C.c_size_t), ("img_ranges", C.c_size_t),
         ("img_tile_cursor", C.c_size_t), ("img_tile_table", C.c_size_t), ("img_total", C.c_size_t),
         ("bin_keys", C.c_size_t * 2), ("bin_vals", C.c_size_t * 2), ("bin_hist", C.c_size_t),
-        ("bin_sorted", C.c_size_t), ("bin_work", C.c_size_t), ("bin_ckpt", C.c_size_t),
+        ("bin_sorted", C.c_size_t), ("bin_work", C.c_size_t), ("bin_mask", C.c_size_t), ("bin_ckpt", C.c_size_t),
         ("bin_total", C.c_size_t),
     ]
 

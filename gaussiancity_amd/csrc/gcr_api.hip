@@ -17,7 +17,7 @@ std::atomic<int> g_force_radix{0};
 std::atomic<int> g_force_global_cursor{0};
 std::atomic<int> g_sort_in_blend{0};     // 1: the forward blend sorts short tile lists itself (lower frame latency, lower throughput)
 std::atomic<int> g_split_preprocess{0};  // 1: K1 as two kernels (streaming cull, then exact pass) instead of the fused one
-std::atomic<int> g_bwd_piece{GCR_PIECE_MAX};  // entries per backward piece (gcr_internal.h "backward pieces")
+std::atomic<int> g_bwd_piece{128};  // entries per backward piece of frames rendered for a backward (gcr_camera.backward)
 #ifdef GCR_EXPERIMENTS  // make EXTRA=-DGCR_EXPERIMENTS: timing experiments, never in the shipping library
 std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results are wrong when set
 std::atomic<unsigned long long*> g_clock_buf{nullptr};  // K7 per-wave phase clocks (gcr_debug_set_clock_buffer)
@@ -157,6 +157,7 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   // (tile, piece) slots of the backward blend, sized for the smallest piece the option "bwd_piece" admits
   const size_t slots = r ? (size_t)gcr_piece_slots(r, T, GCR_PIECE_MIN) : 0;
   L->bin_work = o;       o = align_up(o + slots * 16);
+  L->bin_mask = o;       o = align_up(o + r * sizeof(uint16_t));
   L->bin_ckpt = o;       o = align_up(o + slots * (size_t)GCR_CKPT_BYTES);
   L->bin_total = o;
 }
@@ -327,14 +328,23 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
 
 // Where the forward blend leaves its checkpoints (gcr_internal.h "backward pieces").  `binning` may be null when
 // nothing can be rendered (R_layout == 0): the tiles are empty then and the backward never launches its blend.
-static void set_piece_args(GcrBlendArgs& b, const gcr_layout& L, void* binning, void* geom) {
+static void set_piece_args(GcrBlendArgs& b, const gcr_camera* cam, const gcr_layout& L, void* binning, void* geom) {
   char* bb = (char*)binning;
-  b.piece = g_bwd_piece.load();
+  // Measured (tools/piece_probe.py): the backward blend balances best with 128-entry pieces (C2: 111 -> 95 us), which
+  // cost the forward blend ~10 % (more staging rounds, more sentinel steps) -- so only frames announced as training
+  // frames pay for them.
+  b.piece = cam->backward ? g_bwd_piece.load() : GCR_PIECE_MAX;
   b.ckpt = bb ? (float4*)(bb + L.bin_ckpt) : nullptr;
   b.work = bb ? (uint4*)(bb + L.bin_work) : nullptr;
+  b.mask_out = bb ? (uint16_t*)(bb + L.bin_mask) : nullptr;
   b.ckpt_off = L.bin_ckpt;
   b.work_off = L.bin_work;
+  b.mask_off = L.bin_mask;
   b.frame_out = (unsigned long long*)((char*)geom + L.geom_num_rendered);
+  if (const char* e = getenv("GCR_K6_NOEXTRAS")) {  // A/B only: what the backward's state costs the forward blend
+    if (strchr(e, 'w')) { b.ckpt = nullptr; b.work = nullptr; }
+    if (strchr(e, 'm')) b.mask_out = nullptr;
+  }
 }
 
 // Enqueues scatter + per-tile LDS sort + forward blend (the default binning path).
@@ -405,7 +415,7 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   b.frame = frame_guard;
   b.pairs = pairs;
   b.list_out = list;
-  set_piece_args(b, L, R_layout > 0 ? binning : nullptr, geom);
+  set_piece_args(b, cam, L, R_layout > 0 ? binning : nullptr, geom);
   {
     StageTimer t(s, ST_BLEND_FWD);
     HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, sort_in_blend, s), "blend forward");
@@ -596,7 +606,7 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   b.final_T = (float*)(ib + L.img_final_T);
   b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
   b.out_color = out_color;
-  set_piece_args(b, L, binning, geom);
+  set_piece_args(b, cam, L, binning, geom);
   {
     StageTimer t(s, ST_BLEND_FWD);
     HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, false, s), "blend forward");
@@ -658,11 +668,12 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     seg(gr->dL_drotations, 4 * P);
     unsigned long long total = 0;
     for (int i = 0; i < fill.nseg; i++) total += fill.n[i];
-    const unsigned long long want = (total + 4095ull) / 4096ull;  // >= 16 floats per thread
-    // Few workgroups on purpose.  Measured backward wall time with 32 / 64 / 128 / 256 / 512 / 1024 of them:
-    // C2 (142 MB of zeros) - / 118 / 117 / 121 / 128 / 136 us, 5M Gaussians at 1920x1080 (1.4 GB) 0.78 / 0.77 / 0.89 /
-    // 0.98 / 1.01 / - ms: more of them only take issue slots and memory queues away from the tile workgroups.
-    unsigned long long cap = 64ull;
+    const unsigned long long want = (total + 1023ull) / 1024ull;  // >= 16 floats per thread of a 64-thread wave
+    // Few waves on purpose: the fill rides in the backward blend's launch as extra one-wave workgroups at the front
+    // of its grid.  Measured (round 2, 256-thread workgroups) with 64 / 128 / 256 / 512 / 1024 of them at C2 (142 MB
+    // of zeros): 118 / 117 / 121 / 128 / 136 us backward wall time -- more of them only take issue slots and memory
+    // queues away from the walking waves.  256 waves = the same 16k threads.
+    unsigned long long cap = 256ull;
     if (const char* e = getenv("GCR_FILL_BLOCKS")) cap = (unsigned long long)atoi(e);  // experiments only
     fill.blocks = (int)(want < cap ? (want ? want : 1ull) : cap);
   }
@@ -686,7 +697,8 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     b.grad_rec = gr->dL_dconic;  // [P][GCR_GRAD_REC_FLOATS] accumulation records (include/gcr.h)
     b.binning_base = bb;
     b.frame_in = (const unsigned long long*)(gb + L.geom_num_rendered);
-    // (the kernel takes the piece size, the checkpoints and its work list from what the forward left in frame_in)
+    b.R = (unsigned long long)R;
+    b.piece = g_bwd_piece.load();  // sizes the grid only: the kernel takes the forward's piece size from frame_in
 #ifdef GCR_EXPERIMENTS
     b.debug_flags = g_k7_skip_flush.load();  // bit 0: no global flush, bit 1: no zero fill, bit 2: no LDS adds
     b.clock_buf = g_clock_buf.load();

@@ -114,7 +114,6 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
         frame[0] = total;
         frame[1] = 0ull;
         frame[2] = 0ull;
-        frame[GCR_FRAME_NWORK] = 0ull;  // the forward blend appends its backward work items from here
         if (host_word != nullptr)
           gcr_store_to_host(host_word, ((unsigned long long)seq << 32) | (total > 0xffffffffull ? 0xffffffffull : total));
       }

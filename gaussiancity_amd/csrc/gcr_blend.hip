@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
       sE[tid].c = make_float4(q2.x, pmin, 0.0f, 0.0f);
     }
     sMask[tid] = my_mask;
+    if (tid < n && a.mask_out != nullptr) a.mask_out[r0 + base + tid] = (uint16_t)my_mask;  // reused by the backward
     __syncthreads();
     if (__ballot(Tw > 0.0f) == 0ull) continue;  // this wave's quadrant is finished; keep voting
     // compact the chunk into this wave's four row lists (ascending list order is preserved)
@@ -286,25 +287,24 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
     a.out_color[plane + pix_id] = C1 + Tout * a.bg[1];
     a.out_color[2 * plane + pix_id] = C2 + Tout * a.bg[2];
   }
-  if (a.work != nullptr && entered > 0u) {
+  if (a.work != nullptr) {
     // a tile that crossed a boundary also leaves its final colour (without background) in its last slot: a
     // backward piece that starts from a checkpoint needs C_final - C_prefix
     if (entered >= 2u)
       a.ckpt[(size_t)(sbase + gcr_piece_count((uint32_t)total, piece_P) - 1u) * 256u + tid] =
           make_float4(__builtin_fabsf(Tw), C0, C1, C2);
-    // work items of the backward blend: one per piece this workgroup walked into (the pieces behind a saturated
-    // tile's last one are nobody's business); `entered` consecutive places of the dense list, claimed with one atomic
-    __shared__ uint32_t sWorkPos;
-    if (tid == 0)
-      sWorkPos = atomicAdd(reinterpret_cast<unsigned int*>(a.frame_out + GCR_FRAME_NWORK), entered);
-    __syncthreads();
-    for (uint32_t k = tid; k < entered; k += 256u)
-      a.work[sWorkPos + k] = make_uint4((uint32_t)tile, r0, (uint32_t)total, k);
+    // work items of the backward blend, one per slot of [slot_base(tile), slot_base(tile + 1)): the pieces this
+    // workgroup walked into carry {tile, list start, list length, piece}; the others (behind a saturated tile's last
+    // piece; the gap slot) carry nothing.  Fixed places: no atomic, no barrier at the end of the forward.
+    const uint32_t nslots = r1 / piece_P + 1u - r0 / piece_P;
+    for (uint32_t k = tid; k < nslots; k += 256u)
+      a.work[sbase + k] = k < entered ? make_uint4((uint32_t)tile, r0, (uint32_t)total, k) : make_uint4(GCR_NO_TILE, 0u, 0u, 0u);
   }
   if (a.work != nullptr && tile == 0 && tid == 0) {
     a.frame_out[GCR_FRAME_PIECE] = piece_P;
     a.frame_out[GCR_FRAME_CKPT_OFF] = a.ckpt_off;
     a.frame_out[GCR_FRAME_WORK_OFF] = a.work_off;
+    a.frame_out[GCR_FRAME_MASK_OFF] = a.mask_off;
   }
 }
 
@@ -315,268 +315,171 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
 //     atomics per pixel per Gaussian; here
 //   1. each 16-lane DPP row (= one 4x4 block, all lanes on the SAME Gaussian) reduce-scatters the nine terms
 //      (31 VALU ops, gcr_row_reduce_scatter9; no LDS traffic),
-//   2. lanes 0..8 of each row add the row sums into a per-piece LDS accumulator (one ds_add_f32 to nine
-//      consecutive floats of the entry's accumulator row),
-//   3. after the piece the nine sums of an entry are flushed by nine ADJACENT lanes into the Gaussian's 64-byte
-//      gradient record (gcr_internal.h): one wave instruction = 4 entries = 4 cache lines
-//     so global atomics drop from 9 per (pixel, Gaussian) to one cache-line transaction per (piece, Gaussian).
+//   2. lanes 0..8 of each row add the row sums into an LDS accumulator (one ds_add_f32 to nine consecutive floats of
+//      the entry's accumulator row),
+//   3. after a pass the nine sums of an entry are flushed by nine ADJACENT lanes into the Gaussian's 64-byte gradient
+//      record (gcr_internal.h): one wave instruction = 4 entries = 4 cache lines.
 //
 // (b) The unit of work is a (tile, PIECE) item of the list the forward left behind (gcr_internal.h "backward
 //     pieces"), not a tile: a pixel whose walk goes on behind the piece starts from the forward's checkpoint.
-//     Only entries below the row's max n_contrib are visited (skipped by every pixel upstream too,
-//     contributor >= last_contributor, :511-512), and each row visits only the entries whose block mask includes its
-//     4x4 block (see K6).
 //
-// (c) PERSISTENT, SOFTWARE-PIPELINED workgroups.  Per-wave phase clocks (tools/k7_clocks.py, round 3) showed why one
-//     workgroup per tile ran at half the VALU rate it sustains while walking: a workgroup's life is a chain of
-//     dependent memory round trips (ranges -> pixel state -> list -> records), then the VALU-bound walk, then the
-//     flush -- and the four workgroups of a CU, started together, stay in step: all wait, all walk (VALU saturated
-//     by four walkers), all flush.  Walking waves per SIMD swung between 0 and 3.5 with a mean of 1.7.  Here a
-//     workgroup stays resident, strides over the work list, and has the NEXT item's loads in flight while it walks
-//     the current one: the item's descriptor (scalar) at the top of the iteration, its list entries before the walk,
-//     the record gather from inside the walk loop (two steps in, when the indices have arrived), pixel state and
-//     checkpoints right after the walk, behind the flush.  Between two walks remain the flush, three barriers, the
-//     LDS staging with the block masks and the list compaction.
-//     The dense zero fill of the backward's outputs rides along in slices, one per item (non-temporal stores).
+// (c) ONE WAVE PER (item, 8x8 QUADRANT), NO WORKGROUP BARRIERS.  Per-wave phase clocks (tools/k7_clocks.py, round 3)
+//     showed why one 256-thread workgroup per tile ran at a third of the VALU rate: a workgroup's life is a chain of
+//     dependent memory round trips (ranges -> pixel state -> list -> records), then the walk -- which is LATENCY-bound
+//     per wave (a ~50-deep dependent chain per step, ~1100 cycles; four walking waves per SIMD are needed to saturate
+//     the VALU) -- then the flush, with barriers in between; the four workgroups a CU holds start together and stay in
+//     step, so the SIMDs saw 1.7-2.3 walking waves on average.  Persistent workgroups with the next item's loads in
+//     flight shortened the gaps but not the launch (both measured 95-100 us at C2).  A wave that owns its quadrant's
+//     whole pipeline -- pixel state, list entries, staging, row lists, walk, flush, all in wave-private LDS -- never
+//     waits for another wave: sixteen independent pipelines per CU fill each other's gaps.  What makes it affordable
+//     is that the forward blend stores the block mask of every list entry it stages (uint16 per instance): the
+//     quadrant's wave reads 64 masks per pass, keeps the entries that reach its four 4x4 blocks below the quadrant's
+//     max n_contrib, and gathers only those records -- no mask arithmetic (222 VALU per entry) in the backward at all.
+//     The price: an entry that reaches several quadrants of a tile is flushed by each of them.
+// Only entries below the row's max n_contrib are visited (skipped by every pixel upstream too,
+// contributor >= last_contributor, :511-512), and each row visits only the entries whose block mask includes its
+// 4x4 block (see K6).
 // Experiment builds (make -C csrc experiments): per-wave phase clocks.  With gcr_debug_set_clock_buffer() armed, lane 0
-// of every wave stores {hw id, xcc id, s_memtime at the phase boundaries} of the first items it walks
-// (tools/k7_clocks.py turns them into phase statistics).  The shipping build contains none of it.
+// of every wave stores {hw id, xcc id, s_memtime at its phase boundaries} (tools/k7_clocks.py).  The shipping build
+// contains none of it.
 #ifdef GCR_EXPERIMENTS
 #define GCR_K7_NCLK 8
-#define GCR_K7_ITEMS 4
 #define GCR_K7_CLK(i) \
   if (clk_on) clk[i] = __builtin_readcyclecounter();
-#else
-#define GCR_K7_CLK(i)
-#endif
-
-// One work item, block-uniform (scalar registers): piece `k` of tile `tile`, list entries [lo, lo + n).
-struct BwdItem {
-  int tile;
-  uint32_t r0, lo, n, slot_ck, slot_final;
-  bool has_ckpt;  // the list goes on behind this piece: some pixel may start from the checkpoint at lo + n
-};
-GCR_DEV BwdItem bwd_item(const uint4 d, uint32_t P) {
-  BwdItem it;
-  it.tile = (int)d.x;
-  it.r0 = d.y;
-  const uint32_t len = d.z, k = d.w;
-  const uint32_t npieces = gcr_piece_count(len, P), cs = gcr_piece_size(len, P);
-  it.lo = k * cs;
-  it.n = min(cs, len - it.lo);
-  const uint32_t sbase = d.y / P + d.x;
-  it.slot_ck = sbase + k;
-  it.slot_final = sbase + npieces - 1u;
-  it.has_ckpt = k + 1u < npieces;
-  return it;
-}
-struct BwdEntry {
-  float4 q0, q1, q2;
-  uint32_t id;
-};
-struct BwdPixel {
-  float T_final;
-  uint32_t last_contributor;
-  float d0, d1, d2;
-};
-// chunk slot `tid` of an item holds list entry lo + n - 1 - tid (back to front)
-GCR_DEV uint32_t bwd_load_id(const GcrBlendArgs& a, const BwdItem& it, int tid) {
-  return tid < (int)it.n ? a.list[it.r0 + it.lo + it.n - 1u - (uint32_t)tid] : 0u;
-}
-GCR_DEV BwdEntry bwd_gather(const GcrBlendArgs& a, const BwdItem& it, uint32_t id, int tid) {
-  BwdEntry e;
-  e.id = id;
-  e.q0 = e.q1 = e.q2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if (tid < (int)it.n) {
-    const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
-    e.q0 = rec[0];
-    e.q1 = rec[1];
-    e.q2 = rec[2];
-  }
-  return e;
-}
-GCR_DEV BwdPixel bwd_load_pixel(const GcrBlendArgs& a, const BwdItem& it, int tid) {
-  const LaneGeom g = lane_geom(tid, it.tile % a.gx, it.tile / a.gx);
-  BwdPixel p = {0.0f, 0u, 0.0f, 0.0f, 0.0f};
-  if (g.pxi < a.W && g.pyi < a.H) {
-    const size_t pix_id = (size_t)a.W * g.pyi + g.pxi;
-    const size_t plane = (size_t)a.H * a.W;
-    p.T_final = a.final_T[pix_id];
-    p.last_contributor = a.n_contrib[pix_id];
-    p.d0 = a.dL_dpix[pix_id];
-    p.d1 = a.dL_dpix[plane + pix_id];
-    p.d2 = a.dL_dpix[2 * plane + pix_id];
-  }
-  return p;
-}
-
-template <bool FAST_EXP>
-__global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
-  __shared__ StagedEntry sE[CHUNK + 1];
-  __shared__ uint32_t sMask[CHUNK];
-  __shared__ uint32_t sId[CHUNK];
-  __shared__ uint16_t sList[4][4][LIST_STRIDE];
-  __shared__ float sAcc[CHUNK * 9];  // entry-major: the nine sums of chunk slot j at [9j, 9j+9)
-
-  const int tid = threadIdx.x;
-  const uint32_t G = gridDim.x, wg = blockIdx.x;
-  const uint32_t piece_P = (uint32_t)a.frame_in[GCR_FRAME_PIECE];
-  const uint32_t nwork = piece_P != 0u ? (uint32_t)a.frame_in[GCR_FRAME_NWORK] : 0u;
-  // zero fill of the dense outputs: every workgroup streams S slices, one per work item it walks and the rest at
-  // the end (virtual block sidx * G + wg of G * S)
-  const uint32_t S = max(1u, (nwork + G - 1u) / G);
-  uint32_t slices_done = 0;
-#ifdef GCR_EXPERIMENTS
-#define GCR_FILL_ON !(a.debug_flags & 2)
-#else
-#define GCR_FILL_ON true
-#endif
-#ifdef GCR_EXPERIMENTS
+#define GCR_FLUSH_ON !(a.debug_flags & 1)
 #define GCR_LDS_ADD_ON !(a.debug_flags & 4)
 #else
+#define GCR_K7_CLK(i)
+#define GCR_FLUSH_ON true
 #define GCR_LDS_ADD_ON true
 #endif
-#define GCR_FILL_SLICE()                                                                                     \
-  {                                                                                                          \
-    if (GCR_FILL_ON)                                                                                         \
-    for (int sgi = 0; sgi < a.fill.nseg; sgi++)                                                              \
-      gcr_fill_zero_segment(a.fill.ptr[sgi], a.fill.n[sgi], (int)(slices_done * G + wg), (int)(G * S), tid); \
-    slices_done++;                                                                                           \
+
+constexpr int WPASS = 64;                          // list entries a wave stages per pass
+constexpr int WLIST_STRIDE = WPASS + 8;            // u16 slots per row list: entries + pipeline pads
+constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave's sentinel entry
+
+template <bool FAST_EXP>
+__global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
+  __shared__ StagedEntry sE[WPASS + 1];
+  __shared__ uint32_t sId[WPASS];
+  __shared__ uint16_t sList[4][WLIST_STRIDE];
+  __shared__ uint16_t sRel[WPASS];   // pass slots with something to flush, compacted
+  __shared__ float sAcc[WPASS * 9];  // entry-major: the nine sums of pass slot j at [9j, 9j+9)
+
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x < a.fill.blocks) {  // the launch's leading waves: zero fill of the dense outputs
+    for (int sgi = 0; sgi < a.fill.nseg; sgi++)
+      gcr_fill_zero_segment<64>(a.fill.ptr[sgi], a.fill.n[sgi], (int)blockIdx.x, a.fill.blocks, lane);
+    return;
   }
 #ifdef GCR_EXPERIMENTS
   bool clk_on = a.clock_buf != nullptr;
   unsigned long long clk[GCR_K7_NCLK] = {};
-  uint32_t clk_item = 0;
 #endif
+  GCR_K7_CLK(0)
+  const uint32_t piece_P = (uint32_t)a.frame_in[GCR_FRAME_PIECE];
+  if (piece_P == 0u) return;
+  // (slot, quadrant) units: every slot of the forward's piece grid holds a work item or GCR_NO_TILE
+  const unsigned long long nunits = 4ull * gcr_piece_slots(a.R, (unsigned long long)(a.gx * a.gy), piece_P);
+  const float4* __restrict__ ckpt = reinterpret_cast<const float4*>(a.binning_base + a.frame_in[GCR_FRAME_CKPT_OFF]);
+  const uint4* __restrict__ work = reinterpret_cast<const uint4*>(a.binning_base + a.frame_in[GCR_FRAME_WORK_OFF]);
+  const uint16_t* __restrict__ masks = reinterpret_cast<const uint16_t*>(a.binning_base + a.frame_in[GCR_FRAME_MASK_OFF]);
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const int acc_slot = (lane & 15) <= 8 ? (lane & 15) : -1;  // which of the 9 terms this lane adds / flushes
+  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
+  const char* const sEb = reinterpret_cast<const char*>(sE);
+  char* const acc_base = reinterpret_cast<char*>(&sAcc[acc_slot >= 0 ? acc_slot : 0]);
+  const size_t plane = (size_t)a.H * a.W;
+  if (lane == 0) {
+    sE[WPASS].a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    sE[WPASS].b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    sE[WPASS].c = make_float4(0.0f, __builtin_inff(), __uint_as_float(NO_ENTRY), 0.0f);
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) sAcc[k * WPASS + lane] = 0.0f;  // kept zero by the flush from here on
 
-  if (wg < nwork) {
-    const float4* __restrict__ ckpt = reinterpret_cast<const float4*>(a.binning_base + a.frame_in[GCR_FRAME_CKPT_OFF]);
-    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(a.binning_base + a.frame_in[GCR_FRAME_WORK_OFF]);
-    const int lane = tid & 63, w = tid >> 6;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const int acc_slot = (tid & 15) <= 8 ? (tid & 15) : -1;  // which of the 9 terms this lane flushes
-    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
-    const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
-    const char* const sEb = reinterpret_cast<const char*>(sE);
-    char* const acc_base = reinterpret_cast<char*>(&sAcc[acc_slot >= 0 ? acc_slot : 0]);
-    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (tid == 0) {
-      sE[CHUNK].a = zero4;
-      sE[CHUNK].b = zero4;
-      sE[CHUNK].c = make_float4(0.0f, __builtin_inff(), __uint_as_float(NO_ENTRY), 0.0f);
+  // the grid covers the units the host expects; should the forward have used a smaller piece, the waves stride on
+  for (unsigned long long unit = (unsigned long long)blockIdx.x - (unsigned long long)a.fill.blocks; unit < nunits;
+       unit += (unsigned long long)gridDim.x - (unsigned long long)a.fill.blocks) {
+    const uint4 d = work[unit >> 2];
+    if (d.x == GCR_NO_TILE) continue;  // wave-uniform
+    const int q = (int)(unit & 3ull);  // quadrant of the tile: the `wave` of K6's lane geometry
+    const int tile = (int)d.x;
+    const uint32_t r0 = d.y, len = d.z, kpiece = d.w;
+    const uint32_t npieces = gcr_piece_count(len, piece_P), cs = gcr_piece_size(len, piece_P);
+    const uint32_t lo = kpiece * cs, hi = min(len, lo + cs);  // the piece: list entries [lo, hi), walked back to front
+    const uint32_t sbase = r0 / piece_P + (uint32_t)tile;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const LaneGeom g = lane_geom(q * 64 + lane, tx, ty);
+    const uint32_t quad_bits = (1u << g.bit[0]) | (1u << g.bit[1]) | (1u << g.bit[2]) | (1u << g.bit[3]);
+    const bool inside = g.pxi < a.W && g.pyi < a.H;
+    const float pixx = (float)g.pxi, pixy = (float)g.pyi;
+    const size_t pix_id = (size_t)a.W * g.pyi + g.pxi;
+
+    // ---- per-pixel state (all loads of the prologue are independent of each other)
+    const float T_final = inside ? a.final_T[pix_id] : 0.0f;
+    const uint32_t last_contributor = inside ? a.n_contrib[pix_id] : 0u;
+    float dLp0 = 0.0f, dLp1 = 0.0f, dLp2 = 0.0f;
+    if (inside) {
+      dLp0 = a.dL_dpix[pix_id];
+      dLp1 = a.dL_dpix[plane + pix_id];
+      dLp2 = a.dL_dpix[2 * plane + pix_id];
     }
-
-    // first item: nothing to hide its loads behind
-    GCR_K7_CLK(0)
-    BwdItem cur = bwd_item(work[wg], piece_P);
-    BwdEntry ent = bwd_gather(a, cur, bwd_load_id(a, cur, tid), tid);
-    BwdPixel px = bwd_load_pixel(a, cur, tid);
-    float4 ck = zero4, cf = zero4;
-    if (cur.has_ckpt) {
-      ck = ckpt[(size_t)cur.slot_ck * 256u + tid];
-      cf = ckpt[(size_t)cur.slot_final * 256u + tid];
+    float4 ck = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cf = ck;
+    if (kpiece + 1u < npieces) {  // the list goes on behind this piece
+      ck = ckpt[(size_t)(sbase + kpiece) * 256u + (uint32_t)(q * 64 + lane)];
+      cf = ckpt[(size_t)(sbase + npieces - 1u) * 256u + (uint32_t)(q * 64 + lane)];
     }
-
-    for (uint32_t it = wg;;) {
-      const bool has_next = it + G < nwork;
-      const BwdItem nxt = bwd_item(work[has_next ? it + G : it], piece_P);  // scalar load, used before the walk
-      GCR_K7_CLK(1)
-      const int tx = cur.tile % a.gx, ty = cur.tile / a.gx;
-      const LaneGeom g = lane_geom(tid, tx, ty);
-      const float pixx = (float)g.pxi, pixy = (float)g.pyi;
-      const float tile_x0 = (float)(tx * GCR_TILE_X), tile_y0 = (float)(ty * GCR_TILE_Y);
-      const int n = (int)cur.n;
-      const uint32_t hi = cur.lo + cur.n;  // this item walks list entries [lo, hi), back to front
-
-      // ---- per-pixel state
-      const float T_final = px.T_final;
-      const uint32_t last_contributor = px.last_contributor;
-      const float dLp0 = px.d0, dLp1 = px.d1, dLp2 = px.d2;
-      float bg_dot_dpixel = 0;
-      bg_dot_dpixel += bg0 * dLp0;
-      bg_dot_dpixel += bg1 * dLp1;
-      bg_dot_dpixel += bg2 * dLp2;
-      // entries any pixel of this row (4x4 block) consumed
-      uint32_t row_max = last_contributor;
+    float bg_dot_dpixel = 0;
+    bg_dot_dpixel += bg0 * dLp0;
+    bg_dot_dpixel += bg1 * dLp1;
+    bg_dot_dpixel += bg2 * dLp2;
+    // entries any pixel of this row (4x4 block) / of the quadrant consumed
+    uint32_t row_max = last_contributor;
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        const uint32_t t = __shfl_xor(row_max, o, 64);
-        row_max = t > row_max ? t : row_max;
-      }
-      uint32_t rmax[4];
+    for (int o = 8; o > 0; o >>= 1) {
+      const uint32_t t = __shfl_xor(row_max, o, 64);
+      row_max = t > row_max ? t : row_max;
+    }
+    uint32_t rmax[4];
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) rmax[rr] = __shfl(row_max, rr * 16, 64);
-      // Start state of the reverse walk at entry hi - 1.  A pixel whose last contributor lies in this piece (or before
-      // it) starts as upstream: T_final, accum_rec = 0.  A pixel that goes on behind the piece starts from the
-      // forward's checkpoint at boundary hi: T after entry hi - 1, and accum_rec = what is blended behind it,
-      // normalised: (C_final - C_prefix(hi)) / T(hi) -- which the first update
-      // `a = last_alpha * lc + (1 - last_alpha) * acc` with last_alpha = 0 hands to the first contributing entry
-      // unchanged.
-      float T = T_final;
-      float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;  // accum_rec
-      if (cur.has_ckpt && last_contributor > hi) {
-        T = ck.x;
-        acc0 = (cf.y - ck.y) / ck.x;
-        acc1 = (cf.z - ck.z) / ck.x;
-        acc2 = (cf.w - ck.w) / ck.x;
-      }
-      const float neg_T_final = -T_final;
-      float last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;
+    for (int rr = 0; rr < 4; rr++) rmax[rr] = __shfl(row_max, rr * 16, 64);
+    const uint32_t wave_max = max(max(rmax[0], rmax[1]), max(rmax[2], rmax[3]));
+    GCR_K7_CLK(1)  // pixel state known
+    if (wave_max <= lo) continue;  // wave-uniform: this quadrant consumed nothing of the piece
+    const int top = (int)min(hi, wave_max);
 
-      // ---- stage the prefetched entry
-      uint32_t my_mask = 0;
-      if (tid < n) {
-        const uint32_t entry_l = hi - 1u - (uint32_t)tid;  // == `contributor` upstream
-        const float pmin = gcr_alpha_skip_bound(ent.q1.y);
-        sE[tid].a = ent.q0;
-        sE[tid].b = ent.q1;
-        sE[tid].c = make_float4(ent.q2.x, pmin, __uint_as_float(entry_l), __uint_as_float((uint32_t)tid * 36u));
-        sId[tid] = ent.id;
-        my_mask = gcr_block_mask(ent.q0.x, ent.q0.y, ent.q0.z, ent.q0.w, ent.q1.x, pmin, tile_x0, tile_y0);
-      }
-      sMask[tid] = my_mask;
-#pragma unroll
-      for (int k = 0; k < 9; k++) sAcc[k * CHUNK + tid] = 0.0f;
-      GCR_K7_CLK(2)  // own entry staged
-      __syncthreads();
-      GCR_K7_CLK(3)  // everybody's entries staged
+    // Start state of the reverse walk.  A pixel whose last contributor lies in this piece (or before it) starts as
+    // upstream: T_final, accum_rec = 0.  A pixel that goes on behind the piece starts from the forward's checkpoint
+    // at boundary hi: T after entry hi - 1, and accum_rec = what is blended behind it, normalised:
+    // (C_final - C_prefix(hi)) / T(hi) -- which the first update `a = last_alpha * lc + (1 - last_alpha) * acc`
+    // with last_alpha = 0 hands to the first contributing entry unchanged.
+    float T = T_final;
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;  // accum_rec
+    if (last_contributor > hi) {
+      T = ck.x;
+      acc0 = (cf.y - ck.y) / ck.x;
+      acc1 = (cf.z - ck.z) / ck.x;
+      acc2 = (cf.w - ck.w) / ck.x;
+    }
+    const float neg_T_final = -T_final;
+    float last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;
 
-      // compact the slots each row still consumes: block bit set and list entry < the row's max n_contrib
-      int cnt[4] = {0, 0, 0, 0};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (k * 64 < n) {  // wave-uniform
-          const int jj = k * 64 + lane;
-          const uint32_t m = sMask[jj];  // 0 for jj >= n
-          const uint32_t entry_l = hi - 1u - (uint32_t)jj;
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            const bool rel = ((m >> g.bit[rr]) & 1u) && entry_l < rmax[rr];
-            const uint64_t bal = __ballot(rel);
-            if (rel) sList[w][rr][cnt[rr] + __popcll(bal & lt_mask)] = (uint16_t)(jj * (int)ENTRY_BYTES);
-            cnt[rr] += __popcll(bal);
-          }
-        }
-      }
-      const int maxcnt = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++)
-        for (int s = cnt[rr] + lane; s < maxcnt + 3; s += 64) sList[w][rr][s] = (uint16_t)SENT_OFF;
-      __builtin_amdgcn_wave_barrier();
-
-      // next item, level 1: its list entries (the records are gathered from inside the walk, once these have arrived)
-      const uint32_t next_id = has_next ? bwd_load_id(a, nxt, tid) : 0u;
-      BwdEntry next_ent;
-      next_ent.q0 = next_ent.q1 = next_ent.q2 = zero4;
-      next_ent.id = 0u;
-
-// One list entry against this lane's pixel (cr/backward.cu:505-580).  Branch-free body: lanes
-// that upstream would `continue` keep their state via selects and contribute exact zeros to the
-// row reduction (see K6: scalar-unit pressure).  `power` is forced to 0 on those lanes so that
-// every intermediate stays finite and the three masked factors (dchannel_dcolor, dL_dalpha) zero
-// all nine terms.  The two quotients share the divisor 1-alpha: one v_rcp_f32 + one Newton step
-// (<= 1 ulp) instead of two IEEE division expansions -- the only place the HIP path leaves
-// gcr-fp32-v2; K7's sums are order-dependent (atomics) and tolerance-checked anyway.
+// One list entry against this lane's pixel (cr/backward.cu:505-580).  Branch-free body with THREE selects: what
+// bounds this kernel is VALU issue at ~4 cycles per instruction for this mix (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU,
+// profiles/r03_k7_pmc.txt: v_cndmask with an SGPR-pair mask, v_cmp and the DPP moves cost about twice an FMA), so
+// the step avoids selects on the loop state altogether:
+//   * a lane that upstream would `continue` gets power = 0 (every intermediate stays finite) and alpha_eff = 0;
+//   * with alpha_eff = 0 the transmittance update is exact without a select: rcp(1) = 1, T * 1 = T;
+//   * accum_rec is updated EAGERLY: (last_alpha, last_color, accum_rec) := (alpha_eff, colour, a) where
+//     a = last_alpha * last_color + (1 - last_alpha) * accum_rec is what upstream computes at its next contributing
+//     entry.  After a skipped entry the state reads (0, *, a), whose next blend 0 * c + 1 * a = a is exactly the value
+//     the untouched state would have produced -- same bits, no selects;
+//   * dchannel_dcolor = alpha_eff * T is zero by itself; only dL_dalpha needs masking (one select).
+// The two quotients share the divisor 1 - alpha: one v_rcp_f32 + one Newton step (<= 1 ulp) instead of two IEEE
+// division expansions -- the only place the HIP path leaves gcr-fp32-v2; K7's sums are order-dependent (atomics)
+// and tolerance-checked anyway.
 #define GCR_BWD_STEP(QA, QB, QC)                                                               \
   {                                                                                            \
     const float dx = QA.x - pixx, dy = QA.y - pixy;                                            \
@@ -588,63 +491,109 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
       const float G = blend_exp<FAST_EXP>(power);                                              \
       const float alpha = __builtin_fminf(0.99f, QB.y * G);                                    \
       const bool use = in_range && !(alpha < 1.0f / 255.0f);                                   \
-      const float om = 1.f - alpha;                                                            \
+      const float a_eff = use ? alpha : 0.0f;                                                  \
+      const float om = 1.f - a_eff;                                                            \
       const float rc0 = __builtin_amdgcn_rcpf(om);                                             \
       const float rcp = __builtin_fmaf(rc0, __builtin_fmaf(-om, rc0, 1.0f), rc0);              \
-      const float Tn = T * rcp;                                                                \
-      const float dchannel_dcolor = use ? alpha * Tn : 0.0f;                                   \
-      const float a0 = __builtin_fmaf(last_alpha, lc0, (1.f - last_alpha) * acc0);            \
-      const float a1 = __builtin_fmaf(last_alpha, lc1, (1.f - last_alpha) * acc1);            \
-      const float a2 = __builtin_fmaf(last_alpha, lc2, (1.f - last_alpha) * acc2);            \
+      T = T * rcp;                                                                             \
+      const float dchannel_dcolor = a_eff * T;                                                 \
+      const float oml = 1.f - last_alpha;                                                      \
+      acc0 = __builtin_fmaf(last_alpha, lc0, oml * acc0);                                      \
+      acc1 = __builtin_fmaf(last_alpha, lc1, oml * acc1);                                      \
+      acc2 = __builtin_fmaf(last_alpha, lc2, oml * acc2);                                      \
+      lc0 = QB.z;                                                                              \
+      lc1 = QB.w;                                                                              \
+      lc2 = QC.x;                                                                              \
+      last_alpha = a_eff;                                                                      \
       float dL_dalpha = 0.0f;                                                                  \
-      dL_dalpha = __builtin_fmaf(QB.z - a0, dLp0, dL_dalpha);                                  \
-      dL_dalpha = __builtin_fmaf(QB.w - a1, dLp1, dL_dalpha);                                  \
-      dL_dalpha = __builtin_fmaf(QC.x - a2, dLp2, dL_dalpha);                                  \
-      dL_dalpha *= Tn;                                                                         \
+      dL_dalpha = __builtin_fmaf(lc0 - acc0, dLp0, dL_dalpha);                                 \
+      dL_dalpha = __builtin_fmaf(lc1 - acc1, dLp1, dL_dalpha);                                 \
+      dL_dalpha = __builtin_fmaf(lc2 - acc2, dLp2, dL_dalpha);                                 \
+      dL_dalpha *= T;                                                                          \
       dL_dalpha += (neg_T_final * rcp) * bg_dot_dpixel;                                        \
       dL_dalpha = use ? dL_dalpha : 0.0f;                                                      \
       const float dL_dG = QB.y * dL_dalpha;                                                    \
       const float gdx = G * dx, gdy = G * dy;                                                  \
       const float dG_ddelx = -gdx * QA.z - gdy * QA.w;                                         \
       const float dG_ddely = -gdy * QB.x - gdx * QA.w;                                         \
+      const float hG = -0.5f * dL_dG;                                                          \
       float v[9];                                                                              \
       v[0] = dchannel_dcolor * dLp0;                                                           \
       v[1] = dchannel_dcolor * dLp1;                                                           \
       v[2] = dchannel_dcolor * dLp2;                                                           \
       v[3] = dL_dG * dG_ddelx * ddelx_dx;                                                      \
       v[4] = dL_dG * dG_ddely * ddely_dy;                                                      \
-      v[5] = -0.5f * gdx * dx * dL_dG;                                                         \
-      v[6] = -0.5f * gdx * dy * dL_dG;                                                         \
-      v[7] = -0.5f * gdy * dy * dL_dG;                                                         \
+      v[5] = gdx * dx * hG;                                                                    \
+      v[6] = gdx * dy * hG;                                                                    \
+      v[7] = gdy * dy * hG;                                                                    \
       v[8] = G * dL_dalpha;                                                                    \
-      T = use ? Tn : T;                                                                        \
-      acc0 = use ? a0 : acc0;                                                                  \
-      acc1 = use ? a1 : acc1;                                                                  \
-      acc2 = use ? a2 : acc2;                                                                  \
-      lc0 = use ? QB.z : lc0;                                                                  \
-      lc1 = use ? QB.w : lc1;                                                                  \
-      lc2 = use ? QC.x : lc2;                                                                  \
-      last_alpha = use ? alpha : last_alpha;                                                   \
       /* reduce-scatter over each 16-lane row, then ONE ds_add_f32: lanes 0..8 of every row */ \
       /* add their row's sum of term (lane & 15) into the column of the row's entry */         \
       const float rsum = gcr_row_reduce_scatter9(v, lane);                                     \
       if (acc_slot >= 0 && GCR_LDS_ADD_ON) atomicAdd(reinterpret_cast<float*>(acc_base + __float_as_uint(QC.w)), rsum); \
     }                                                                                          \
   }
+#ifdef GCR_EXPERIMENTS  /* knock-out bit 3: one LDS read per step instead of three (results wrong) */
+#define GCR_BWD_LOAD(QA, QB, QC, OFF)                              \
+  QA = *reinterpret_cast<const float4*>(sEb + (OFF));             \
+  if (!(a.debug_flags & 8)) {                                      \
+    QB = *reinterpret_cast<const float4*>(sEb + (OFF) + 16);       \
+    QC = *reinterpret_cast<const float4*>(sEb + (OFF) + 32);       \
+  } else {                                                         \
+    QB = make_float4(QA.z, 0.5f, QA.x, QA.y);                      \
+    QC = make_float4(QA.w, -5.0f, __uint_as_float(0u), __uint_as_float(0u)); \
+  }
+#else
 #define GCR_BWD_LOAD(QA, QB, QC, OFF)                              \
   QA = *reinterpret_cast<const float4*>(sEb + (OFF));             \
   QB = *reinterpret_cast<const float4*>(sEb + (OFF) + 16);         \
   QC = *reinterpret_cast<const float4*>(sEb + (OFF) + 32);
+#endif
 
 
-      GCR_K7_CLK(4)  // lists compacted
+    // ---- passes of 64 list entries, back to front: pass slot `lane` holds list entry pos - 1 - lane
+    for (int pos = top; pos > (int)lo; pos -= WPASS) {
+      const int e_l = pos - 1 - lane;
+      const bool have = e_l >= (int)lo;
+      const uint32_t m16 = have ? (uint32_t)masks[r0 + (uint32_t)e_l] : 0u;
+      const bool any_rel = (m16 & quad_bits) != 0u;  // reaches one of this quadrant's 4x4 blocks (e_l < wave_max holds)
+      const uint64_t rel_bal = __ballot(any_rel);
+      if (rel_bal == 0ull) continue;  // wave-uniform: nothing of these 64 entries concerns the quadrant
+      if (any_rel) {
+        const uint32_t id = a.list[r0 + (uint32_t)e_l];
+        const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        sE[lane].a = q0;
+        sE[lane].b = q1;
+        sE[lane].c = make_float4(q2.x, gcr_alpha_skip_bound(q1.y), __uint_as_float((uint32_t)e_l),
+                                 __uint_as_float((uint32_t)lane * 36u));
+        sId[lane] = id;
+        sRel[__popcll(rel_bal & lt_mask)] = (uint16_t)lane;
+      }
+      const int nrel = __popcll(rel_bal);
+      // the four row lists: block bit set and list entry below the row's max n_contrib (lane order = walk order)
+      int maxcnt = 0;
+      int cnt[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const bool rel = ((m16 >> g.bit[rr]) & 1u) && (uint32_t)e_l < rmax[rr];
+        const uint64_t bal = __ballot(rel);
+        if (rel) sList[rr][__popcll(bal & lt_mask)] = (uint16_t)(lane * (int)ENTRY_BYTES);
+        cnt[rr] = __popcll(bal);
+        maxcnt = max(maxcnt, cnt[rr]);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+        for (int s = cnt[rr] + lane; s < maxcnt + 3; s += 64) sList[rr][s] = (uint16_t)WSENT_OFF;
+      __builtin_amdgcn_wave_barrier();
+      GCR_K7_CLK(2)  // first pass staged (overwritten by later passes: the last one counts)
+
       // software pipeline, two entries per trip (see K6)
-      const uint16_t* lp = &sList[w][g.row][0];
+      const uint16_t* lp = &sList[g.row][0];
       float4 qa0, qb0, qc0, qa1, qb1, qc1;
       uint32_t e0 = lp[0], e1 = lp[1];
       GCR_BWD_LOAD(qa0, qb0, qc0, e0)
       for (int i = 0; i < maxcnt; i += 2, lp += 2) {
-        if (i == 2 && has_next) next_ent = bwd_gather(a, nxt, next_id, tid);  // next item, level 2
         GCR_BWD_LOAD(qa1, qb1, qc1, e1)
         e0 = lp[2];
         GCR_BWD_STEP(qa0, qb0, qc0)
@@ -653,65 +602,42 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const GcrBlendArgs a) {
         e1 = lp[3];
         GCR_BWD_STEP(qa1, qb1, qc1)
       }
-      if (maxcnt <= 2 && has_next) next_ent = bwd_gather(a, nxt, next_id, tid);
-#undef GCR_BWD_STEP
-#undef GCR_BWD_LOAD
-      GCR_K7_CLK(5)  // walk done
-      __syncthreads();
-      GCR_K7_CLK(6)  // every wave's walk done
-      // next item, level 3: pixel state and checkpoints, in flight behind the flush
-      BwdPixel next_px = {0.0f, 0u, 0.0f, 0.0f, 0.0f};
-      float4 next_ck = zero4, next_cf = zero4;
-      if (has_next) {
-        next_px = bwd_load_pixel(a, nxt, tid);
-        if (nxt.has_ckpt) {
-          next_ck = ckpt[(size_t)nxt.slot_ck * 256u + tid];
-          next_cf = ckpt[(size_t)nxt.slot_final * 256u + tid];
-        }
-      }
-#ifdef GCR_EXPERIMENTS
-      if (!(a.debug_flags & 1))
-#endif
+      __builtin_amdgcn_wave_barrier();
+      GCR_K7_CLK(3)  // walk of the pass done
+      // flush: lane = (entry within a group of 4) * 16 + component: the nine sums of an entry go out from nine adjacent
+      // lanes into one 64-byte record; the accumulator rows are left zeroed for the next pass
       {
-        // lane = (entry within a group of 16) * 16 + component: the nine sums of an entry go out from nine
-        // adjacent lanes into one 64-byte record
-        const int comp = tid & 15;
+        const int comp = lane & 15;
         const int rec_idx = comp < 3 ? comp : (comp == 8 ? 3 : comp + 1);  // record layout: gcr_internal.h
         if (comp < 9) {
-          for (int e = tid >> 4; e < n; e += 16) {
-            const float v = sAcc[e * 9 + comp];
-            if (v != 0.0f) atomicAdd(&a.grad_rec[(size_t)sId[e] * GCR_GRAD_REC_FLOATS + rec_idx], v);
+          for (int i = lane >> 4; i < nrel; i += 4) {
+            const int slot = (int)sRel[i];
+            const float v = sAcc[slot * 9 + comp];
+            if (v != 0.0f) {
+              sAcc[slot * 9 + comp] = 0.0f;
+              if (GCR_FLUSH_ON) atomicAdd(&a.grad_rec[(size_t)sId[slot] * GCR_GRAD_REC_FLOATS + rec_idx], v);
+            }
           }
         }
       }
-      GCR_FILL_SLICE()
-#ifdef GCR_EXPERIMENTS
-      if (clk_on) {
-        clk[7] = __builtin_readcyclecounter();  // flush and fill slice issued
-        if (lane == 0) {
-          unsigned long long* o =
-              a.clock_buf + (((size_t)wg * 4u + (size_t)w) * GCR_K7_ITEMS + clk_item) * (GCR_K7_NCLK + 2);
-          o[0] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |         // HW_REG_HW_ID
-                 ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);  // HW_REG_XCC_ID
-          o[1] = ((unsigned long long)maxcnt << 32) | (unsigned long long)n;
-          for (int i = 0; i < GCR_K7_NCLK; i++) o[2 + i] = clk[i];
-        }
-        clk[0] = clk[7];
-        if (++clk_item >= GCR_K7_ITEMS) clk_on = false;
-      }
-#endif
-      if (!has_next) break;
-      __syncthreads();  // the flush has read sAcc / sId: the next item may be staged
-      it += G;
-      cur = nxt;
-      ent = next_ent;
-      px = next_px;
-      ck = next_ck;
-      cf = next_cf;
+      __builtin_amdgcn_wave_barrier();
     }
+#ifdef GCR_EXPERIMENTS
+    if (clk_on) {
+      clk[4] = __builtin_readcyclecounter();
+      if (lane == 0) {
+        unsigned long long* o = a.clock_buf + (size_t)blockIdx.x * (GCR_K7_NCLK + 2);
+        o[0] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |         // HW_REG_HW_ID
+               ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);  // HW_REG_XCC_ID
+        o[1] = (unsigned long long)(top - (int)lo);
+        for (int i = 0; i < GCR_K7_NCLK; i++) o[2 + i] = clk[i];
+      }
+      clk_on = false;  // first unit only
+    }
+#endif
   }
-  while (slices_done < S) GCR_FILL_SLICE()
-#undef GCR_FILL_SLICE
+#undef GCR_BWD_STEP
+#undef GCR_BWD_LOAD
 }
 
 }  // namespace
@@ -733,32 +659,17 @@ hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool fast_exp, bool sort_
   return hipGetLastError();
 }
 
-// Persistent grid of the backward blend: as many workgroups as the device keeps resident (queried once).
-static int gcr_blend_bwd_resident(bool fast_exp) {
-  static int cached[2] = {0, 0};
-  int& c = cached[fast_exp ? 1 : 0];
-  if (c == 0) {
-    int dev = 0, cus = 256, per_cu = 4;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    }
-    const hipError_t e = fast_exp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_blend_bwd<true>, 256, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_blend_bwd<false>, 256, 0);
-    if (e != hipSuccess || per_cu < 1) per_cu = 4;
-    c = per_cu * cus;
-    if (const char* env = getenv("GCR_K7_BLOCKS")) c = atoi(env) > 0 ? atoi(env) : c;  // experiments only
-  }
-  return c;
-}
-
 hipError_t gcr_launch_blend_bwd(const GcrBlendArgs& a, bool fast_exp, hipStream_t s) {
   const int T = a.gx * a.gy;
   if (T <= 0) return hipSuccess;
-  const unsigned int grid = (unsigned int)gcr_blend_bwd_resident(fast_exp);
+  // one wave per (work item, quadrant) for the piece size the host expects the forward to have used; the number of
+  // items is only known on the device, the slot count bounds it
+  unsigned long long units = 4ull * gcr_piece_slots(a.R, (unsigned long long)T, (unsigned long long)a.piece);
+  if (const char* env = getenv("GCR_K7_BLOCKS")) units = (unsigned long long)atoll(env);  // experiments only
+  const unsigned int grid = (unsigned int)(units > 0x3fffffffull ? 0x3fffffffull : units) + (unsigned int)a.fill.blocks;
   if (fast_exp)
-    k_blend_bwd<true><<<grid, 256, 0, s>>>(a);
+    k_blend_bwd<true><<<grid, 64, 0, s>>>(a);
   else
-    k_blend_bwd<false><<<grid, 256, 0, s>>>(a);
+    k_blend_bwd<false><<<grid, 64, 0, s>>>(a);
   return hipGetLastError();
 }

@@ -83,8 +83,9 @@ GCR_DEV void gcr_store_to_host(unsigned long long* p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Workgroup `b` of `nb` (256 threads each) writes its share of zeros over n floats at p: a scalar head up to the
+// Workgroup `b` of `nb` (BS threads each) writes its share of zeros over n floats at p: a scalar head up to the
 // first 16-byte boundary, dwordx4 stores, a scalar tail.  Non-temporal: nothing reads these lines soon.
+template <int BS = 256>
 GCR_DEV void gcr_fill_zero_segment(float* __restrict__ p, unsigned long long n, int b, int nb, int tid) {
   const unsigned long long mis = ((unsigned long long)(uintptr_t)p >> 2) & 3ull;
   unsigned long long head = (4ull - mis) & 3ull;
@@ -98,8 +99,8 @@ GCR_DEV void gcr_fill_zero_segment(float* __restrict__ p, unsigned long long n, 
   typedef float gcr_f4 __attribute__((ext_vector_type(4)));
   gcr_f4* __restrict__ q = (gcr_f4*)(p + head);
   const gcr_f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-  for (unsigned long long i = (unsigned long long)b * 256ull + (unsigned long long)tid; i < n4;
-       i += (unsigned long long)nb * 256ull)
+  for (unsigned long long i = (unsigned long long)b * (unsigned long long)BS + (unsigned long long)tid; i < n4;
+       i += (unsigned long long)nb * (unsigned long long)BS)
     __builtin_nontemporal_store(z, q + i);  // measured: plain stores make the C2 backward 5 % slower
 }
 

@@ -96,11 +96,12 @@ struct GcrFillArgs {
 //   slot_base(t) = floor(ranges[t].start / P) + t,   slot_base(t) + ceil(len / P) <= slot_base(t + 1),
 // so neither a prefix sum over tiles nor a host-side count is needed; total slots = floor(R / P) + T.  Slot
 // slot_base(t) + k holds the checkpoint at boundary k + 1 (k < pieces - 1); the tile's LAST slot holds the final state.
-// Work list: every forward workgroup appends one 16-byte item {tile, list start, list length, piece} per piece it
-// walked into (one returning atomic per tile on the frame word GCR_FRAME_NWORK); the backward's persistent
-// workgroups stride over that dense list.
+// Work items: slot s of tile t's range also holds a 16-byte item {tile, list start, list length, piece} if the
+// forward walked into that piece, {GCR_NO_TILE} otherwise (a saturated tile's remaining pieces, the gap slot between two
+// tiles); the backward launches one wave per (slot, quadrant).
 #define GCR_PIECE_MIN 64
 #define GCR_PIECE_MAX 256
+#define GCR_NO_TILE 0xFFFFFFFFu
 #define GCR_CKPT_BYTES 4096  // 256 pixels x float4
 static inline __host__ __device__ uint32_t gcr_piece_count(uint32_t len, uint32_t P) { return (len + P - 1u) / P; }
 static inline __host__ __device__ uint32_t gcr_piece_size(uint32_t len, uint32_t P) {
@@ -113,11 +114,11 @@ static inline __host__ __device__ unsigned long long gcr_piece_slots(unsigned lo
 }
 // device frame words (geometry buffer, gcr_layout.geom_num_rendered): [0] R, [1] longest list, [2] go flag,
 // [3] piece size the forward used, [4] / [5] byte offsets of the checkpoints / the work list in the binning buffer,
-// [6] number of work items (zeroed by the kernel that publishes R, bumped by the forward blend)
+// [7] byte offset of the block masks the forward blend computed for every list entry it staged
 #define GCR_FRAME_PIECE 3
 #define GCR_FRAME_CKPT_OFF 4
 #define GCR_FRAME_WORK_OFF 5
-#define GCR_FRAME_NWORK 6
+#define GCR_FRAME_MASK_OFF 7  // byte offset of the per-instance block masks (uint16, sorted-list order)
 
 struct GcrBlendArgs {
   const uint32_t* ranges;  // [T][2]
@@ -139,10 +140,13 @@ struct GcrBlendArgs {
   int piece;                       // fwd: piece size P
   float4* ckpt;                    // fwd: [slots][256] checkpoints
   uint4* work;                     // fwd: [slots] work items {tile, list start, list length, piece}
-  unsigned long long* frame_out;   // fwd: device frame words; [3..5] published by the first tile, [6] bumped by all
+  uint16_t* mask_out;              // fwd: [R] block mask of every staged list entry (the backward reuses them)
+  unsigned long long mask_off;     // fwd: its byte offset in the binning buffer (published in the frame words)
+  unsigned long long* frame_out;   // fwd: device frame words; [3..7] published by the first tile
   unsigned long long ckpt_off, work_off;  // fwd: what it publishes (byte offsets in the binning buffer)
   const char* binning_base;        // bwd: checkpoints / work list are found through the frame words
   const unsigned long long* frame_in;  // bwd
+  unsigned long long R;            // bwd: num_rendered (with `piece`: bounds the number of work items for the grid)
 #ifdef GCR_EXPERIMENTS
   unsigned long long* clock_buf;   // bwd: [grid][4 waves][10] phase clocks (gcr_debug_set_clock_buffer), or null
 #endif

@@ -752,7 +752,6 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ curs
   if (tid == 0) {
     if (host_R != nullptr)  // (frame tag << 32 | R) for the polling host thread, see k_tile_table<false>
       gcr_store_to_host(host_R, ((unsigned long long)seq << 32) | (total > 0xffffffffull ? 0xffffffffull : total));
-    frame[GCR_FRAME_NWORK] = 0ull;  // the forward blend appends its backward work items from here
     frame[0] = total;
     frame[1] = mm;
     frame[2] = (total <= cap_instances && (unsigned long long)mm <= cap_list) ? 1ull : 0ull;

@@ -13,6 +13,7 @@ Differences, all on the safe side:
 """
 import collections
 import ctypes as C
+import threading
 
 import torch
 
@@ -32,6 +33,16 @@ _capacity_hint = collections.OrderedDict()
 # Debug aid (the GPU tests switch it on): hand gcr_backward NaN-filled outputs instead of whatever the caching
 # allocator returns, so that an element the library failed to write cannot pass for a zero gradient.
 poison_outputs = False
+
+
+# "A backward call will follow this forward": set by RasterizeGaussiansFunction around its native call (per host
+# thread), read by rasterize_gaussians.  A pure performance hint (gcr_camera.backward): the forward blend leaves its
+# checkpoints in the smaller pieces the backward balances best with; results do not depend on it.
+_tls = threading.local()
+
+
+def set_backward_hint(flag):
+    _tls.backward = bool(flag)
 
 
 def _hint_get(key):
@@ -63,7 +74,7 @@ def _dev_f32(t, name, device):
 
 
 def _camera(device, bg, view, proj, campos, tan_fovx, tan_fovy, H, W, scale_modifier, degree,
-            prefiltered, debug):
+            prefiltered, debug, for_backward=False):
     keep = []
     ptrs = []
     for t, name, n in ((bg, "bg", 3), (view, "viewmatrix", 16), (proj, "projmatrix", 16),
@@ -75,6 +86,7 @@ def _camera(device, bg, view, proj, campos, tan_fovx, tan_fovy, H, W, scale_modi
         ptrs.append(p)
     cam = N.Camera(int(H), int(W), float(tan_fovx), float(tan_fovy), float(scale_modifier),
                    int(degree), int(bool(prefiltered)), int(bool(debug)), *ptrs)
+    cam.backward = int(bool(for_backward))
     return cam, keep
 
 
@@ -132,13 +144,20 @@ class _on_device:
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
-                        image_width, sh, degree, campos, prefiltered, debug):
+                        image_width, sh, degree, campos, prefiltered, debug, _for_backward=None):
     """RasterizeGaussiansCUDA (dgr/rasterize_points.cu:37-93, dgr/rasterize_points.h:18-28).
 
     Returns (num_rendered:int, out_color[3,H,W], radii[P] int32, geomBuffer, binningBuffer,
     imgBuffer) -- the three buffers are opaque uint8 tensors to be handed back to
     rasterize_gaussians_backward.
+
+    `_for_backward` (keyword, not part of the reference's positional signature above) is a pure performance hint:
+    None = what set_backward_hint() announced for this thread (RasterizeGaussiansFunction does, when an input requires
+    a gradient).  The forward blend then leaves its checkpoints in the smaller pieces the backward balances best with
+    (gcr_camera.backward).
     """
+    if _for_backward is None:
+        _for_backward = getattr(_tls, "backward", False)
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if not means3D.is_cuda:
@@ -156,7 +175,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     radii = torch.empty((P,), dtype=torch.int32, device=device)
     with _on_device(device):
         cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
-                              tan_fovy, H, W, scale_modifier, degree, prefiltered, debug)
+                              tan_fovy, H, W, scale_modifier, degree, prefiltered, debug, _for_backward)
         g, keep_g = _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations,
                                cov3D_precomp)
         stream = _stream(device)

@@ -76,8 +76,17 @@ class RasterizeGaussiansFunction(torch.autograd.Function):
             cov3Ds_precomp, rs.view_matrix, rs.proj_matrix, rs.tanfovx, rs.tanfovy, rs.img_h,
             rs.img_w, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug,
         )
-        num_rendered, color, radii, geom_buffer, binning_buffer, img_buffer = _call_native(
-            _ext.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
+        # Out-of-band performance hint for the native side (the call itself keeps the reference's positional
+        # signature): a backward call will follow iff an input requires a gradient.
+        hint = getattr(_ext, "set_backward_hint", None)
+        if hint is not None:
+            hint(any(ctx.needs_input_grad))
+        try:
+            num_rendered, color, radii, geom_buffer, binning_buffer, img_buffer = _call_native(
+                _ext.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
+        finally:
+            if hint is not None:
+                hint(False)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii,

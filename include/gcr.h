@@ -68,6 +68,9 @@ typedef struct gcr_camera {
   const float *view_matrix; /* [16] */
   const float *proj_matrix; /* [16] */
   const float *campos;      /* [3] */
+  int32_t backward;    /* hint, never changes a result: !=0 = gcr_backward will be called on this frame's state (the
+                          forward blend then cuts its tile lists into the smaller pieces the backward balances best
+                          with, option "bwd_piece"); 0 = inference (256-entry pieces: gcr_backward still works) */
 } gcr_camera;
 
 /* Per-Gaussian inputs (argument list of cr/rasterizer.h:25-37) */
@@ -119,7 +122,7 @@ typedef struct gcr_layout {
   size_t geom_vis_list;      /* uint32 per Gaussian: K1 block b's survivors, packed at b*chunk */
   size_t geom_vis_count;     /* uint32 per K1 block */
   size_t geom_num_rendered;  /* uint64 {num_rendered, longest tile list, go flag, backward piece size,
-                                byte offsets of bin_ckpt / bin_work as the forward carved them, number of work items} */
+                                byte offsets of bin_ckpt / bin_work / bin_mask as the forward carved them} */
   size_t geom_block_tiles;   /* uint64 per K1 block: its share of num_rendered */
   size_t geom_total;
   /* image buffer */
@@ -136,7 +139,9 @@ typedef struct gcr_layout {
   size_t bin_hist;    /* radix-sort histogram table */
   size_t bin_sorted;  /* 0 or 1: which ping/pong half holds the sorted list */
   size_t bin_work;      /* 16 B per (tile, piece) slot: work items of the backward blend {tile, list start, list
-                           length, piece}, appended by the forward blend for every piece it walked into */
+                           length, piece} written by the forward blend for every piece it walked into */
+  size_t bin_mask;      /* uint16 per instance, sorted-list order: which of the tile's sixteen 4x4 blocks the
+                           entry can reach (computed by the forward blend while staging, reused by the backward) */
   size_t bin_ckpt;      /* 4096 B per slot: per-pixel (T, prefix colour) at the piece boundaries the forward
                            blend crossed -- what lets the backward blend start in the middle of a tile list */
   size_t bin_total;
@@ -230,6 +235,8 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *                     is <= 384 (one launch less: lower frame latency, lower throughput)
  *   "split_preprocess" 1: K1 as two kernels (streaming cull, then exact pass) instead of   default 0
  *                     the fused one (A/B)
+ *   "bwd_piece"    entries per backward piece (64..256) of frames rendered with             default 128
+ *                     gcr_camera.backward != 0 (include/gcr.h; gcr_internal.h "backward pieces")
  *   "timing"       1: record per-stage HIP events (see gcr_get_stage_ms)             default 0
  * Returns the previous value or <0 if the name is unknown. */
 int gcr_set_option(const char *name, int value);

@@ -13,8 +13,9 @@ def to_dev(a, device):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
-def run_forward(rs, sc, device, *, use_sh=True, use_cov3d=False, cov3D=None):
-    """Calls ext.rasterize_gaussians with the reference's positional signature."""
+def run_forward(rs, sc, device, *, use_sh=True, use_cov3d=False, cov3D=None, for_backward=False):
+    """Calls ext.rasterize_gaussians with the reference's positional signature (`for_backward`: the performance
+    hint RasterizeGaussiansFunction gives when an input requires a gradient)."""
     colors = torch.Tensor([]) if use_sh else to_dev(sc["colors_precomp"], device)
     sh = to_dev(sc["shs"], device) if use_sh else torch.Tensor([])
     scales = torch.Tensor([]) if use_cov3d else to_dev(sc["scales"], device)
@@ -24,7 +25,7 @@ def run_forward(rs, sc, device, *, use_sh=True, use_cov3d=False, cov3D=None):
             scales, rots, rs.scale_modifier, cov, rs.view_matrix.to(device), rs.proj_matrix.to(device),
             rs.tanfovx, rs.tanfovy, rs.img_h, rs.img_w, sh, rs.sh_degree, rs.campos.to(device),
             rs.prefiltered, rs.debug)
-    out = ext.rasterize_gaussians(*args)
+    out = ext.rasterize_gaussians(*args, _for_backward=for_backward)
     torch.cuda.synchronize()
     return args, out
 

@@ -40,7 +40,7 @@ rs = cams[args.pose]
 a = (rs.bg, t["means3D"], E, t["opacities"], t["scales"], t["rotations"], rs.scale_modifier, E, rs.view_matrix, rs.proj_matrix,
      rs.tanfovx, rs.tanfovy, rs.img_h, rs.img_w, t["shs"], cfg["sh_degree"], rs.campos, False, False)
 for _ in range(3):
-    R, color, radii, geom, binning, img = ext.rasterize_gaussians(*a)
+    R, color, radii, geom, binning, img = ext.rasterize_gaussians(*a, _for_backward=True)
 
 
 def bwd():
@@ -51,9 +51,9 @@ def bwd():
 
 for _ in range(5):
     bwd()
-NITEMS, NW = 4, 10
-grid = 4096  # >= the persistent grid
-buf = torch.zeros((grid, 4, NITEMS, NW), dtype=torch.int64, device=dev)
+NW = 10
+grid = 256 + 4 * (R // 64 + ((W + 15) // 16) * ((H + 15) // 16)) + 64  # >= the launch's grid (one wave per workgroup)
+buf = torch.zeros((grid, NW), dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
 N.set_option("timing", 1)
 N.stage_ms()
@@ -63,35 +63,33 @@ torch.cuda.synchronize()
 L.gcr_debug_set_clock_buffer(None)
 st = N.stage_ms()
 N.set_option("timing", 0)
-b = buf.cpu().numpy().astype(np.uint64)          # [wg, wave, item, 10]
+b = buf.cpu().numpy().astype(np.uint64)          # [wave, 10]: hw id | xcc << 32, entries, clk[0..7]
 np.save(os.path.join(ROOT, "gpurun_out", "k7_clocks_p%d.npy" % args.piece), b)
-used = b[..., 2] != 0
-item_idx = np.broadcast_to(np.arange(NITEMS)[None, None, :], used.shape)[used]
-waves = b[used]
-hw, meta, clk = waves[:, 0], waves[:, 1], waves[:, 2:].astype(np.int64)
-n_ent = (meta & np.uint64(0xffffffff)).astype(np.int64)
-steps = (meta >> np.uint64(32)).astype(np.int64)
+waves = b[b[:, 2] != 0]
+hw, n_ent, clk = waves[:, 0], waves[:, 1].astype(np.int64), waves[:, 2:].astype(np.int64)
 # s_memtime is a per-CU counter here (the bases differ between CUs): put every CU's first clock at 0
 lo32 = (hw & np.uint64(0xffffffff)).astype(np.int64)
-cu = ((hw >> np.uint64(32)).astype(np.int64) & 15) * (1 << 16) + (lo32 & 0xff00)
+xcc = (hw >> np.uint64(32)).astype(np.int64) & 15
+cu = xcc * (1 << 16) + (lo32 & 0xff00)
+simd = cu * 4 + ((lo32 >> 4) & 3)
 for x in np.unique(cu):
     clk[cu == x] -= clk[cu == x][:, 0].min()
-span = clk[:, 7].max()
-names = ("prefetch_issue", "state+stage_own", "stage_skew", "compaction", "walk", "walk_skew", "flush+fill")
-ph = {nm: clk[:, k + 1] - clk[:, k] for k, nm in enumerate(names)}
-life = clk[:, 7] - clk[:, 0]
+span = clk[:, 4].max()
+life = clk[:, 4] - clk[:, 0]
+nsimd = len(np.unique(simd))
 edges = np.linspace(0, span, 21)
-walking = [round(float(np.clip(np.minimum(clk[:, 5], hi) - np.maximum(clk[:, 4], lo), 0, None).sum()) / (hi - lo) / 1024, 2)
-           for lo, hi in zip(edges[:-1], edges[1:])]
+resident = [round(float(np.clip(np.minimum(clk[:, 4], hi) - np.maximum(clk[:, 0], lo), 0, None).sum()) / (hi - lo) / nsimd, 2)
+            for lo, hi in zip(edges[:-1], edges[1:])]
 out = {
     "config": args.config, "bwd_piece": args.piece, "R": int(R), "blend_bwd_stage_ms": round(st["blend_bwd"], 4),
-    "workgroups_with_work": int(used[:, 0, 0].sum()), "items_clocked": int(len(waves) // 4),
-    "cu_span_ticks_max": int(span), "ticks_per_us_if_span_is_stage": round(span / (st["blend_bwd"] * 1e3), 1),
-    "walking_waves_per_simd_by_twentieth (first %d items of every workgroup)" % NITEMS: walking,
-    "phase_share": {k: round(float(v.sum()) / float(life.sum()), 3) for k, v in ph.items()},
-    "phase_mean_ticks_first_item": {k: int(v[item_idx == 0].mean()) for k, v in ph.items()},
-    "phase_mean_ticks_later_items": {k: int(v[item_idx > 0].mean()) if (item_idx > 0).any() else 0 for k, v in ph.items()},
-    "entries_per_item_mean": round(float(n_ent.mean()), 1), "row_steps_per_wave_mean": round(float(steps.mean()), 1),
-    "walk_ticks_per_step": round(float(ph["walk"].sum()) / max(1, int(steps.sum())), 1),
+    "waves_with_work": int(len(waves)), "simds_seen": int(nsimd), "cu_span_ticks_max": int(span),
+    "ticks_per_us_if_span_is_stage": round(span / (st["blend_bwd"] * 1e3), 1),
+    "wave_life_ticks_mean_p50_p90_max": [int(life.mean())] + [int(np.percentile(life, q)) for q in (50, 90, 100)],
+    "resident_working_waves_per_simd_by_twentieth": resident,
+    "wave_start_ticks_p10_p50_p90_p99": [int(np.percentile(clk[:, 0], q)) for q in (10, 50, 90, 99)],
+    "phase_mean_ticks": {"prologue (work item, pixel state)": int((clk[:, 1] - clk[:, 0]).mean()),
+                         "passes (stage + walk + flush), all but the tail": int((clk[:, 3] - clk[:, 1]).mean()),
+                         "last flush": int((clk[:, 4] - clk[:, 3]).mean())},
+    "entries_per_wave_mean": round(float(n_ent.mean()), 1),
 }
 print(json.dumps(out))

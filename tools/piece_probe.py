@@ -41,15 +41,15 @@ W, H = cfg["W"], cfg["H"]
 dpix = torch.from_numpy(synth.grad_image(W, H, cfg["seed"])).to(dev)
 
 
-def fwd(i, tt=t, cc=cams):
+def fwd(i, tt=t, cc=cams, for_bwd=False):
     rs = cc[i % 24]
     a = (rs.bg, tt["means3D"], E, tt["opacities"], tt["scales"], tt["rotations"], rs.scale_modifier, E, rs.view_matrix,
          rs.proj_matrix, rs.tanfovx, rs.tanfovy, rs.img_h, rs.img_w, tt["shs"], 3, rs.campos, False, False)
-    return rs, ext.rasterize_gaussians(*a)
+    return rs, ext.rasterize_gaussians(*a, _for_backward=for_bwd)
 
 
 def fb(i):
-    rs, (R, color, radii, geom, binning, img) = fwd(i)
+    rs, (R, color, radii, geom, binning, img) = fwd(i, for_bwd=True)
     g = ext.rasterize_gaussians_backward(rs.bg, t["means3D"], radii, E, t["scales"], t["rotations"], rs.scale_modifier, E,
                                          rs.view_matrix, rs.proj_matrix, rs.tanfovx, rs.tanfovy, dpix, t["shs"], 3,
                                          rs.campos, geom, R, binning, img, False)
@@ -103,19 +103,19 @@ if not args.no_c3:
     for P in pieces:
         N.set_option("bwd_piece", P)
         for i in range(30):
-            fwd(i, t3, cams3)
+            fwd(i, t3, cams3, True)
         N.set_option("timing", 1)
         N.stage_ms()
         for i in range(96):
-            fwd(i, t3, cams3)
+            fwd(i, t3, cams3, True)
         torch.cuda.synchronize()
         st = N.stage_ms()
         N.set_option("timing", 0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(96):
-            fwd(i, t3, cams3)
+            fwd(i, t3, cams3, True)
         torch.cuda.synchronize()
-        print(json.dumps({"config": "C3 forward, one stream", "bwd_piece": P, "blend_fwd_ms": round(st["blend_fwd"], 4),
+        print(json.dumps({"config": "C3 forward announced as a training frame, one stream", "bwd_piece": P, "blend_fwd_ms": round(st["blend_fwd"], 4),
                           "frame_ms": round(1e3 * (time.perf_counter() - t0) / 96, 4)}), flush=True)
-N.set_option("bwd_piece", 256)
+N.set_option("bwd_piece", 128)
