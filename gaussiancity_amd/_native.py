@@ -34,6 +34,9 @@ class Camera(C.Structure):
         ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("bg", C.c_void_p), ("view_matrix", C.c_void_p),
         ("proj_matrix", C.c_void_p), ("campos", C.c_void_p),
+        ("host_camera", C.c_int32),  # bg/view/proj/campos are host pointers (copied into the kernel arguments)
+        ("flip_x", C.c_int32), ("flip_y", C.c_int32),  # mirrored image store / gradient load
+        ("win_x", C.c_int32), ("win_y", C.c_int32), ("win_w", C.c_int32), ("win_h", C.c_int32),  # output window
         ("backward", C.c_int32),  # hint: a backward call will follow (sizes the forward's checkpoint pieces)
     ]
 
@@ -44,13 +47,18 @@ class Gaussians(C.Structure):
         ("means3D", C.c_void_p), ("opacities", C.c_void_p), ("shs", C.c_void_p),
         ("colors_precomp", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p),
+        ("stride_means3D", C.c_int32), ("stride_opacities", C.c_int32), ("stride_colors", C.c_int32),
+        ("stride_scales", C.c_int32), ("stride_rotations", C.c_int32),
     ]
 
 
 class Grads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D",
-        "dL_dsh", "dL_dscales", "dL_drotations")]
+        "dL_dsh", "dL_dscales", "dL_drotations")] + [
+        ("stride_means3D", C.c_int32), ("stride_opacity", C.c_int32), ("stride_colors", C.c_int32),
+        ("stride_scales", C.c_int32), ("stride_rotations", C.c_int32),
+        ("packed", C.c_void_p), ("packed_floats", C.c_int64)]
 
 
 class Layout(C.Structure):

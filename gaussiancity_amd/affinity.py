@@ -1,0 +1,75 @@
+"""Rank -> CPU affinity: pin a rank's host threads to the CPUs local to ITS GPU (same NUMA node / PCIe root).
+
+Counterpart of the reference's utils/distributed.py:19-62 (`set_affinity`, which asks NVML for the GPU's CPU mask before
+torch.cuda.set_device).  On ROCm the same information is in sysfs: /sys/bus/pci/devices/<domain:bus:dev.fn>/
+local_cpulist (and numa_node).  It matters on this path: every frame ends with the calling thread polling a pinned host
+word the GPU writes (gcr_forward), and the frame loop is host-enqueue-bound at small scenes -- a thread that migrates to the
+other socket pays a cross-socket hop per poll and per doorbell.  With eight ranks on one node each rank keeps to its GPU's
+node; the pinned read-back word is allocated by the first frame, i.e. after the binding, on that node (first touch).
+
+No GPU / no sysfs / an empty list -> nothing is changed and the reason is returned (never an error: affinity is an
+optimisation).  GCR_NO_AFFINITY=1 disables it.
+"""
+import os
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-", 1)
+            cpus.extend(range(int(lo), int(hi) + 1))
+        else:
+            cpus.append(int(part))
+    return sorted(set(cpus))
+
+
+def gpu_pci_address(device_index):
+    """'0000:c1:00.0' of torch device `device_index`, or None."""
+    import torch
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        dom, bus, dev = int(getattr(pr, "pci_domain_id", 0)), int(pr.pci_bus_id), int(pr.pci_device_id)
+    except Exception:
+        return None
+    return "%04x:%02x:%02x.0" % (dom, bus, dev)
+
+
+def gpu_local_cpus(device_index, sysfs="/sys/bus/pci/devices"):
+    """(cpus, numa_node, why): the CPUs local to the GPU according to sysfs; cpus == [] with a reason otherwise."""
+    addr = gpu_pci_address(device_index)
+    if addr is None:
+        return [], None, "no PCI address for device %s" % device_index
+    base = os.path.join(sysfs, addr)
+    try:
+        cpus = parse_cpulist(open(os.path.join(base, "local_cpulist")).read())
+    except OSError as e:
+        return [], None, "sysfs: %s" % e
+    node = None
+    try:
+        node = int(open(os.path.join(base, "numa_node")).read())
+    except (OSError, ValueError):
+        pass
+    return cpus, node, "ok" if cpus else "empty local_cpulist for %s" % addr
+
+
+def bind_rank_to_gpu(device_index, sysfs="/sys/bus/pci/devices"):
+    """os.sched_setaffinity(this process, CPUs local to the GPU).  Returns a dict for logs:
+    {"bound": bool, "cpus": n, "numa_node": k, "why": str}."""
+    if os.environ.get("GCR_NO_AFFINITY") == "1":
+        return {"bound": False, "cpus": 0, "numa_node": None, "why": "GCR_NO_AFFINITY=1"}
+    cpus, node, why = gpu_local_cpus(device_index, sysfs)
+    if not cpus:
+        return {"bound": False, "cpus": 0, "numa_node": node, "why": why}
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))  # never widen a mask the launcher / cgroup set
+    if not allowed:
+        return {"bound": False, "cpus": 0, "numa_node": node, "why": "GPU-local CPUs are outside this process's mask"}
+    try:
+        os.sched_setaffinity(0, allowed)
+    except OSError as e:
+        return {"bound": False, "cpus": 0, "numa_node": node, "why": "sched_setaffinity: %s" % e}
+    return {"bound": True, "cpus": len(allowed), "numa_node": node, "why": "ok"}

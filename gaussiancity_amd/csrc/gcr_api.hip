@@ -172,6 +172,11 @@ int check_inputs(const gcr_camera* cam, const gcr_gaussians* g, bool need_opacit
     return fail(GCR_ERR_INVALID_ARGUMENT, "image too large for 16-bit tile coordinates");
   if (!cam->bg || !cam->view_matrix || !cam->proj_matrix || !cam->campos)
     return fail(GCR_ERR_INVALID_ARGUMENT, "bg/view_matrix/proj_matrix/campos must be non-null");
+  if (cam->win_w != 0 || cam->win_h != 0) {
+    if (cam->win_w <= 0 || cam->win_h <= 0 || cam->win_x < 0 || cam->win_y < 0 || cam->win_x + cam->win_w > cam->img_w ||
+        cam->win_y + cam->win_h > cam->img_h)
+      return fail(GCR_ERR_INVALID_ARGUMENT, "the output window must lie inside the image");
+  }
   if (g->P == 0) return 0;
   if (!g->means3D) return fail(GCR_ERR_INVALID_ARGUMENT, "means3D must have dimensions (num_points, 3)");
   if (need_opacity && !g->opacities) return fail(GCR_ERR_INVALID_ARGUMENT, "opacities must be non-null");
@@ -253,6 +258,18 @@ int gcr_get_stage_ms(float* ms_out, int capacity) {
   return n;
 }
 
+// gcr_camera.host_camera: the camera constants travel in the kernels' argument blocks
+static void fill_cam(GcrCamVals& c, const gcr_camera* cam) {
+  memset(&c, 0, sizeof(c));
+  if (!cam->host_camera) return;
+  c.by_value = 1;
+  memcpy(c.view, cam->view_matrix, sizeof(c.view));
+  memcpy(c.proj, cam->proj_matrix, sizeof(c.proj));
+  memcpy(c.campos, cam->campos, sizeof(c.campos));
+  memcpy(c.bg, cam->bg, sizeof(c.bg));
+}
+static inline int stride_or(int32_t s, int dense) { return s > 0 ? (int)s : dense; }
+
 // Enqueues K1 + tile counting + tile scan; leaves {R, longest list, go flag} in the geometry
 // buffer (*frame_dev_out).  cap_* only influence the go flag used by speculative launches.
 // `host_R` (optional): pinned word that receives (seq << 32 | num_rendered) as soon as K1 is done.
@@ -280,6 +297,12 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
   a.opacities = g->opacities; a.shs = g->shs; a.cov3D_precomp = g->cov3D_precomp;
   a.colors_precomp = g->colors_precomp;
   a.view = cam->view_matrix; a.proj = cam->proj_matrix; a.campos = cam->campos;
+  a.s_mean = stride_or(g->stride_means3D, 3);
+  a.s_opac = stride_or(g->stride_opacities, 1);
+  a.s_col = stride_or(g->stride_colors, 3);
+  a.s_scale = stride_or(g->stride_scales, 3);
+  a.s_rot = stride_or(g->stride_rotations, 4);
+  fill_cam(a.cam, cam);
   a.radii = radii;
   a.rec = (float4*)(gb + L.geom_rec);
   a.cov3D = (float*)(gb + L.geom_cov3D);
@@ -409,6 +432,9 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   b.rec = rec;
   b.W = cam->img_w; b.H = cam->img_h; b.gx = gx; b.gy = gy;
   b.bg = cam->bg;
+  b.flip_x = cam->flip_x != 0; b.flip_y = cam->flip_y != 0;
+  b.win_x = cam->win_x; b.win_y = cam->win_y; b.win_w = cam->win_w; b.win_h = cam->win_h;
+  fill_cam(b.cam, cam);
   b.final_T = (float*)(ib + L.img_final_T);
   b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
   b.out_color = out_color;
@@ -603,6 +629,9 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   b.rec = rec;
   b.W = cam->img_w; b.H = cam->img_h; b.gx = gx; b.gy = gy;
   b.bg = cam->bg;
+  b.flip_x = cam->flip_x != 0; b.flip_y = cam->flip_y != 0;
+  b.win_x = cam->win_x; b.win_y = cam->win_y; b.win_w = cam->win_w; b.win_h = cam->win_h;
+  fill_cam(b.cam, cam);
   b.final_T = (float*)(ib + L.img_final_T);
   b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
   b.out_color = out_color;
@@ -629,8 +658,14 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   // the accumulation records are read and written as 16-byte quads of 64-byte records, dL_drotations as float4
   if ((uintptr_t)gr->dL_dconic & 63u)
     return fail(GCR_ERR_INVALID_ARGUMENT, "dL_dconic (the gradient records) must be 64-byte aligned");
-  if (g->scales && ((uintptr_t)gr->dL_drotations & 15u))
+  if (g->scales && stride_or(gr->stride_rotations, 4) == 4 && ((uintptr_t)gr->dL_drotations & 15u))
     return fail(GCR_ERR_INVALID_ARGUMENT, "dL_drotations must be 16-byte aligned");
+  if (g->rotations && stride_or(g->stride_rotations, 4) == 4 && ((uintptr_t)g->rotations & 15u))
+    return fail(GCR_ERR_INVALID_ARGUMENT, "rotations must be 16-byte aligned when dense");
+  const bool any_grad_stride = gr->stride_means3D > 0 || gr->stride_opacity > 0 || gr->stride_colors > 0 ||
+                               gr->stride_scales > 0 || gr->stride_rotations > 0;
+  if (any_grad_stride && (!gr->packed || gr->packed_floats <= 0))
+    return fail(GCR_ERR_INVALID_ARGUMENT, "strided gradient outputs need the block they live in (gcr_grads.packed)");
   if (R < 0 || R > 0x7fffffffll) return fail(GCR_ERR_INVALID_ARGUMENT, "R out of range");
   gcr_layout L;
   compute_layout(g->P, cam->img_w, cam->img_h, R, &L);
@@ -658,14 +693,16 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
         fill.n[fill.nseg++] = n;
       }
     };
+    // strided outputs live in gr->packed, which is filled as one block; dense ones are filled one by one
     seg(gr->dL_dmeans2D, 3 * P);
-    seg(gr->dL_dcolors, (unsigned long long)GCR_NUM_CHANNELS * P);
-    seg(gr->dL_dopacity, P);
-    seg(gr->dL_dmeans3D, 3 * P);
+    seg(gr->stride_colors > 0 ? nullptr : gr->dL_dcolors, (unsigned long long)GCR_NUM_CHANNELS * P);
+    seg(gr->stride_opacity > 0 ? nullptr : gr->dL_dopacity, P);
+    seg(gr->stride_means3D > 0 ? nullptr : gr->dL_dmeans3D, 3 * P);
     seg(gr->dL_dcov3D, 6 * P);
     seg(gr->dL_dsh, g->shs ? 3ull * (unsigned long long)g->M * P : 0ull);
-    seg(gr->dL_dscales, 3 * P);
-    seg(gr->dL_drotations, 4 * P);
+    seg(gr->stride_scales > 0 ? nullptr : gr->dL_dscales, 3 * P);
+    seg(gr->stride_rotations > 0 ? nullptr : gr->dL_drotations, 4 * P);
+    if (any_grad_stride) seg(gr->packed, (unsigned long long)gr->packed_floats);
     unsigned long long total = 0;
     for (int i = 0; i < fill.nseg; i++) total += fill.n[i];
     const unsigned long long want = (total + 1023ull) / 1024ull;  // >= 16 floats per thread of a 64-thread wave
@@ -691,6 +728,13 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     b.rec = (const float4*)(gb + L.geom_rec);
     b.W = cam->img_w; b.H = cam->img_h; b.gx = gx; b.gy = gy;
     b.bg = cam->bg;
+    b.flip_x = cam->flip_x != 0; b.flip_y = cam->flip_y != 0;
+    b.win_x = cam->win_x; b.win_y = cam->win_y; b.win_w = cam->win_w; b.win_h = cam->win_h;
+  b.win_x = cam->win_x; b.win_y = cam->win_y; b.win_w = cam->win_w; b.win_h = cam->win_h;
+    fill_cam(b.cam, cam);
+  b.flip_x = cam->flip_x != 0; b.flip_y = cam->flip_y != 0;
+  b.win_x = cam->win_x; b.win_y = cam->win_y; b.win_w = cam->win_w; b.win_h = cam->win_h;
+  fill_cam(b.cam, cam);
     b.final_T = (float*)(ib + L.img_final_T);
     b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
     b.dL_dpix = dL_dpix;
@@ -727,6 +771,15 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dcolor = gr->dL_dcolors; a.dL_dopacity = gr->dL_dopacity;
   a.dL_dmean3D = gr->dL_dmeans3D; a.dL_dcov3D = gr->dL_dcov3D; a.dL_dsh = gr->dL_dsh;
   a.dL_dscale = gr->dL_dscales; a.dL_drot = gr->dL_drotations;
+  a.s_mean = stride_or(g->stride_means3D, 3);
+  a.s_scale = stride_or(g->stride_scales, 3);
+  a.s_rot = stride_or(g->stride_rotations, 4);
+  a.g_mean = stride_or(gr->stride_means3D, 3);
+  a.g_opac = stride_or(gr->stride_opacity, 1);
+  a.g_col = stride_or(gr->stride_colors, 3);
+  a.g_scale = stride_or(gr->stride_scales, 3);
+  a.g_rot = stride_or(gr->stride_rotations, 4);
+  fill_cam(a.cam, cam);
   {
     StageTimer t(s, ST_PRE_BWD);
     HIP_TRY(gcr_launch_preprocess_bwd(a, s), "preprocess backward");

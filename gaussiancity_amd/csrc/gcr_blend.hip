@@ -76,6 +76,27 @@ GCR_DEV LaneGeom lane_geom(int tid, int tx, int ty) {
   return g;
 }
 
+// Output window (gcr_camera.win_*): where pixel (px, py) of the frame lands in out_color / dL_dpix, or -1.  The
+// window is given in image coordinates AFTER the optional mirroring.
+GCR_DEV long long gcr_out_index(const GcrBlendArgs& a, int px, int py, size_t* plane) {
+  const int ox = a.flip_x ? a.W - 1 - px : px, oy = a.flip_y ? a.H - 1 - py : py;
+  if (a.win_w == 0) {
+    *plane = (size_t)a.H * a.W;
+    return (long long)a.W * oy + ox;
+  }
+  *plane = (size_t)a.win_h * a.win_w;
+  const int wx = ox - a.win_x, wy = oy - a.win_y;
+  return (wx >= 0 && wx < a.win_w && wy >= 0 && wy < a.win_h) ? (long long)a.win_w * wy + wx : -1ll;
+}
+// does tile (tx, ty) own a pixel of the window?
+GCR_DEV bool gcr_tile_in_window(const GcrBlendArgs& a, int tx, int ty) {
+  if (a.win_w == 0) return true;
+  int x0 = tx * GCR_TILE_X, x1 = min(a.W, x0 + GCR_TILE_X) - 1, y0 = ty * GCR_TILE_Y, y1 = min(a.H, y0 + GCR_TILE_Y) - 1;
+  if (a.flip_x) { const int t = a.W - 1 - x1; x1 = a.W - 1 - x0; x0 = t; }
+  if (a.flip_y) { const int t = a.H - 1 - y1; y1 = a.H - 1 - y0; y0 = t; }
+  return x1 >= a.win_x && x0 < a.win_x + a.win_w && y1 >= a.win_y && y0 < a.win_y + a.win_h;
+}
+
 // byte offset -> chunk slot (offsets are multiples of 48 below 2^14: 1366/65536 is 1/48 rounded up,
 // exact for slots < 2048)
 GCR_DEV uint32_t slot_of_offset(uint32_t off) { return (off * 1366u) >> 16; }
@@ -125,6 +146,20 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   const float pixx = (float)g.pxi, pixy = (float)g.pyi;
   const float tile_x0 = (float)(tx * GCR_TILE_X), tile_y0 = (float)(ty * GCR_TILE_Y);
   const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
+  if (!gcr_tile_in_window(a, tx, ty)) {
+    // none of this tile's pixels is wanted (gcr_camera.win_*): nothing to blend, and no work for the backward either
+    if (a.work != nullptr) {
+      const uint32_t P0 = (uint32_t)a.piece, sb = r0 / P0 + (uint32_t)tile, ns = r1 / P0 + 1u - r0 / P0;
+      for (uint32_t k = tid; k < ns; k += 256u) a.work[sb + k] = make_uint4(GCR_NO_TILE, 0u, 0u, 0u);
+      if (tile == 0 && tid == 0) {
+        a.frame_out[GCR_FRAME_PIECE] = P0;
+        a.frame_out[GCR_FRAME_CKPT_OFF] = a.ckpt_off;
+        a.frame_out[GCR_FRAME_WORK_OFF] = a.work_off;
+        a.frame_out[GCR_FRAME_MASK_OFF] = a.mask_off;
+      }
+    }
+    return;
+  }
   const int total = (int)(r1 - r0);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const char* const sEb = reinterpret_cast<const char*>(sE);
@@ -280,12 +315,17 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   if (inside) {
     const float Tout = __builtin_fabsf(Tw);
     const size_t pix_id = (size_t)a.W * g.pyi + g.pxi;
-    const size_t plane = (size_t)a.H * a.W;
     a.final_T[pix_id] = Tout;
     a.n_contrib[pix_id] = last_contributor;
-    a.out_color[pix_id] = C0 + Tout * a.bg[0];
-    a.out_color[plane + pix_id] = C1 + Tout * a.bg[1];
-    a.out_color[2 * plane + pix_id] = C2 + Tout * a.bg[2];
+    // the image may be stored mirrored (the wrapper's flip_lr / flip_ud without a copy kernel) and / or as a window of
+    // the frame (the helpers' crop without slice kernels); the per-pixel state is neither
+    size_t oplane;
+    const long long out_id = gcr_out_index(a, g.pxi, g.pyi, &oplane);
+    if (out_id >= 0) {
+      a.out_color[out_id] = C0 + Tout * GCR_CAM(a, bg, a.bg, 0);
+      a.out_color[oplane + out_id] = C1 + Tout * GCR_CAM(a, bg, a.bg, 1);
+      a.out_color[2 * oplane + out_id] = C2 + Tout * GCR_CAM(a, bg, a.bg, 2);
+    }
   }
   if (a.work != nullptr) {
     // a tile that crossed a boundary also leaves its final colour (without background) in its last slot: a
@@ -386,11 +426,10 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
   const uint16_t* __restrict__ masks = reinterpret_cast<const uint16_t*>(a.binning_base + a.frame_in[GCR_FRAME_MASK_OFF]);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const int acc_slot = (lane & 15) <= 8 ? (lane & 15) : -1;  // which of the 9 terms this lane adds / flushes
-  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  const float bg0 = GCR_CAM(a, bg, a.bg, 0), bg1 = GCR_CAM(a, bg, a.bg, 1), bg2 = GCR_CAM(a, bg, a.bg, 2);
   const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
   const char* const sEb = reinterpret_cast<const char*>(sE);
   char* const acc_base = reinterpret_cast<char*>(&sAcc[acc_slot >= 0 ? acc_slot : 0]);
-  const size_t plane = (size_t)a.H * a.W;
   if (lane == 0) {
     sE[WPASS].a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     sE[WPASS].b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -421,10 +460,14 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
     const float T_final = inside ? a.final_T[pix_id] : 0.0f;
     const uint32_t last_contributor = inside ? a.n_contrib[pix_id] : 0u;
     float dLp0 = 0.0f, dLp1 = 0.0f, dLp2 = 0.0f;
-    if (inside) {
-      dLp0 = a.dL_dpix[pix_id];
-      dLp1 = a.dL_dpix[plane + pix_id];
-      dLp2 = a.dL_dpix[2 * plane + pix_id];
+    if (inside) {  // (dL_dpix is the gradient of the image as it was handed out: mirrored / windowed as the store was)
+      size_t iplane;
+      const long long in_id = gcr_out_index(a, g.pxi, g.pyi, &iplane);
+      if (in_id >= 0) {
+        dLp0 = a.dL_dpix[in_id];
+        dLp1 = a.dL_dpix[iplane + in_id];
+        dLp2 = a.dL_dpix[2 * iplane + in_id];
+      }
     }
     float4 ck = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cf = ck;
     if (kpiece + 1u < npieces) {  // the list goes on behind this piece

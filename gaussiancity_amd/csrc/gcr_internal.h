@@ -15,6 +15,14 @@
 // same line serialise (measured: C2's 1120 unpadded counters made K1 4.6x slower).
 #define GCR_CURSOR_STRIDE 32
 
+// Camera constants by value (gcr_camera.host_camera): when `by_value` is set the kernels take bg / view / proj /
+// campos from their own argument block instead of loading them through the pointers.
+struct GcrCamVals {
+  int by_value;
+  float view[16], proj[16], campos[3], bg[3];
+};
+#define GCR_CAM(A, FIELD, PTR, i) ((A).cam.by_value ? (A).cam.FIELD[i] : (PTR)[i])
+
 struct GcrPreprocessArgs {
   int P, D, M, W, H, gx, gy;
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
@@ -31,6 +39,8 @@ struct GcrPreprocessArgs {
   uint32_t* cand_count;  // [nblocks]
   unsigned long long* block_tiles;  // [nblocks] every K1 block's share of num_rendered
   int nblocks, chunk;    // persistent grid: block b owns Gaussians [b*chunk, (b+1)*chunk)
+  int s_mean, s_opac, s_col, s_scale, s_rot;  // row strides in floats (3 / 1 / 3 / 3 / 4 when dense)
+  GcrCamVals cam;
 };
 
 // Persistent-grid geometry of K1 (also used by the kernels that walk its visible lists):
@@ -65,6 +75,9 @@ struct GcrPreprocessBwdArgs {
   const float4* grad_rec;  // K7's per-Gaussian accumulation records (GCR_GRAD_REC_FLOATS each)
   float *dL_dmean2D, *dL_dcolor, *dL_dopacity;  // written here from the records (API outputs)
   float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+  int s_mean, s_scale, s_rot;                   // input row strides in floats
+  int g_mean, g_opac, g_col, g_scale, g_rot;    // output row strides in floats
+  GcrCamVals cam;
 };
 
 // K7 accumulates its nine per-(tile, Gaussian) sums into ONE 64-byte record per Gaussian
@@ -135,6 +148,9 @@ struct GcrBlendArgs {
   const float* dL_dpix;     // bwd
   float* grad_rec;          // bwd: [P][GCR_GRAD_REC_FLOATS] accumulation records (zeroed for K1's survivors)
   GcrFillArgs fill;         // bwd: zero fill of the dense outputs, streamed in slices between the work items
+  int win_x, win_y, win_w, win_h;  // output window in image coordinates AFTER mirroring (win_w == 0: whole image)
+  int flip_x, flip_y;       // fwd: out_color stored mirrored; bwd: dL_dpix loaded mirrored (gcr_camera.flip_x / flip_y)
+  GcrCamVals cam;           // bg by value when cam.by_value
   int debug_flags;  // experiment builds only (GCR_EXPERIMENTS, "k7_skip_flush"): bit 0 = K7 drops its global atomics
   // pieces / checkpoints (above)
   int piece;                       // fwd: piece size P

@@ -139,17 +139,24 @@ struct PhaseAIn {
 // compiler's s_waitcnt placement lose count across the loop back-edge and wait for everything.
 template <bool PRECOMP_COV>
 GCR_DEV void phase_a_load(const GcrPreprocessArgs& a, long long idx, PhaseAIn& in) {
-  in.p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+  const float* __restrict__ mp = a.means3D + (size_t)idx * a.s_mean;  // row strides: 3 / 3 / 4 floats when dense,
+  in.p = {mp[0], mp[1], mp[2]};                                       // 14 for column slices of a [N,14] tensor
   if (PRECOMP_COV) {
     const float* __restrict__ c = a.cov3D_precomp + 6 * (size_t)idx;
     in.c0 = c[0]; in.c1 = c[1]; in.c2 = c[2]; in.c3 = c[3]; in.c4 = c[4]; in.c5 = c[5];
     in.c6 = 0.0f;
   } else {
-    in.c0 = a.scales[3 * idx];
-    in.c1 = a.scales[3 * idx + 1];
-    in.c2 = a.scales[3 * idx + 2];
-    const float4 rot = reinterpret_cast<const float4*>(a.rotations)[idx];
-    in.c3 = rot.x; in.c4 = rot.y; in.c5 = rot.z; in.c6 = rot.w;
+    const float* __restrict__ sp = a.scales + (size_t)idx * a.s_scale;
+    in.c0 = sp[0];
+    in.c1 = sp[1];
+    in.c2 = sp[2];
+    const float* __restrict__ rp = a.rotations + (size_t)idx * a.s_rot;
+    if (a.s_rot == 4) {  // dense: one 16-byte load (the array is 16-byte aligned: torch allocations are)
+      const float4 rot = *reinterpret_cast<const float4*>(rp);
+      in.c3 = rot.x; in.c4 = rot.y; in.c5 = rot.z; in.c6 = rot.w;
+    } else {
+      in.c3 = rp[0]; in.c4 = rp[1]; in.c5 = rp[2]; in.c6 = rp[3];
+    }
   }
 }
 
@@ -327,11 +334,11 @@ GCR_DEV float sh_accumulate(int i, int deg, const ShDir& d, float result, float 
 
 GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 mean, const Projected& pr,
                                 uint32_t list_pos, uint32_t* __restrict__ vis_list) {
-  const float opacity = a.opacities[idx];
+  const float opacity = a.opacities[(size_t)idx * a.s_opac];
   float cr, cg, cb;
   if (a.colors_precomp == nullptr) {
-    const float* __restrict__ cp = a.campos;
-    const float ox = mean.x - cp[0], oy = mean.y - cp[1], oz = mean.z - cp[2];
+    const float ox = mean.x - GCR_CAM(a, campos, a.campos, 0), oy = mean.y - GCR_CAM(a, campos, a.campos, 1),
+                oz = mean.z - GCR_CAM(a, campos, a.campos, 2);
     const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
     ShDir d;
     d.x = ox / len; d.y = oy / len; d.z = oz / len;
@@ -367,9 +374,10 @@ GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 me
     cg = gcr_max(res[1], 0.0f);
     cb = gcr_max(res[2], 0.0f);
   } else {
-    cr = a.colors_precomp[3 * idx];
-    cg = a.colors_precomp[3 * idx + 1];
-    cb = a.colors_precomp[3 * idx + 2];
+    const float* __restrict__ cpp = a.colors_precomp + (size_t)idx * a.s_col;
+    cr = cpp[0];
+    cg = cpp[1];
+    cb = cpp[2];
   }
   float4* __restrict__ rec = a.rec + (size_t)idx * GCR_REC_QUADS;
   rec[0] = make_float4(pr.px, pr.py, pr.conx, pr.cony);
@@ -399,8 +407,8 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
   float vm[16], pm[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    vm[i] = gcr_uniform(a.view[i]);
-    pm[i] = gcr_uniform(a.proj[i]);
+    vm[i] = gcr_uniform(GCR_CAM(a, view, a.view, i));
+    pm[i] = gcr_uniform(GCR_CAM(a, proj, a.proj, i));
   }
   // wf2 >= |W|_2^2 for the 3x3 block W the covariance projection uses: Gershgorin row sums of W^T W
   float wf2 = 0.0f;
@@ -464,8 +472,8 @@ __global__ __launch_bounds__(256) void k_preprocess_project(const GcrPreprocessA
   float vm[16], pm[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    vm[i] = gcr_uniform(a.view[i]);
-    pm[i] = gcr_uniform(a.proj[i]);
+    vm[i] = gcr_uniform(GCR_CAM(a, view, a.view, i));
+    pm[i] = gcr_uniform(GCR_CAM(a, proj, a.proj, i));
   }
   const size_t chunk_begin = (size_t)blockIdx.x * a.chunk;
   const uint32_t* __restrict__ my_cand = a.cand_list + chunk_begin;
@@ -539,8 +547,8 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
   float vm[16], pm[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    vm[i] = gcr_uniform(a.view[i]);
-    pm[i] = gcr_uniform(a.proj[i]);
+    vm[i] = gcr_uniform(GCR_CAM(a, view, a.view, i));
+    pm[i] = gcr_uniform(GCR_CAM(a, proj, a.proj, i));
   }
   float wf2 = 0.0f;
   {
@@ -772,16 +780,17 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
   float vm[16], proj[16], cp[3];
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    vm[i] = gcr_uniform(a.view[i]);
-    proj[i] = gcr_uniform(a.proj[i]);
+    vm[i] = gcr_uniform(GCR_CAM(a, view, a.view, i));
+    proj[i] = gcr_uniform(GCR_CAM(a, proj, a.proj, i));
   }
 #pragma unroll
-  for (int i = 0; i < 3; i++) cp[i] = gcr_uniform(a.campos[i]);
+  for (int i = 0; i < 3; i++) cp[i] = gcr_uniform(GCR_CAM(a, campos, a.campos, i));
   const uint32_t nvis = a.vis_count[blockIdx.x];
   const uint32_t* __restrict__ my_list = a.vis_list + (size_t)blockIdx.x * a.chunk;
   for (uint32_t it = threadIdx.x; it < nvis; it += 256) {
   const int idx = (int)my_list[it];
-  const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+  const float* __restrict__ mp = a.means3D + (size_t)idx * a.s_mean;
+  const V3 mean = {mp[0], mp[1], mp[2]};
   float cv[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) cv[i] = a.cov3D[6 * (size_t)idx + i];
@@ -805,9 +814,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
   float4 rot = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   float scl[3] = {0.0f, 0.0f, 0.0f};
   if (a.scales != nullptr) {
-    rot = reinterpret_cast<const float4*>(a.rotations)[idx];
+    const float* __restrict__ rp = a.rotations + (size_t)idx * a.s_rot;
+    rot = a.s_rot == 4 ? *reinterpret_cast<const float4*>(rp) : make_float4(rp[0], rp[1], rp[2], rp[3]);
 #pragma unroll
-    for (int i = 0; i < 3; i++) scl[i] = a.scales[3 * idx + i];
+    for (int i = 0; i < 3; i++) scl[i] = a.scales[(size_t)idx * a.s_scale + i];
   }
   // K7's accumulation record of this Gaussian (gcr_internal.h); the API's per-Gaussian outputs of the
   // blend gradient are written from it here
@@ -817,10 +827,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
   const float dcx = g1.z, dcy = g1.w, dcz = g2.x;
   a.dL_dmean2D[3 * (size_t)idx] = g1.x;
   a.dL_dmean2D[3 * (size_t)idx + 1] = g1.y;
-  a.dL_dcolor[3 * (size_t)idx] = g0.x;
-  a.dL_dcolor[3 * (size_t)idx + 1] = g0.y;
-  a.dL_dcolor[3 * (size_t)idx + 2] = g0.z;
-  a.dL_dopacity[idx] = g0.w;
+  a.dL_dcolor[(size_t)idx * a.g_col] = g0.x;
+  a.dL_dcolor[(size_t)idx * a.g_col + 1] = g0.y;
+  a.dL_dcolor[(size_t)idx * a.g_col + 2] = g0.z;
+  a.dL_dopacity[(size_t)idx * a.g_opac] = g0.w;
 
   // ---- K8a
   Cov2DCtx c;
@@ -983,9 +993,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
     dmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
     dmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
   }
-  a.dL_dmean3D[3 * idx] = dmx;
-  a.dL_dmean3D[3 * idx + 1] = dmy;
-  a.dL_dmean3D[3 * idx + 2] = dmz;
+  a.dL_dmean3D[(size_t)idx * a.g_mean] = dmx;
+  a.dL_dmean3D[(size_t)idx * a.g_mean + 1] = dmy;
+  a.dL_dmean3D[(size_t)idx * a.g_mean + 2] = dmz;
 
   // ---- K8b: cov3D -> scale / rotation (cr/backward.cu:297-373)
   if (a.scales != nullptr) {
@@ -1011,7 +1021,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
         Mt[rr][cidx] = M2[0][rr] * dS[cidx][0] + M2[1][rr] * dS[cidx][1] + M2[2][rr] * dS[cidx][2];
 #pragma unroll
     for (int cidx = 0; cidx < 3; cidx++)
-      a.dL_dscale[3 * idx + cidx] =
+      a.dL_dscale[(size_t)idx * a.g_scale + cidx] =
           Rm[0][cidx] * Mt[cidx][0] + Rm[1][cidx] * Mt[cidx][1] + Rm[2][cidx] * Mt[cidx][2];
 #pragma unroll
     for (int cidx = 0; cidx < 3; cidx++)
@@ -1025,7 +1035,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
            4 * y * (Mt[2][2] + Mt[0][0]);
     dq.w = 2 * r * (Mt[0][1] - Mt[1][0]) + 2 * x * (Mt[2][0] + Mt[0][2]) + 2 * y * (Mt[1][2] + Mt[2][1]) -
            4 * z * (Mt[1][1] + Mt[0][0]);
-    reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
+    float* __restrict__ dqp = a.dL_drot + (size_t)idx * a.g_rot;
+    if (a.g_rot == 4) {
+      *reinterpret_cast<float4*>(dqp) = dq;
+    } else {
+      dqp[0] = dq.x; dqp[1] = dq.y; dqp[2] = dq.z; dqp[3] = dq.w;
+    }
   }
 }
 }

@@ -74,19 +74,34 @@ def _dev_f32(t, name, device):
 
 
 def _camera(device, bg, view, proj, campos, tan_fovx, tan_fovy, H, W, scale_modifier, degree,
-            prefiltered, debug, for_backward=False):
+            prefiltered, debug, for_backward=False, flip_x=False, flip_y=False, window=None):
+    """gcr_camera.  The four camera tensors are device tensors as in the reference -- or ALL four CPU tensors
+    (GaussianRasterizerWrapper(host_camera=True)): then the library copies the 38 floats into its kernels' arguments
+    (gcr_camera.host_camera) and no device copy of the camera exists at all."""
+    cams = ((bg, "bg", 3), (view, "viewmatrix", 16), (proj, "projmatrix", 16), (campos, "campos", 3))
+    on_host = all(isinstance(t, torch.Tensor) and t.device.type == "cpu" and t.numel() != 0 for t, _, _ in cams)
     keep = []
     ptrs = []
-    for t, name, n in ((bg, "bg", 3), (view, "viewmatrix", 16), (proj, "projmatrix", 16),
-                       (campos, "campos", 3)):
-        tt, p = _dev_f32(t, name, device)
+    for t, name, n in cams:
+        if on_host:
+            if t.dtype != torch.float32:
+                raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
+            tt = t.contiguous()
+            p = tt.data_ptr()
+        else:
+            tt, p = _dev_f32(t, name, device)
         if tt is None or tt.numel() != n:
             raise RuntimeError("%s must have %d elements" % (name, n))
         keep.append(tt)
         ptrs.append(p)
     cam = N.Camera(int(H), int(W), float(tan_fovx), float(tan_fovy), float(scale_modifier),
                    int(degree), int(bool(prefiltered)), int(bool(debug)), *ptrs)
+    cam.host_camera = int(on_host)
+    cam.flip_x = int(bool(flip_x))
+    cam.flip_y = int(bool(flip_y))
     cam.backward = int(bool(for_backward))
+    if window is not None:  # (x, y, w, h) of the mirrored image: gcr_camera.win_*
+        cam.win_x, cam.win_y, cam.win_w, cam.win_h = (int(v) for v in window)
     return cam, keep
 
 
@@ -142,6 +157,43 @@ class _on_device:
         return False
 
 
+def _forward(L, device, cam, g, P, H, W):
+    """gcr_forward (+ the staged retry) with torch-owned buffers; returns the reference's six-tuple."""
+    byte = dict(dtype=torch.uint8, device=device)
+    # every pixel / every radius is written by the kernels, so no zero-fill launches are needed
+    out_color = torch.empty((NUM_CHANNELS, cam.win_h, cam.win_w) if cam.win_w else (NUM_CHANNELS, H, W),
+                            dtype=torch.float32, device=device)
+    radii = torch.empty((P,), dtype=torch.int32, device=device)
+    stream = _stream(device)
+    geom = torch.empty((L.gcr_geometry_bytes(P),), **byte)
+    img = torch.empty((L.gcr_image_bytes(W, H),), **byte)
+    info = N.FrameInfo()
+    key = (device.index, P, W, H)
+    capacity, list_cap = _hint_get(key)
+    binning = torch.empty((L.gcr_binning_bytes(capacity, W, H) if capacity else 0,), **byte)
+    rc = N.check(L.gcr_forward(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
+                               binning.data_ptr() if capacity else None, binning.numel(), capacity,
+                               list_cap, img.data_ptr(), img.numel(), radii.data_ptr(), out_color.data_ptr(),
+                               C.byref(info), stream),
+                 "gcr_forward")
+    R = int(info.num_rendered)
+    if rc == 1:  # GCR_RETRY_RENDER: no/too small a guess, or a tile list beyond the LDS sort
+        binning = torch.empty((L.gcr_binning_bytes(R, W, H),), **byte)
+        N.check(L.gcr_forward_render(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
+                                     binning.data_ptr(), binning.numel(), img.data_ptr(),
+                                     img.numel(), C.byref(info), out_color.data_ptr(), stream),
+                "gcr_forward_render")
+    longest = int(info.max_tile_instances)
+    _hint_put(key, (R + R // 2 + 4096, longest))  # the library adds its own margin to the longest list
+    return R, out_color, radii, geom, binning, img
+
+
+def _empty_frame(device, H, W):
+    e = torch.empty((0,), dtype=torch.uint8, device=device)  # dgr/rasterize_points.cu:71: zero image, nothing rendered
+    return (0, torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=device),
+            torch.zeros((0,), dtype=torch.int32, device=device), e, e.clone(), e.clone())
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                         image_width, sh, degree, campos, prefiltered, debug, _for_backward=None):
@@ -165,42 +217,106 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     L = N.lib()
     device = means3D.device
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-    byte = dict(dtype=torch.uint8, device=device)
-    if P == 0:  # dgr/rasterize_points.cu:71: zero image, nothing rendered
-        e = torch.empty((0,), **byte)
-        return (0, torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=device),
-                torch.zeros((0,), dtype=torch.int32, device=device), e, e.clone(), e.clone())
-    # every pixel / every radius is written by the kernels, so no zero-fill launches are needed
-    out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=device)
-    radii = torch.empty((P,), dtype=torch.int32, device=device)
+    if P == 0:
+        return _empty_frame(device, H, W)
     with _on_device(device):
         cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
                               tan_fovy, H, W, scale_modifier, degree, prefiltered, debug, _for_backward)
         g, keep_g = _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations,
                                cov3D_precomp)
-        stream = _stream(device)
-        geom = torch.empty((L.gcr_geometry_bytes(P),), **byte)
-        img = torch.empty((L.gcr_image_bytes(W, H),), **byte)
-        info = N.FrameInfo()
-        key = (device.index, P, W, H)
-        capacity, list_cap = _hint_get(key)
-        binning = torch.empty((L.gcr_binning_bytes(capacity, W, H) if capacity else 0,), **byte)
-        rc = N.check(L.gcr_forward(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
-                                   binning.data_ptr() if capacity else None, binning.numel(), capacity,
-                                   list_cap, img.data_ptr(), img.numel(), radii.data_ptr(), out_color.data_ptr(),
-                                   C.byref(info), stream),
-                     "gcr_forward")
-        R = int(info.num_rendered)
-        if rc == 1:  # GCR_RETRY_RENDER: no/too small a guess, or a tile list beyond the LDS sort
-            binning = torch.empty((L.gcr_binning_bytes(R, W, H),), **byte)
-            N.check(L.gcr_forward_render(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
-                                         binning.data_ptr(), binning.numel(), img.data_ptr(),
-                                         img.numel(), C.byref(info), out_color.data_ptr(), stream),
-                    "gcr_forward_render")
-        longest = int(info.max_tile_instances)
-        _hint_put(key, (R + R // 2 + 4096, longest))  # the library adds its own margin to the longest list
+        out = _forward(L, device, cam, g, P, H, W)
         del keep_c, keep_g
-    return R, out_color, radii, geom, binning, img
+    return out
+
+
+# ---- GaussianCity's own call shape: points [N,14] = xyz(3) opacity(1) scale(3) rotation(4) rgb(3) ---------------------
+# dgr/__init__.py:404-426 slices that tensor into five strided views, which the reference's binding copies one by one
+# (.contiguous()), and autograd assembles the [N,14] gradient from five slice-backward kernels and four adds.  The C ABI
+# takes row strides (gcr_gaussians.stride_*, gcr_grads.stride_* / packed): the kernels read the tensor in place and
+# write its gradient in place -- same arithmetic, same bits, about twenty small launches fewer per training step.
+_POINT_COLUMNS = dict(means3D=0, opacities=3, scales=4, rotations=7, colors=11)
+
+
+def _points14_gaussians(points):
+    if points.dim() != 2 or points.size(1) != 14:
+        raise RuntimeError("points must have dimensions (num_points, 14)")
+    if not points.is_cuda:
+        raise RuntimeError("points must be a GPU tensor: this rasterizer has no CPU path")
+    if points.dtype != torch.float32:
+        raise RuntimeError("points must be float32 (got %s)" % points.dtype)
+    if points.stride(1) != 1:
+        points = points.contiguous()
+    base, row = points.data_ptr(), int(points.stride(0))
+    col = {k: base + 4 * v for k, v in _POINT_COLUMNS.items()}
+    g = N.Gaussians(int(points.size(0)), 0, col["means3D"], col["opacities"], None, col["colors"], col["scales"],
+                    col["rotations"], None)
+    g.stride_means3D = g.stride_opacities = g.stride_colors = g.stride_scales = g.stride_rotations = row
+    return g, points
+
+
+def rasterize_points14(points, background, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
+                       image_width, campos, flip_x=False, flip_y=False, for_backward=False, window=None):
+    """Forward of GaussianRasterizerWrapper's call shape on the [N,14] tensor in place (precomputed colours, SH degree
+    0).  Same six-tuple as rasterize_gaussians; the image comes out already mirrored if flip_x / flip_y ask for it, and
+    as the `window` = (x, y, w, h) of that mirrored image if one is given (tiles outside it are not blended)."""
+    L = N.lib()
+    g, pts = _points14_gaussians(points)
+    device = pts.device
+    P, H, W = int(pts.size(0)), int(image_height), int(image_width)
+    if P == 0:
+        return _empty_frame(device, *((window[3], window[2]) if window is not None else (H, W)))
+    with _on_device(device):
+        cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W,
+                              scale_modifier, 0, False, False, for_backward, flip_x, flip_y, window)
+        out = _forward(L, device, cam, g, P, H, W)
+        del keep_c, pts
+    return out
+
+
+def rasterize_points14_backward(points, radii, background, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                                dL_dout_color, campos, geomBuffer, R, binningBuffer, imageBuffer, image_height,
+                                image_width, flip_x=False, flip_y=False, window=None):
+    """Gradient of rasterize_points14 with respect to `points`, as ONE [N,14] tensor the library fills completely
+    (`dL_dout_color` has the shape of the image that was handed out: the window's, if there was one)."""
+    L = N.lib()
+    g, pts = _points14_gaussians(points)
+    device = pts.device
+    P = int(pts.size(0))
+    H, W = int(image_height), int(image_width)
+    want = (NUM_CHANNELS, window[3], window[2]) if window is not None else (NUM_CHANNELS, H, W)
+    if tuple(dL_dout_color.shape) != want:
+        raise RuntimeError("dL_dout_color has shape %s, expected %s" % (tuple(dL_dout_color.shape), want))
+    grad = torch.empty((P, 14), dtype=torch.float32, device=device)
+    if P == 0:
+        return grad
+    if poison_outputs:
+        grad.fill_(float("nan"))
+    # scratch the API wants besides: accumulation records [P,16] (64-byte aligned), dL_dmeans2D [P,3], dL_dcov3D [P,6]
+    flat = torch.empty((P * (N.GRAD_REC_FLOATS + 3 + 6) + 64,), dtype=torch.float32, device=device)
+    if poison_outputs:
+        flat.fill_(float("nan"))
+    rec = flat[:P * N.GRAD_REC_FLOATS]
+    m2d = flat[P * N.GRAD_REC_FLOATS:P * (N.GRAD_REC_FLOATS + 3)]
+    c3d = flat[P * (N.GRAD_REC_FLOATS + 3):P * (N.GRAD_REC_FLOATS + 9)]
+    with _on_device(device):
+        cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W,
+                              scale_modifier, 0, False, False, False, flip_x, flip_y, window)
+        dpix, dpix_ptr = _dev_f32(dL_dout_color, "dL_dout_color", device)
+        gb = grad.data_ptr()
+        col = {k: gb + 4 * v for k, v in _POINT_COLUMNS.items()}
+        grads = N.Grads(m2d.data_ptr(), rec.data_ptr(), col["opacities"], col["colors"], col["means3D"], c3d.data_ptr(),
+                        None, col["scales"], col["rotations"])
+        grads.stride_means3D = grads.stride_opacity = grads.stride_colors = grads.stride_scales = \
+            grads.stride_rotations = 14
+        grads.packed = gb
+        grads.packed_floats = P * 14
+        N.check(L.gcr_backward(C.byref(cam), C.byref(g), radii.data_ptr(), geomBuffer.data_ptr(), geomBuffer.numel(),
+                               binningBuffer.data_ptr() if binningBuffer.numel() else None, binningBuffer.numel(),
+                               imageBuffer.data_ptr(), imageBuffer.numel(), int(R), dpix_ptr, C.byref(grads),
+                               _stream(device)),
+                "gcr_backward")
+        del keep_c, dpix, pts
+    return grad
 
 
 def _gradient_buffers(P, M, device):
@@ -240,7 +356,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if P != 0:
         with _on_device(device):
             cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
-                                  tan_fovy, H, W, scale_modifier, degree, False, debug)
+                                  tan_fovy, H, W, scale_modifier, degree, False, debug)  # (flips: see rasterize_points14)
             # opacity is not an input of the backward (it is read from the geometry state)
             g, keep_g = _gaussians(device, P, means3D, None, sh, colors, scales, rotations,
                                    cov3D_precomp)

@@ -156,6 +156,69 @@ class TrainStepHarness:
         return loss.detach(), img.detach(), n_buckets
 
 
+class StandInGenerator(torch.nn.Module):
+    """A parameter set with the BG generator's size (69,809,101 fp32 values) in front of the rasterizer:
+    `n_layers` chained elementwise layers, each owning an equal share of the parameters, of which the first 28 act on the
+    points -- x <- x * (1 + p[:14]) + p[14:28], the identity at initialisation.  Its gradients are DENSE tensors of the
+    full size (zeros but for 28 values per layer), produced layer by layer while the backward runs, which is what
+    DistributedDataParallel needs to see: message sizes and readiness order of a real generator, none of its arithmetic
+    (the generator itself is out of scope: plain torch modules that run unchanged on ROCm)."""
+
+    def __init__(self, n_param=69_809_101, n_layers=4, device=None):
+        super().__init__()
+        n_layers = max(1, min(int(n_layers), n_param // 28))
+        base = n_param // n_layers
+        sizes = [base] * (n_layers - 1) + [n_param - base * (n_layers - 1)]
+        self.layers = torch.nn.ParameterList(
+            [torch.nn.Parameter(torch.zeros(sz, dtype=torch.float32, device=device)) for sz in sizes])
+
+    def forward(self, base_points):
+        x = base_points
+        for p in self.layers:
+            x = x * (1.0 + p[:14]) + p[14:28]
+        return x
+
+
+class DDPTrainStep:
+    """The reference's G-step (core/train.py:263-295) with its real data-parallel wiring (core/train.py:78-87): the
+    generator stand-in is wrapped in torch's DistributedDataParallel(find_unused_parameters=True), so the gradient
+    buckets are all-reduced over RCCL/xGMI WHILE the backward is still running (autograd hooks), exactly as the
+    reference's DDP does -- not in a separate pass after loss.backward() as TrainStepHarness does.  One frame per
+    rank per step through helpers.get_gaussian_rasterization (wrapper -> one autograd node on the [N,14] tensor).
+    Buckets of `bucket_cap_mb` (default 64): few large messages, a ring all-reduce over xGMI is per-link bound."""
+
+    def __init__(self, rasterizer_wrapper, generator, crop=None, lr=None, group=None, bucket_cap_mb=64):
+        self.rw = rasterizer_wrapper
+        self.crop = crop
+        self.generator = generator
+        self.net = generator
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            first = next(generator.parameters())
+            self.net = torch.nn.parallel.DistributedDataParallel(
+                generator, device_ids=[first.device.index] if first.is_cuda else None, process_group=group,
+                find_unused_parameters=True, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+        # cfg.TRAIN.GAUSSIAN optimizer (core/train.py:293-295); None = the step ends with the reduced gradients
+        self.opt = (torch.optim.Adam(generator.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-7)
+                    if lr is not None else None)
+
+    def step(self, base_points, cam_pos, cam_quat, target=None):
+        """base_points: [N,14] (no gradient needed).  Returns (loss, image)."""
+        from . import helpers
+        for p in self.generator.parameters():
+            p.grad = None
+        pts = self.net(base_points)
+        box = None
+        if self.crop is not None:
+            x, y, w, h = self.crop
+            box = [{"x": x, "y": y, "w": w, "h": h}]
+        img = helpers.get_gaussian_rasterization(pts[None], self.rw, [cam_pos], [cam_quat], crop_bboxes=box)[0]
+        loss = (img - target).abs().mean() if target is not None else img.abs().mean()
+        loss.backward()
+        if self.opt is not None:
+            self.opt.step()
+        return loss.detach(), img.detach()
+
+
 class InferenceLoop:
     """Shape of the reference's render loop (scripts/inference.py:655-667) around the rasterizer only: for
     every pose, points [N,14] -> image -> uint8 HWC frame on the host.  The reference does this on the

@@ -28,11 +28,19 @@ def get_gaussian_rasterization(gs_points, rasterizator, cam_pos, cam_quat, crop_
     Frames are independent, so this loop is also the unit that shards one-per-GPU
     (gaussiancity_amd.frames).
     """
+    # This build's wrapper takes the crop itself (GaussianRasterizerWrapper.forward(crop=...): only the window is
+    # stored and differentiated); any other callable gets the reference's render-then-slice.
+    takes_crop = getattr(rasterizator, "forward", None) is not None and "crop" in getattr(
+        rasterizator.forward, "__code__", type("", (), {"co_varnames": ()})).co_varnames
     frames = []
     for i in range(gs_points.size(0)):
-        img = rasterizator(gs_points[i], cam_pos[i], cam_quat[i])
-        if crop_bboxes is not None:
-            box = crop_bboxes[i]
-            img = img[:, box["y"]: box["y"] + box["h"], box["x"]: box["x"] + box["w"]]
+        box = crop_bboxes[i] if crop_bboxes is not None else None
+        if box is not None and takes_crop:
+            img = rasterizator(gs_points[i], cam_pos[i], cam_quat[i], crop=(box["x"], box["y"], box["w"], box["h"]))
+        else:
+            img = rasterizator(gs_points[i], cam_pos[i], cam_quat[i])
+            if box is not None:
+                img = img[:, box["y"]: box["y"] + box["h"], box["x"]: box["x"] + box["w"]]
         frames.append(img)
-    return torch.stack(frames, dim=0)
+    # B == 1 (GaussianCity's batch size): the stacked batch is a view of the frame, not a copy
+    return frames[0].unsqueeze(0) if len(frames) == 1 else torch.stack(frames, dim=0)

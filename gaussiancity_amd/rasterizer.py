@@ -115,6 +115,35 @@ class RasterizeGaussiansFunction(torch.autograd.Function):
                 grad_scales, grad_rotations, grad_cov3Ds_precomp, None)
 
 
+class _RasterizePoints14Function(torch.autograd.Function):
+    """GaussianRasterizerWrapper's call shape -- points [N,14], precomputed colours, optional mirrored image -- as ONE
+    autograd node on the tensor in place.  The generic route (slice into five views -> GaussianRasterizer ->
+    torch.flip) costs, per training step, five .contiguous() copies in each direction, a zeros_like, five
+    slice-backward zero-fill + copy pairs, four gradient adds and two flip kernels around six + three launches of
+    actual work; here the native side reads the columns with row strides, stores the image mirrored and writes the
+    [N,14] gradient itself (gcr_gaussians.stride_*, gcr_grads.packed, gcr_camera.flip_x).  Same kernels, same bits."""
+
+    @staticmethod
+    def forward(ctx, points, raster_settings, flip_x, flip_y, window):
+        rs = raster_settings
+        num_rendered, color, radii, geom_buffer, binning_buffer, img_buffer = _ext.rasterize_points14(
+            points, rs.bg, rs.scale_modifier, rs.view_matrix, rs.proj_matrix, rs.tanfovx, rs.tanfovy, rs.img_h,
+            rs.img_w, rs.campos, flip_x, flip_y, for_backward=ctx.needs_input_grad[0], window=window)
+        ctx.raster_settings, ctx.num_rendered, ctx.view = rs, num_rendered, (flip_x, flip_y, window)
+        ctx.save_for_backward(points, radii, geom_buffer, binning_buffer, img_buffer)
+        return color
+
+    @staticmethod
+    def backward(ctx, grad_color):
+        rs = ctx.raster_settings
+        points, radii, geom_buffer, binning_buffer, img_buffer = ctx.saved_tensors
+        grad_points = _ext.rasterize_points14_backward(
+            points, radii, rs.bg, rs.scale_modifier, rs.view_matrix, rs.proj_matrix, rs.tanfovx, rs.tanfovy,
+            grad_color, rs.campos, geom_buffer, ctx.num_rendered, binning_buffer, img_buffer, rs.img_h, rs.img_w,
+            *ctx.view)
+        return grad_points, None, None, None, None
+
+
 class GaussianRasterizer(torch.nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
@@ -123,8 +152,8 @@ class GaussianRasterizer(torch.nn.Module):
     def markVisible(self, positions):
         """Frustum (near-plane) test; exported natively as mark_visible (dgr/bindings.cpp:18)."""
         rs = self.raster_settings
-        with torch.no_grad():
-            return _ext.mark_visible(positions, rs.view_matrix, rs.proj_matrix)
+        with torch.no_grad():  # (host-side camera matrices, host_camera=True, go to the device for this one call)
+            return _ext.mark_visible(positions, rs.view_matrix.to(positions.device), rs.proj_matrix.to(positions.device))
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
                 rotations=None, cov3D_precomp=None):
@@ -155,8 +184,15 @@ class GaussianRasterizerWrapper(torch.nn.Module):
     """
 
     def __init__(self, K, sensor_size, flip_lr=True, flip_ud=False, z_near=0.01, z_far=50000.0,
-                 device=torch.device("cuda")):
+                 device=torch.device("cuda"), host_camera=False):
+        """`host_camera` (not in the reference; default off): camera matrices are computed on the host in closed form
+        and handed to the kernels by value -- no scipy, no host-to-device copies, no GEMM, and no
+        `view.inverse()` (rocsolver + a device synchronisation in the reference's recipe).  The matrices then
+        agree with the reference's to rounding (a rigid transform's inverse translation IS the camera position;
+        the 4x4 product is done in float32 on the host), not bit for bit -- the default path stays bit-equal
+        (tests/golden/camera.npz)."""
         super().__init__()
+        self.host_camera = bool(host_camera)
         self.flip_lr = flip_lr
         self.flip_ud = flip_ud
         self.z_near = z_near
@@ -209,6 +245,8 @@ class GaussianRasterizerWrapper(torch.nn.Module):
         # matrix rounds differently from inverse() of its contiguous copy); what is handed out is .contiguous():
         # same values, but the native module would otherwise copy the 16 floats of a strided matrix on every
         # forward and backward call (a 2-4 us kernel in the frame's dependency chain each time).
+        if self.host_camera:
+            return self._host_camera_settings(cam_position, cam_quaternion)
         view = self._get_w2c_matrix(cam_position, cam_quaternion).transpose(0, 1)
         proj_t = self.P.transpose(0, 1)
         return GaussianRasterizationSettings(
@@ -226,13 +264,45 @@ class GaussianRasterizerWrapper(torch.nn.Module):
             debug=False,
         )
 
+    def _host_camera_settings(self, cam_position, cam_quaternion):
+        """The same settings from host arithmetic only (opt-in, see __init__).  Rotation from the quaternion
+        (x, y, z, w) in float64 as scipy does it, columns [F|R|U] -> [R|U|F]; w2c = [R^T | -R^T t]; the tensors
+        handed out are CPU tensors, which the native module passes to its kernels by value.  Scalar Python
+        arithmetic on purpose: a dozen 3x3 numpy calls cost more host time than the whole frame's launches."""
+        tx, ty, tz = (float(v) for v in (cam_position.tolist() if hasattr(cam_position, "tolist") else cam_position))
+        qx, qy, qz, qw = (float(v) for v in (cam_quaternion.tolist() if hasattr(cam_quaternion, "tolist")
+                                             else cam_quaternion))
+        n = math.sqrt(qx * qx + qy * qy + qz * qz + qw * qw)
+        x, y, z, w = qx / n, qy / n, qz / n, qw / n
+        # rotation matrix, columns (forward, right, up)
+        f = (1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w))
+        r = (2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w))
+        u = (2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y))
+        rows = (r, u, f)  # w2c[:3, :3] = [R|U|F]^T
+        w2c = [c for row in rows for c in (row[0], row[1], row[2], -(row[0] * tx + row[1] * ty + row[2] * tz))]
+        view = np.array(w2c + [0.0, 0.0, 0.0, 1.0], dtype=np.float32).reshape(4, 4).T.copy()
+        if getattr(self, "_P_host_t", None) is None:
+            self._P_host_t = np.ascontiguousarray(self.P.detach().cpu().numpy().T)
+            self._bg_host = torch.zeros(3, dtype=torch.float32)
+            self._tan_host = (math.tan(self.fov_x * 0.5), math.tan(self.fov_y * 0.5))
+        return GaussianRasterizationSettings(
+            self.sensor_size[1], self.sensor_size[0], self._tan_host[0], self._tan_host[1], self._bg_host, 1.0,
+            torch.from_numpy(view), torch.from_numpy(view @ self._P_host_t), 0,
+            torch.tensor((tx, ty, tz), dtype=torch.float32), False, False)
+
     def get_gaussian_rasterizer(self, cam_position, cam_quaternion):
         return GaussianRasterizer(
             raster_settings=self._get_gaussian_rasterization_settings(cam_position, cam_quaternion))
 
     # ---- rendering ---------------------------------------------------------------------
-    def _get_gaussian_rasterization(self, points, rasterizer):
+    def _get_gaussian_rasterization(self, points, rasterizer, crop=None):
         # dgr/__init__.py:404-426
+        if (type(rasterizer) is GaussianRasterizer and points.is_cuda and points.dtype == torch.float32
+                and not rasterizer.raster_settings.debug):
+            # this build's own rasterizer: the [N,14] tensor in place, flips (and the caller's crop) folded into the
+            # image store
+            return _RasterizePoints14Function.apply(points, rasterizer.raster_settings, bool(self.flip_lr),
+                                                    bool(self.flip_ud), crop)
         xyz, opacity = points[:, 0:3], points[:, 3:4]
         scales, quaternion, rgbs = points[:, 4:7], points[:, 7:11], points[:, 11:]
         image, _radii = rasterizer(
@@ -249,11 +319,17 @@ class GaussianRasterizerWrapper(torch.nn.Module):
             image = torch.flip(image, dims=[2])
         if self.flip_ud:
             image = torch.flip(image, dims=[1])
+        if crop is not None:
+            x, y, w, h = crop
+            image = image[:, y:y + h, x:x + w]
         return image
 
-    def forward(self, points, cam_position=None, cam_quaternion=None, gaussian_rasterizer=None):
+    def forward(self, points, cam_position=None, cam_quaternion=None, gaussian_rasterizer=None, crop=None):
+        """`crop` = (x, y, w, h) (not in the reference, used by helpers.get_gaussian_rasterization): return only that
+        window of the image -- the same values as image[:, y:y+h, x:x+w], but the native side stores just the window,
+        skips the tiles outside it in both directions, and the crop's slice-backward kernels disappear."""
         _, n_channels = points.shape
         assert n_channels == 14, "The input tensor should have 14 channels."
         if gaussian_rasterizer is None:
             gaussian_rasterizer = self.get_gaussian_rasterizer(cam_position, cam_quaternion)
-        return self._get_gaussian_rasterization(points, gaussian_rasterizer)
+        return self._get_gaussian_rasterization(points, gaussian_rasterizer, crop)

@@ -68,6 +68,17 @@ typedef struct gcr_camera {
   const float *view_matrix; /* [16] */
   const float *proj_matrix; /* [16] */
   const float *campos;      /* [3] */
+  int32_t host_camera; /* !=0: bg / view_matrix / proj_matrix / campos are HOST pointers; the 38 floats are copied
+                          into the kernels' arguments at call time (no device copy of the camera is needed, and the
+                          kernels start without a dependent load).  0: device pointers as in the reference */
+  int32_t flip_x, flip_y; /* !=0: out_color is written mirrored in x / y and dL_dpix is read mirrored -- what
+                          GaussianRasterizerWrapper's flip_lr / flip_ud do with torch.flip after the render
+                          (dgr/__init__.py:421-424), without the copy kernels; the pixel values are the same bits */
+  int32_t win_x, win_y, win_w, win_h; /* win_w > 0: only this window of the (mirrored, if flip_*) image is wanted --
+                          out_color and dL_dpix are [3, win_h, win_w]; tiles that do not touch the window are neither
+                          blended nor walked by the backward (their pixels would be cropped away / have zero gradient:
+                          GaussianCity renders 960x540 and keeps a 640x448 crop, utils/helpers.py:255-260).  radii,
+                          num_rendered and the binning state are those of the full frame.  0: the whole image */
   int32_t backward;    /* hint, never changes a result: !=0 = gcr_backward will be called on this frame's state (the
                           forward blend then cuts its tile lists into the smaller pieces the backward balances best
                           with, option "bwd_piece"); 0 = inference (256-entry pieces: gcr_backward still works) */
@@ -84,6 +95,11 @@ typedef struct gcr_gaussians {
   const float *scales;         /* [P,3]   or NULL */
   const float *rotations;      /* [P,4]   or NULL */
   const float *cov3D_precomp;  /* [P,6]   or NULL  (exactly one of scales+rotations/cov3D) */
+  /* Row strides in floats (0 = dense: 3 / 1 / 3 / 3 / 4).  GaussianCity hands the rasterizer column slices of one
+   * [N,14] tensor (dgr/__init__.py:404-409): with strides = 14 and the five pointers aimed at columns 0 / 3 / 4 / 7 /
+   * 11 the kernels read it in place, where the reference's binding copies every slice (.contiguous(),
+   * dgr/rasterize_points.cu:37-93 through torch).  shs and cov3D_precomp are always dense. */
+  int32_t stride_means3D, stride_opacities, stride_colors, stride_scales, stride_rotations;
 } gcr_gaussians;
 
 /* Gradient outputs (cr/rasterizer.h:39-48).  The arrays may be UNINITIALISED memory: gcr_backward writes every
@@ -107,6 +123,13 @@ typedef struct gcr_grads {
   float *dL_drotations; /* [P,4] (unused when scales==NULL); 16-byte aligned (stored as float4) --
                            gcr_backward rejects a misaligned dL_dconic / dL_drotations with
                            GCR_ERR_INVALID_ARGUMENT */
+  /* Row strides in floats of dL_dmeans3D / dL_dopacity / dL_dcolors / dL_dscales / dL_drotations (0 = dense) and,
+   * when any is set, the ONE block all strided outputs live in (e.g. a [N,14] gradient tensor with strides 14):
+   * gcr_backward zero-fills `packed` as a whole and writes the survivors' values into its columns -- the reference's
+   * caller assembles that tensor with five slice-backward kernels and four adds. */
+  int32_t stride_means3D, stride_opacity, stride_colors, stride_scales, stride_rotations;
+  float *packed;         /* NULL when every output is dense */
+  int64_t packed_floats;
 } gcr_grads;
 
 /* Byte offsets of the sub-arrays carved from the three opaque scratch buffers.  Exposed so

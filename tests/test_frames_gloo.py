@@ -118,3 +118,80 @@ def test_train_step_harness_optimizer_and_inference_loop():
         frames.InferenceLoop(lambda p, cp, cq: torch.full((3, 2, 2), float(cp[0]) / 2 - 1.0), n_streams=ns).run(
             None, poses, consume=lambda i, f: seen.append((i, int(f[0, 0, 0]))))
         assert seen == [(0, 0), (1, 63), (2, 127), (3, 191), (4, 255)], ns
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        gen = frames.StandInGenerator(n_param=4 * 5000 + 3, n_layers=4)
+        with torch.no_grad():  # away from the identity so that every layer's gradient is non-trivial
+            for i, p in enumerate(gen.layers):
+                p[:28] = 0.01 * (i + 1) * torch.arange(28, dtype=torch.float32)
+        step = frames.DDPTrainStep(_FakeWrapper(), gen, crop=(0, 0, 4, 3), bucket_cap_mb=0.02)  # several buckets
+        base = torch.linspace(-1, 1, 50 * 14).view(50, 14) * (rank + 1)      # another frame on every rank
+        pose = np.array([1.0 + rank, 2.0, 3.0])
+        loss, img = step.step(base, pose, np.array([0, 0, 0, 1.0]), torch.zeros(3, 3, 4))
+        grads = [p.grad.clone() for p in gen.layers]
+        # the same step without DDP on both ranks' data: the rank-averaged gradient DDP must have produced
+        want = [torch.zeros_like(p) for p in gen.layers]
+        for r in range(world):
+            ref = frames.StandInGenerator(n_param=4 * 5000 + 3, n_layers=4)
+            ref.load_state_dict(gen.state_dict())
+            s2 = frames.DDPTrainStep.__new__(frames.DDPTrainStep)
+            s2.rw, s2.crop, s2.generator, s2.net, s2.opt = _FakeWrapper(), (0, 0, 4, 3), ref, ref, None
+            s2.step(torch.linspace(-1, 1, 50 * 14).view(50, 14) * (r + 1), np.array([1.0 + r, 2.0, 3.0]),
+                    np.array([0, 0, 0, 1.0]), torch.zeros(3, 3, 4))
+            for w, p in zip(want, ref.layers):
+                w += p.grad / world
+        ok = all(torch.allclose(g, w, rtol=1e-5, atol=1e-7) for g, w in zip(grads, want))
+        dense = all(g.shape == p.shape and float(g[28:].abs().max()) == 0.0 and float(g[:28].abs().max()) > 0
+                    for g, p in zip(grads, gen.layers))
+        q.put((rank, ok, dense, isinstance(step.net, torch.nn.parallel.DistributedDataParallel), img.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_train_step_world2_gloo():
+    """frames.DDPTrainStep: the generator stand-in runs under torch's DistributedDataParallel (the reference's wiring,
+    core/train.py:78-87) -- its bucketed all-reduce, fired by autograd hooks during the backward, leaves the
+    rank-averaged dense gradients on every rank."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, dense, is_ddp, shape in res:
+        assert ok and dense and is_ddp and tuple(shape) == (3, 3, 4), (rank, ok, dense, is_ddp, shape)
+
+
+def test_rank_affinity_from_sysfs(tmp_path, monkeypatch):
+    """gaussiancity_amd.affinity (counterpart of utils/distributed.py:19-62): cpulist parsing, the sysfs lookup on a fake
+    tree, the binding restricted to the process's own mask, and the no-GPU fallbacks."""
+    from gaussiancity_amd import affinity as A
+    assert A.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and A.parse_cpulist("") == []
+    dev = tmp_path / "0000:c1:00.0"
+    dev.mkdir()
+    mine = sorted(os.sched_getaffinity(0))
+    (dev / "local_cpulist").write_text("%d,4000-4001\n" % mine[0])
+    (dev / "numa_node").write_text("1\n")
+    monkeypatch.setattr(A, "gpu_pci_address", lambda i: "0000:c1:00.0")
+    cpus, node, why = A.gpu_local_cpus(0, sysfs=str(tmp_path))
+    assert cpus == sorted({mine[0], 4000, 4001}) and node == 1 and why == "ok"
+    try:
+        r = A.bind_rank_to_gpu(0, sysfs=str(tmp_path))
+        assert r == {"bound": True, "cpus": 1, "numa_node": 1, "why": "ok"} and sorted(os.sched_getaffinity(0)) == [mine[0]]
+    finally:
+        os.sched_setaffinity(0, mine)
+    monkeypatch.setenv("GCR_NO_AFFINITY", "1")
+    assert A.bind_rank_to_gpu(0, sysfs=str(tmp_path))["bound"] is False
+    monkeypatch.delenv("GCR_NO_AFFINITY")
+    monkeypatch.setattr(A, "gpu_pci_address", lambda i: None)
+    assert A.bind_rank_to_gpu(0)["bound"] is False
+    monkeypatch.setattr(A, "gpu_pci_address", lambda i: "0000:ff:1f.0")
+    assert "sysfs" in A.bind_rank_to_gpu(0, sysfs=str(tmp_path))["why"]

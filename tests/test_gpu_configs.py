@@ -158,6 +158,95 @@ def test_c4_training_step_through_helpers_wrapper_and_autograd(oracle_mod, cuda_
     assert np.abs(got_g["dL_dmean3D"]).max() > 0
 
 
+@pytest.mark.parametrize("flip_lr,flip_ud", [(True, False), (False, False), (True, True), (False, True)])
+def test_points14_node_equals_the_generic_route(oracle_mod, cuda_device, flip_lr, flip_ud):
+    """GaussianRasterizerWrapper on this build's own rasterizer runs as ONE autograd node on the [N,14] tensor in place
+    (row strides, mirrored image store, one [N,14] gradient: rasterizer._RasterizePoints14Function).  Against the
+    generic route of the reference (five slices -> GaussianRasterizer -> torch.flip), forced here by a subclass
+    instance: image bit-equal for every flip combination, gradient equal within the atomics' tolerance -- with general
+    opacities and rotations, and with `points` a column window of a wider tensor (row stride 20)."""
+    from gaussiancity_amd.rasterizer import GaussianRasterizer, GaussianRasterizerWrapper
+    cfg, sc = synth.make_scene("C4")
+    N, W, H = cfg["P"], cfg["W"], cfg["H"]
+    dev = cuda_device
+    rng = np.random.default_rng(77)
+    rot = rng.normal(size=(N, 4)).astype(np.float32)
+    rot /= np.linalg.norm(rot, axis=1, keepdims=True)
+    opa = rng.uniform(0.1, 1.0, size=(N, 1)).astype(np.float32)
+    pts_np = np.concatenate([sc["means3D"], opa, sc["scales"] * np.float32(3.0), rot, sc["colors_precomp"]], axis=1)
+    wide = torch.zeros((N, 20), dtype=torch.float32, device=dev)
+    wide[:, 3:17] = torch.from_numpy(pts_np).to(dev)
+    wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), flip_lr=flip_lr, flip_ud=flip_ud, device=dev)
+    pos, quat = synth.orbit_poses()[7]
+    dpix = torch.from_numpy(synth.grad_image(W, H, 5)).to(dev)
+
+    class Foreign(GaussianRasterizer):  # not `type(...) is GaussianRasterizer`: takes the reference's route
+        pass
+
+    res = {}
+    for name in ("node", "generic"):
+        leaf = wide.clone().requires_grad_(True)
+        points = leaf[:, 3:17]
+        assert points.stride(0) == 20
+        rz = wr.get_gaussian_rasterizer(pos, quat)
+        if name == "generic":
+            rz = Foreign(rz.raster_settings)
+        img = wr(points, gaussian_rasterizer=rz)
+        (img * dpix).sum().backward()
+        res[name] = (img.detach().cpu().numpy(), leaf.grad.cpu().numpy())
+    assert np.array_equal(res["node"][0].view(np.uint32), res["generic"][0].view(np.uint32)), "image differs"
+    gn, gg = res["node"][1], res["generic"][1]
+    assert np.all(gn[:, :3] == 0) and np.all(gn[:, 17:] == 0) and np.abs(gn[:, 3:17]).max() > 0
+    for lo, hi, nme in ((3, 6, "xyz"), (6, 7, "opacity"), (7, 10, "scale"), (10, 14, "rotation"), (14, 17, "rgb")):
+        a, b = gn[:, lo:hi], gg[:, lo:hi]
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max()), nme
+    # and against the oracle (image of the un-mirrored frame, then the wrapper's flips)
+    rs = wr._get_gaussian_rasterization_settings(pos, quat)
+    rs_cpu = rs._replace(bg=rs.bg.cpu(), view_matrix=rs.view_matrix.cpu(), proj_matrix=rs.proj_matrix.cpu(),
+                         campos=rs.campos.cpu())
+    sco = dict(means3D=sc["means3D"], scales=sc["scales"] * np.float32(3.0), rotations=rot, opacities=opa,
+               colors_precomp=sc["colors_precomp"])
+    fr = _frame(oracle_mod, rs_cpu, sco, use_sh=False)
+    want = fr.out_color
+    if flip_lr:
+        want = want[:, :, ::-1]
+    if flip_ud:
+        want = want[:, ::-1, :]
+    assert np.array_equal(res["node"][0].view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+
+
+def test_host_camera_option(oracle_mod, cuda_device):
+    """GaussianRasterizerWrapper(host_camera=True): the camera is host arithmetic handed to the kernels by value
+    (gcr_camera.host_camera).  The matrices agree with the reference recipe's to rounding; the render is bit-exact
+    against the oracle fed with the SAME matrices, and within 1e-4 of the default path's image but for a counted
+    handful of threshold pixels; gradients flow through the same node."""
+    from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper
+    cfg, sc = synth.make_scene("C4")
+    N, W, H = cfg["P"], cfg["W"], cfg["H"]
+    dev = cuda_device
+    pts_np, rot = _c4_points(sc)
+    pos, quat = synth.orbit_poses()[9]
+    wr_ref = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), device=dev)
+    wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), device=dev, host_camera=True)
+    rs_ref, rs = wr_ref._get_gaussian_rasterization_settings(pos, quat), wr._get_gaussian_rasterization_settings(pos, quat)
+    assert rs.view_matrix.device.type == "cpu" and rs.campos.device.type == "cpu"
+    for a, b in ((rs.view_matrix, rs_ref.view_matrix), (rs.proj_matrix, rs_ref.proj_matrix), (rs.campos, rs_ref.campos)):
+        assert np.allclose(a.numpy(), b.cpu().numpy(), rtol=2e-6, atol=2e-4)
+    points = torch.from_numpy(pts_np).to(dev).requires_grad_(True)
+    img = wr(points, pos, quat)
+    img.abs().sum().backward()
+    assert points.grad is not None and float(points.grad.abs().max()) > 0
+    sco = dict(means3D=sc["means3D"], scales=sc["scales"], rotations=rot, opacities=np.ones((N, 1), np.float32),
+               colors_precomp=sc["colors_precomp"])
+    fr = _frame(oracle_mod, rs, sco, use_sh=False)
+    got = img.detach().cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(fr.out_color[:, :, ::-1]).view(np.uint32))
+    ref_img = wr_ref(torch.from_numpy(pts_np).to(dev), pos, quat).cpu().numpy()
+    off = np.abs(got - ref_img).max(axis=0) > 1e-4 * max(1.0, float(np.abs(ref_img).max()))
+    assert int(off.sum()) <= max(2, int(2e-5 * W * H)), int(off.sum())
+    assert bool(wr.get_gaussian_rasterizer(pos, quat).markVisible(points.detach()[:, :3].contiguous()).any())
+
+
 def test_c5_20m_4k_forward_vs_oracle_and_list_properties(oracle_mod, cuda_device):
     cfg, sc = synth.make_scene("C5")
     P, W, H = cfg["P"], cfg["W"], cfg["H"]

@@ -4,10 +4,24 @@ tools/collect_profiles.sh: per bench.py stage, the per-launch averages of the st
 
 usage: make_traffic.py <fetch.db> <write.db> <out.json> [<sq.db> [<workload label>]]
 """
+import hashlib
 import json
+import os
 import re
 import sqlite3
 import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussiancity_amd", "csrc")
+
+
+def kernel_source_hashes():
+    """sha256[:16] of every kernel source: bench.py compares them with the tree it runs from, so that per-launch
+    instruction counts taken from a committed file are flagged when the kernel has changed since."""
+    out = {}
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")) and f.startswith("gcr_"):
+            out[f] = hashlib.sha256(open(os.path.join(CSRC, f), "rb").read()).hexdigest()[:16]
+    return out
 
 # bench.py stage -> substrings of the kernel names launched inside that stage timer (gcr_api.hip)
 STAGES = {
@@ -53,6 +67,7 @@ def main(fetch_db, write_db, out, sq_db=None, workload="C3 (5M S-city, 1920x1080
         "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: MI355X_MICROARCH.md says FETCH_SIZE reports half the "
                 "bytes of 16-B/lane reads on gfx950; raw values kept here",
         "kernels": kernels,
+        "kernel_source_sha16": kernel_source_hashes(),
     }
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc, indent=1))
