@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = (
     "gcr_backward", "gcr_mark_visible", "gcr_rasterize_forward", "gcr_set_option",
     "gcr_get_stage_ms", "gcr_grad_record_floats",
 )
-GRAD_REC_FLOATS = 16  # gcr_grad_record_floats(): floats per Gaussian of gcr_grads.dL_dconic (checked at load)
+GRAD_REC_FLOATS = 16  # gcr_grad_record_floats() by default (32 under option "deterministic_backward": ext asks per call)
 
 STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "ranges", "blend_fwd", "blend_bwd",
                "preprocess_bwd")
@@ -142,7 +142,7 @@ def lib():
     L.gcr_get_stage_ms.restype = C.c_int
     L.gcr_get_stage_ms.argtypes = [C.POINTER(C.c_float), C.c_int]
     L.gcr_grad_record_floats.restype = C.c_int
-    if L.gcr_grad_record_floats() != GRAD_REC_FLOATS:
+    if L.gcr_grad_record_floats() not in (GRAD_REC_FLOATS, 2 * GRAD_REC_FLOATS):
         raise RuntimeError("libgcr_hip.so gradient record size mismatch")
     if L.gcr_abi_version() != ABI_VERSION:
         raise RuntimeError("libgcr_hip.so ABI version mismatch")

@@ -17,6 +17,7 @@ std::atomic<int> g_force_radix{0};
 std::atomic<int> g_force_global_cursor{0};
 std::atomic<int> g_sort_in_blend{0};     // 1: the forward blend sorts short tile lists itself (lower frame latency, lower throughput)
 std::atomic<int> g_split_preprocess{0};  // 1: K1 as two kernels (streaming cull, then exact pass) instead of the fused one
+std::atomic<int> g_deterministic{0};  // 1: fixed-point gradient records (order-independent sums), gcr_internal.h
 std::atomic<int> g_bwd_piece{128};  // entries per backward piece of frames rendered for a backward (gcr_camera.backward)
 #ifdef GCR_EXPERIMENTS  // make EXTRA=-DGCR_EXPERIMENTS: timing experiments, never in the shipping library
 std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results are wrong when set
@@ -204,7 +205,7 @@ void gcr_debug_set_clock_buffer(void* dev_ptr) { g_clock_buf.store((unsigned lon
 #endif
 
 int gcr_abi_version(void) { return GCR_ABI_VERSION; }
-int gcr_grad_record_floats(void) { return GCR_GRAD_REC_FLOATS; }
+int gcr_grad_record_floats(void) { return g_deterministic.load() ? GCR_GRAD_REC_FLOATS_DET : GCR_GRAD_REC_FLOATS; }
 const char* gcr_last_error(void) { return g_err.c_str(); }
 
 size_t gcr_geometry_bytes(int32_t P) {
@@ -239,6 +240,7 @@ int gcr_set_option(const char* name, int value) {
 #endif
   if (!strcmp(name, "split_preprocess")) return g_split_preprocess.exchange(value);
   if (!strcmp(name, "sort_in_blend")) return g_sort_in_blend.exchange(value);
+  if (!strcmp(name, "deterministic_backward")) return g_deterministic.exchange(value != 0);
   if (!strcmp(name, "bwd_piece")) {
     const int v = value < GCR_PIECE_MIN ? GCR_PIECE_MIN : (value > GCR_PIECE_MAX ? GCR_PIECE_MAX : value);
     return g_bwd_piece.exchange(v);
@@ -680,6 +682,8 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   int nblocks_k1 = 0, chunk_k1 = 0;
   gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(g_split_preprocess.load() != 0), &nblocks_k1, &chunk_k1);
 
+  const int det = g_deterministic.load();  // the caller sized dL_dconic with gcr_grad_record_floats() under the same option
+
   // Every output is written here (the reference asks its caller for nine zero-filled tensors,
   // dgr/rasterize_points.cu:118-126): zeros are streamed over the dense arrays by extra workgroups of the K7
   // launch, K8 then writes the survivors' values.
@@ -718,7 +722,8 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   if (R > 0) {
     StageTimer t(s, ST_BLEND_BWD);  // one slot per stage: a second timer of the same stage would halve the average
     HIP_TRY(gcr_launch_zero_grad_records(nblocks_k1, chunk_k1, (const uint32_t*)(gb + L.geom_vis_list),
-                                         (const uint32_t*)(gb + L.geom_vis_count), (float4*)gr->dL_dconic, s),
+                                         (const uint32_t*)(gb + L.geom_vis_count), (float4*)gr->dL_dconic,
+                                         (det ? GCR_GRAD_REC_FLOATS_DET : GCR_GRAD_REC_FLOATS) / 4, s),
             "zero gradient records");
     GcrBlendArgs b;
     memset(&b, 0, sizeof(b));
@@ -738,7 +743,8 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     b.final_T = (float*)(ib + L.img_final_T);
     b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
     b.dL_dpix = dL_dpix;
-    b.grad_rec = gr->dL_dconic;  // [P][GCR_GRAD_REC_FLOATS] accumulation records (include/gcr.h)
+    b.grad_rec = gr->dL_dconic;  // [P][gcr_grad_record_floats()] accumulation records (include/gcr.h)
+    b.deterministic = det;
     b.binning_base = bb;
     b.frame_in = (const unsigned long long*)(gb + L.geom_num_rendered);
     b.R = (unsigned long long)R;
@@ -768,6 +774,7 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   a.vis_count = (const uint32_t*)(gb + L.geom_vis_count);
   a.nblocks = nblocks_k1; a.chunk = chunk_k1;
   a.grad_rec = (const float4*)gr->dL_dconic;
+  a.deterministic = det;
   a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dcolor = gr->dL_dcolors; a.dL_dopacity = gr->dL_dopacity;
   a.dL_dmean3D = gr->dL_dmeans3D; a.dL_dcov3D = gr->dL_dcov3D; a.dL_dsh = gr->dL_dsh;
   a.dL_dscale = gr->dL_dscales; a.dL_drot = gr->dL_drotations;

@@ -658,7 +658,16 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
             const float v = sAcc[slot * 9 + comp];
             if (v != 0.0f) {
               sAcc[slot * 9 + comp] = 0.0f;
-              if (GCR_FLUSH_ON) atomicAdd(&a.grad_rec[(size_t)sId[slot] * GCR_GRAD_REC_FLOATS + rec_idx], v);
+              if (!GCR_FLUSH_ON) continue;
+              if (!a.deterministic) {
+                atomicAdd(&a.grad_rec[(size_t)sId[slot] * GCR_GRAD_REC_FLOATS + rec_idx], v);
+              } else {  // Q31.32, order-independent (gcr_internal.h); saturating conversion
+                const double sc = (double)v * GCR_DET_SCALE;
+                const long long q = sc >= 9.2e18 ? 0x7fffffffffffffffll : (sc <= -9.2e18 ? -0x7fffffffffffffffll : __double2ll_rn(sc));
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.grad_rec) + (size_t)sId[slot] * (GCR_GRAD_REC_FLOATS_DET / 2) +
+                              rec_idx,
+                          (unsigned long long)q);
+              }
             }
           }
         }

@@ -75,6 +75,7 @@ struct GcrPreprocessBwdArgs {
   const float4* grad_rec;  // K7's per-Gaussian accumulation records (GCR_GRAD_REC_FLOATS each)
   float *dL_dmean2D, *dL_dcolor, *dL_dopacity;  // written here from the records (API outputs)
   float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+  int deterministic;                            // grad_rec holds fixed-point records (GCR_GRAD_REC_FLOATS_DET)
   int s_mean, s_scale, s_rot;                   // input row strides in floats
   int g_mean, g_opac, g_col, g_scale, g_rot;    // output row strides in floats
   GcrCamVals cam;
@@ -86,6 +87,13 @@ struct GcrPreprocessBwdArgs {
 // memory-side transaction (scattered over four arrays they were 44 % of K7: DESIGN.md section 5).
 // K8 reads the record with three dwordx4 loads and writes the API's dL_dmeans2D / dL_dcolors / dL_dopacity.
 #define GCR_GRAD_REC_FLOATS 16
+// Option "deterministic_backward": the record is nine 64-bit FIXED-POINT sums (same order, Q31.32) in a 128-byte
+// slot instead of nine floats in a 64-byte one.  Integer addition is associative, so the per-Gaussian totals no longer
+// depend on the order in which the tiles' waves reach the memory-side atomic units -- two runs give the same bits
+// (SURVEY.md section 5 asks for such a debug mode; the float atomics of the default path differ in the last bits from
+// run to run, like the reference's).  Resolution 2^-32 = 2.3e-10 per addend, range +-2.1e9.
+#define GCR_GRAD_REC_FLOATS_DET 32
+#define GCR_DET_SCALE 4294967296.0  // 2^32
 
 // The dense zero fill of the backward's outputs (every Gaussian K8 does not visit keeps gradient 0): up to eight
 // float arrays, streamed by the first `blocks` workgroups of the K7 launch while its tile workgroups -- which
@@ -148,6 +156,7 @@ struct GcrBlendArgs {
   const float* dL_dpix;     // bwd
   float* grad_rec;          // bwd: [P][GCR_GRAD_REC_FLOATS] accumulation records (zeroed for K1's survivors)
   GcrFillArgs fill;         // bwd: zero fill of the dense outputs, streamed in slices between the work items
+  int deterministic;        // bwd: fixed-point gradient records (option "deterministic_backward")
   int win_x, win_y, win_w, win_h;  // output window in image coordinates AFTER mirroring (win_w == 0: whole image)
   int flip_x, flip_y;       // fwd: out_color stored mirrored; bwd: dL_dpix loaded mirrored (gcr_camera.flip_x / flip_y)
   GcrCamVals cam;           // bg by value when cam.by_value
@@ -174,7 +183,7 @@ hipError_t gcr_launch_mark_visible(int P, const float* means3D, const float* vie
 hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, bool split, hipStream_t s);
 // zero the K7 accumulation records of K1's survivors / stream zeros over the backward's outputs (R == 0 frames)
 hipError_t gcr_launch_zero_grad_records(int nblocks, int chunk, const uint32_t* vis_list, const uint32_t* vis_count,
-                                        float4* grad_rec, hipStream_t s);
+                                        float4* grad_rec, int rec_quads, hipStream_t s);
 hipError_t gcr_launch_fill(const GcrFillArgs& f, hipStream_t s);
 hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long long* total,
                                       hipStream_t s);

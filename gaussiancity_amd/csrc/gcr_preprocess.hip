@@ -821,9 +821,21 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
   }
   // K7's accumulation record of this Gaussian (gcr_internal.h); the API's per-Gaussian outputs of the
   // blend gradient are written from it here
-  const float4 g0 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 0];  // dcolor.rgb, dopacity
-  const float4 g1 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 1];  // dmean2D.xy, dconic.x, dconic.y
-  const float4 g2 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 2];  // dconic.w
+  float4 g0, g1, g2;  // dcolor.rgb, dopacity | dmean2D.xy, dconic.x, dconic.y | dconic.w
+  if (!a.deterministic) {
+    g0 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 0];
+    g1 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 1];
+    g2 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 2];
+  } else {  // nine Q31.32 sums (option "deterministic_backward")
+    const long long* __restrict__ r64 =
+        reinterpret_cast<const long long*>(a.grad_rec) + (size_t)idx * (GCR_GRAD_REC_FLOATS_DET / 2);
+    float f[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) f[k] = (float)((double)r64[k] * (1.0 / GCR_DET_SCALE));
+    g0 = make_float4(f[0], f[1], f[2], f[3]);
+    g1 = make_float4(f[4], f[5], f[6], f[7]);
+    g2 = make_float4(f[8], 0.0f, 0.0f, 0.0f);
+  }
   const float dcx = g1.z, dcy = g1.w, dcz = g2.x;
   a.dL_dmean2D[3 * (size_t)idx] = g1.x;
   a.dL_dmean2D[3 * (size_t)idx + 1] = g1.y;
@@ -1114,14 +1126,13 @@ namespace {
 // records that have to start at zero (and the only ones K8 reads).
 __global__ __launch_bounds__(256) void k_zero_grad_records(int chunk, const uint32_t* __restrict__ vis_list,
                                                            const uint32_t* __restrict__ vis_count,
-                                                           float4* __restrict__ grad_rec) {
+                                                           float4* __restrict__ grad_rec, int rec_quads) {
   const uint32_t nvis = vis_count[blockIdx.x];
   const uint32_t* __restrict__ my_list = vis_list + (size_t)blockIdx.x * chunk;
   const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  // four lanes per record: one 64-byte line per quad of lanes
-  for (uint32_t it = threadIdx.x; it < nvis * (GCR_GRAD_REC_FLOATS / 4); it += 256)
-    grad_rec[(size_t)my_list[it / (GCR_GRAD_REC_FLOATS / 4)] * (GCR_GRAD_REC_FLOATS / 4) +
-             (it % (GCR_GRAD_REC_FLOATS / 4))] = z;
+  // rec_quads (4, or 8 for the fixed-point records) lanes per record: one 64-byte line per quad of lanes
+  for (uint32_t it = threadIdx.x; it < nvis * (uint32_t)rec_quads; it += 256)
+    grad_rec[(size_t)my_list[it / (uint32_t)rec_quads] * (uint32_t)rec_quads + (it % (uint32_t)rec_quads)] = z;
 }
 
 __global__ __launch_bounds__(256) void k_fill_zero(const GcrFillArgs f) {
@@ -1131,9 +1142,9 @@ __global__ __launch_bounds__(256) void k_fill_zero(const GcrFillArgs f) {
 }  // namespace
 
 hipError_t gcr_launch_zero_grad_records(int nblocks, int chunk, const uint32_t* vis_list, const uint32_t* vis_count,
-                                        float4* grad_rec, hipStream_t s) {
+                                        float4* grad_rec, int rec_quads, hipStream_t s) {
   if (nblocks <= 0) return hipSuccess;
-  k_zero_grad_records<<<nblocks, 256, 0, s>>>(chunk, vis_list, vis_count, grad_rec);
+  k_zero_grad_records<<<nblocks, 256, 0, s>>>(chunk, vis_list, vis_count, grad_rec, rec_quads);
   return hipGetLastError();
 }
 

@@ -292,12 +292,13 @@ def rasterize_points14_backward(points, radii, background, scale_modifier, viewm
     if poison_outputs:
         grad.fill_(float("nan"))
     # scratch the API wants besides: accumulation records [P,16] (64-byte aligned), dL_dmeans2D [P,3], dL_dcov3D [P,6]
-    flat = torch.empty((P * (N.GRAD_REC_FLOATS + 3 + 6) + 64,), dtype=torch.float32, device=device)
+    nrec = int(L.gcr_grad_record_floats())  # 16, or 32 under option "deterministic_backward"
+    flat = torch.empty((P * (nrec + 3 + 6) + 64,), dtype=torch.float32, device=device)
     if poison_outputs:
         flat.fill_(float("nan"))
-    rec = flat[:P * N.GRAD_REC_FLOATS]
-    m2d = flat[P * N.GRAD_REC_FLOATS:P * (N.GRAD_REC_FLOATS + 3)]
-    c3d = flat[P * (N.GRAD_REC_FLOATS + 3):P * (N.GRAD_REC_FLOATS + 9)]
+    rec = flat[:P * nrec]
+    m2d = flat[P * nrec:P * (nrec + 3)]
+    c3d = flat[P * (nrec + 3):P * (nrec + 9)]
     with _on_device(device):
         cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W,
                               scale_modifier, 0, False, False, False, flip_x, flip_y, window)
@@ -324,7 +325,8 @@ def _gradient_buffers(P, M, device):
     of ONE uninitialised buffer: gcr_backward writes every element of every output itself (include/gcr.h).
     dL_dconic is the native side's accumulation scratch: one 64-byte record per Gaussian.
     Order: dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations."""
-    shapes = ((P, 3), (P, 3), (P, NUM_CHANNELS), (P, N.GRAD_REC_FLOATS), (P, 1), (P, 6), (P, M, 3), (P, 3), (P, 4))
+    nrec = int(N.lib().gcr_grad_record_floats())  # 16, or 32 under option "deterministic_backward"
+    shapes = ((P, 3), (P, 3), (P, NUM_CHANNELS), (P, nrec), (P, 1), (P, 6), (P, M, 3), (P, 3), (P, 4))
     sizes = [int(torch.Size(sh).numel()) for sh in shapes]
     starts, off = [], 0
     for n in sizes:  # every view starts 256-byte aligned (dL_dconic and dL_drotations are accessed as float4)

@@ -109,7 +109,7 @@ typedef struct gcr_gaussians {
  * records. */
 typedef struct gcr_grads {
   float *dL_dmeans2D;   /* [P,3] (x,y used) */
-  float *dL_dconic;     /* [P, gcr_grad_record_floats() = 16] scratch (contents undefined on return), 64-byte
+  float *dL_dconic;     /* [P, gcr_grad_record_floats()] (16 floats; 32 in the deterministic mode) scratch (contents undefined on return), 64-byte
                            aligned: the role of the
                            reference's dL_dconic [P,2,2] (dgr/rasterize_points.cu:121), widened to one
                            64-byte accumulation record per Gaussian (colour 3, opacity 1, mean2D 2,
@@ -227,7 +227,7 @@ int gcr_forward_render(const gcr_camera *cam, const gcr_gaussians *g, void *geom
                        void *hip_stream);
 
 /* K7 (reverse-walk blend gradient) + K8 (preprocess gradient). dL_dpix is [3,H,W]. */
-/* floats per Gaussian of gcr_grads.dL_dconic (16) */
+/* floats per Gaussian of gcr_grads.dL_dconic: 16, or 32 under option "deterministic_backward" */
 int gcr_grad_record_floats(void);
 
 int gcr_backward(const gcr_camera *cam, const gcr_gaussians *g, const int32_t *radii,
@@ -258,6 +258,11 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *                     is <= 384 (one launch less: lower frame latency, lower throughput)
  *   "split_preprocess" 1: K1 as two kernels (streaming cull, then exact pass) instead of   default 0
  *                     the fused one (A/B)
+ *   "deterministic_backward" 1: gcr_backward accumulates the per-Gaussian blend gradients as 64-bit       default 0
+ *                     fixed-point sums (Q31.32) instead of fp32 atomics: integer addition is associative, so two runs
+ *                     give bit-identical gradients whatever order the tiles' waves arrive in (a debug mode: fp32
+ *                     atomics -- here and in the reference -- differ in the last bits from run to run).
+ *                     gcr_grad_record_floats() then returns 32: size gcr_grads.dL_dconic AFTER setting the option.
  *   "bwd_piece"    entries per backward piece (64..256) of frames rendered with             default 128
  *                     gcr_camera.backward != 0 (include/gcr.h; gcr_internal.h "backward pieces")
  *   "timing"       1: record per-stage HIP events (see gcr_get_stage_ms)             default 0

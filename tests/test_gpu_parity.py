@@ -152,6 +152,44 @@ def test_fast_exp_mode_within_tolerance(oracle_mod, cuda_device, name, P, W, H, 
                  ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot", "dL_dsh"])
 
 
+def test_deterministic_backward_mode(oracle_mod, cuda_device):
+    """Option "deterministic_backward" (a deterministic debug mode next to the atomics): the
+    per-Gaussian blend gradients are accumulated as 64-bit fixed-point sums, so the order in which the tiles' waves
+    reach the atomic units no longer matters -- repeated runs are BIT-identical, through both native entry points, and
+    still within tolerance of the oracle.  (The default fp32 atomics are not asserted to differ: they usually do, in
+    the last bits, but need not.)"""
+    from gaussiancity_amd import _native as N, ext
+    P, W, H, seed = 9000, 96, 80, 43
+    rs = scenes.camera(W, H, pose_index=seed % 24)._replace(sh_degree=1, bg=torch.tensor((0.1, 0.3, 0.0)))
+    sc = scenes.blob_scene(P, seed, 1, smax=14.0)   # every Gaussian lands in many tiles: many waves per record
+    fr = _frame(oracle_mod, rs, sc, True)
+    dpix = np.random.default_rng(seed).normal(size=(3, H, W)).astype(np.float32)
+    names = ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot", "dL_dsh"]
+    prev = N.set_option("deterministic_backward", 1)
+    try:
+        assert N.lib().gcr_grad_record_floats() == 32
+        args, out = G.run_forward(rs, sc, cuda_device, for_backward=True)
+        runs = [G.run_backward(args, out, dpix, cuda_device) for _ in range(4)]
+        for r in runs[1:]:
+            for n in names:
+                assert np.array_equal(r[n].view(np.uint32), runs[0][n].view(np.uint32)), n + " differs between runs"
+        _check_grads(fr.backward(dpix), runs[0], names)
+        # the [N,14] entry point shares the mode
+        pts = torch.from_numpy(np.concatenate([sc["means3D"], sc["opacities"], sc["scales"], sc["rotations"],
+                                               np.clip(sc["shs"][:, 0, :], 0, 1)], axis=1).astype(np.float32)).to(cuda_device)
+        cam = (rs.bg.to(cuda_device), rs.scale_modifier, rs.view_matrix.to(cuda_device), rs.proj_matrix.to(cuda_device),
+               rs.tanfovx, rs.tanfovy)
+        R, _, radii, geom, binning, img = ext.rasterize_points14(pts, *cam, H, W, rs.campos.to(cuda_device), for_backward=True)
+        g14 = [ext.rasterize_points14_backward(pts, radii, *cam, torch.from_numpy(dpix).to(cuda_device),
+                                               rs.campos.to(cuda_device), geom, R, binning, img, H, W).cpu().numpy()
+               for _ in range(3)]
+        assert np.array_equal(g14[0].view(np.uint32), g14[1].view(np.uint32)) and np.array_equal(
+            g14[0].view(np.uint32), g14[2].view(np.uint32)) and np.abs(g14[0]).max() > 0
+    finally:
+        N.set_option("deterministic_backward", prev)
+    assert N.lib().gcr_grad_record_floats() == 16
+
+
 def test_precomputed_cov3d(oracle_mod, cuda_device):
     P, W, H = 2500, 160, 96
     rs = scenes.camera(W, H)._replace(sh_degree=2)
