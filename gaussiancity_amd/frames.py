@@ -24,19 +24,21 @@ def shard_frames(n_frames, rank, world):
     return list(range(rank, n_frames, world))
 
 
-def render_sharded(render_fn, n_frames, rank=None, world=None, gather=True, group=None):
+def render_sharded(render_fn, n_frames, rank=None, world=None, gather=True, group=None, as_uint8=False):
     """Each rank renders its own frames with `render_fn(frame_index) -> Tensor[3,H,W]`.
 
     Returns {frame_index: image}.  With gather=True every rank ends up with all frames
     (one all_gather of equally sized stacks; the last round is padded), which is the only
-    collective and is off the per-frame critical path.
+    collective and is off the per-frame critical path.  as_uint8=True converts every frame to the
+    uint8 [H,W,3] the video writer wants (scripts/inference.py:665) BEFORE the gather: a quarter of the bytes
+    over xGMI (a 4K frame: 24.9 MB instead of 99.5 MB).
     """
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = shard_frames(n_frames, rank, world)
-    local = {f: render_fn(f) for f in mine}
+    local = {f: (InferenceLoop.to_uint8_hwc(render_fn(f)) if as_uint8 else render_fn(f)) for f in mine}
     if not gather or world == 1:
         return local
     per_rank = (n_frames + world - 1) // world
@@ -47,7 +49,7 @@ def render_sharded(render_fn, n_frames, rank=None, world=None, gather=True, grou
     dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=group)
     c, h, w = [int(v) for v in shape.tolist()]
     ref = sample if sample is not None else torch.zeros(1, device=shape.device)
-    stack = torch.zeros((per_rank, c, h, w), dtype=torch.float32, device=ref.device)
+    stack = torch.zeros((per_rank, c, h, w), dtype=torch.uint8 if as_uint8 else torch.float32, device=ref.device)
     for slot, f in enumerate(mine):
         stack[slot] = local[f]
     gathered = [torch.empty_like(stack) for _ in range(world)]

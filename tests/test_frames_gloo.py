@@ -36,6 +36,11 @@ def _worker(rank, world, port, q):
         out = frames.render_sharded(render, 7)          # 7 frames on 2 ranks: ragged last round
         ok_gather = sorted(out) == list(range(7)) and all(torch.equal(out[f], _fake_frame(f)) for f in out)
         local_only = frames.render_sharded(_fake_frame, 7, gather=False)
+        # uint8 [H,W,3] frames gathered instead of fp32 [3,H,W]: a quarter of the bytes, same frames
+        u8 = frames.render_sharded(lambda f: _fake_frame(f) / 8.0 - 0.5, 7, as_uint8=True)
+        ok_gather = ok_gather and sorted(u8) == list(range(7)) and all(
+            u8[f].dtype == torch.uint8 and tuple(u8[f].shape) == (4, 5, 3)
+            and torch.equal(u8[f], frames.InferenceLoop.to_uint8_hwc(_fake_frame(f) / 8.0 - 0.5)) for f in u8)
         # gradient exchange: three tensors, tiny buckets so that several messages are used
         g = [torch.full((1000,), float(rank + 1)), torch.full((17, 3), float(10 * (rank + 1))),
              torch.full((5,), float(-rank))]

@@ -6,7 +6,7 @@
 # Afterwards copy gpurun_out/<tag>_* into profiles/ and commit.
 #   usage: gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
 set -u
-TAG=${1:-r01}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out
@@ -42,6 +42,22 @@ python $R/tools/rocpd_pmc.py /tmp/${TAG}_c2_w/p_results.db $O/${TAG}_c2_bwd_pmc_
 python $R/tools/rocpd_pmc.py /tmp/${TAG}_c2_sq/p_results.db $O/${TAG}_c2_bwd_pmc_sq.txt > /dev/null
 python $R/tools/make_traffic.py /tmp/${TAG}_c2_f/p_results.db /tmp/${TAG}_c2_w/p_results.db $O/${TAG}_traffic_c2.json \
   /tmp/${TAG}_c2_sq/p_results.db "C2 (500k S-rand, 640x448, SH3, forward + backward)" > /dev/null
+# ---- backward blend: SQ counters (VALU / LDS activity), per-wave phase clocks and knock-outs (experiment build) --------
+bash $R/tools/k7_pmc.sh ${TAG} 128 > /dev/null 2>&1
+if [ -f $R/tools/_build/libgcr_hip_exp.so ]; then
+  (cd $R && timeout 200 python tools/k7_clocks.py --piece 128 > $O/${TAG}_k7_clocks.json 2>/dev/null)
+  (cd $R && timeout 200 python tools/k7_knockout.py 128 > $O/${TAG}_k7_knockouts.jsonl 2>/dev/null)
+fi
+(cd $R && timeout 300 python tools/piece_probe.py --pieces 256,128,64 > $O/${TAG}_piece_probe.jsonl 2>/dev/null)
+
+# ---- C4: the wrapper / helpers path at the product's own shape (host-bound): kernel trace + host profile ---------------
+B="python $R/bench.py --train-step --steps 200 --host-camera"
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_c4_kt -o k -- $B > /dev/null 2>&1 < /dev/null
+python $R/tools/rocpd_stats.py /tmp/${TAG}_c4_kt/k_results.db $O/${TAG}_c4_kernel_trace_stats.txt > /dev/null
+(cd $R && timeout 200 python tools/host_profile_c4.py --host-camera > $O/${TAG}_c4_host_profile.txt 2>/dev/null)
+(cd $R && timeout 200 python tools/host_profile_c4.py > $O/${TAG}_c4_host_profile_reference_camera.txt 2>/dev/null)
+python $R/bench.py --train-step --steps 200 > $O/${TAG}_bench_c4_trainstep.json 2>/dev/null
+python $R/bench.py --train-step --steps 200 --host-camera > $O/${TAG}_bench_c4_trainstep_host_camera.json 2>/dev/null
 [ -n "${RASTER_ONLY:-}" ] && { python $R/bench.py > $O/${TAG}_bench_c3.json 2>/dev/null; echo collected $TAG raster only; ls $O | grep "^${TAG}_"; exit 0; }
 
 # ---- visibility and hash-grid encoder ------------------------------------------------------------------------
@@ -61,5 +77,7 @@ python $R/bench.py > $O/${TAG}_bench_c3.json 2>/dev/null
 python $R/bench.py --config C5 --steps 48 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_c5.json 2>/dev/null
 python $R/bench.py --path visibility > $O/${TAG}_bench_visibility.json 2>/dev/null
 python $R/bench.py --path grid-encoder > $O/${TAG}_bench_grid_encoder.json 2>/dev/null
-python $R/bench.py --train-step --steps 100 > $O/${TAG}_bench_c4_trainstep.json 2>/dev/null
+python $R/bench.py --config C2 --backward --no-secondary --steps 200 > $O/${TAG}_bench_c2_fwd_bwd.json 2>/dev/null
+python $R/bench.py --steps 20 --no-cpu-baseline --no-secondary > $O/${TAG}_bench_c3_k20.json 2>/dev/null
+python $R/bench.py --fast-exp --no-cpu-baseline > $O/${TAG}_bench_c3_fast_exp.json 2>/dev/null
 echo collected $TAG; ls $O | grep "^${TAG}_"
