@@ -388,7 +388,11 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   if (clk_on) clk[i] = __builtin_readcyclecounter();
 #define GCR_FLUSH_ON !(a.debug_flags & 1)
 #define GCR_LDS_ADD_ON !(a.debug_flags & 4)
+#define GCR_STEP_ON !(a.debug_flags & 16)   /* knock-out: the step's arithmetic (loads and loop stay) */
+#define GCR_PASSES_ON !(a.debug_flags & 32) /* knock-out: everything after the unit's prologue */
 #else
+#define GCR_STEP_ON true
+#define GCR_PASSES_ON true
 #define GCR_K7_CLK(i)
 #define GCR_FLUSH_ON true
 #define GCR_LDS_ADD_ON true
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
     for (int rr = 0; rr < 4; rr++) rmax[rr] = __shfl(row_max, rr * 16, 64);
     const uint32_t wave_max = max(max(rmax[0], rmax[1]), max(rmax[2], rmax[3]));
     GCR_K7_CLK(1)  // pixel state known
-    if (wave_max <= lo) continue;  // wave-uniform: this quadrant consumed nothing of the piece
+    if (wave_max <= lo || !GCR_PASSES_ON) continue;  // wave-uniform: this quadrant consumed nothing of the piece
     const int top = (int)min(hi, wave_max);
 
     // Start state of the reverse walk.  A pixel whose last contributor lies in this piece (or before it) starts as
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
     const float power_raw = gcr_power(QA.z, QA.w, QB.x, dx, dy);                               \
     const bool in_range = __float_as_uint(QC.z) < last_contributor && !(power_raw > 0.0f) &&   \
                           !(power_raw < QC.y);                                                 \
-    if (__ballot(in_range) != 0ull) { /* else the whole wave skips this step */                \
+    if (__ballot(in_range) != 0ull && GCR_STEP_ON) { /* else the whole wave skips this step */ \
       const float power = in_range ? power_raw : 0.0f;                                         \
       const float G = blend_exp<FAST_EXP>(power);                                              \
       const float alpha = __builtin_fminf(0.99f, QB.y * G);                                    \
@@ -662,8 +666,8 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
               if (!a.deterministic) {
                 atomicAdd(&a.grad_rec[(size_t)sId[slot] * GCR_GRAD_REC_FLOATS + rec_idx], v);
               } else {  // Q31.32, order-independent (gcr_internal.h); saturating conversion
-                const double sc = (double)v * GCR_DET_SCALE;
-                const long long q = sc >= 9.2e18 ? 0x7fffffffffffffffll : (sc <= -9.2e18 ? -0x7fffffffffffffffll : __double2ll_rn(sc));
+                const float sc = v * (float)GCR_DET_SCALE;  // exact: a power of two
+                const long long q = sc >= 9.2e18f ? 0x7fffffffffffffffll : (sc <= -9.2e18f ? -0x7fffffffffffffffll : __float2ll_rn(sc));
                 atomicAdd(reinterpret_cast<unsigned long long*>(a.grad_rec) + (size_t)sId[slot] * (GCR_GRAD_REC_FLOATS_DET / 2) +
                               rec_idx,
                           (unsigned long long)q);

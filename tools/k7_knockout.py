@@ -1,5 +1,6 @@
 """K7 knock-out timings (experiment build: results are WRONG with any flag set): which part of the backward blend the
-launch time hangs on.  flags: 1 = no global flush, 4 = no LDS adds, 8 = one LDS read per step instead of three."""
+launch time hangs on.  flags: 1 = no global flush, 4 = no LDS adds, 8 = one LDS read per step instead of three,
+16 = no step arithmetic (loads and loops stay), 32 = only the units' prologues (pixel state, early exits)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["GCR_LIB_PATH"] = os.path.join(ROOT, "tools", "_build", "libgcr_hip_exp.so")
@@ -19,7 +20,7 @@ def fb(i):
     a = (rs.bg, t["means3D"], E, t["opacities"], t["scales"], t["rotations"], 1.0, E, rs.view_matrix, rs.proj_matrix, rs.tanfovx, rs.tanfovy, H, W, t["shs"], 3, rs.campos, False, False)
     R, color, radii, geom, binning, img = ext.rasterize_gaussians(*a, _for_backward=True)
     ext.rasterize_gaussians_backward(rs.bg, t["means3D"], radii, E, t["scales"], t["rotations"], 1.0, E, rs.view_matrix, rs.proj_matrix, rs.tanfovx, rs.tanfovy, dpix, t["shs"], 3, rs.campos, geom, R, binning, img, False)
-for flag in (0, 1, 4, 8, 12, 13, 0):
+for flag in (0, 1, 4, 5, 16, 21, 32, 0):
     N.set_option("k7_skip_flush", flag)
     for i in range(5): fb(i)
     N.set_option("timing", 1); N.stage_ms(); torch.cuda.synchronize()
