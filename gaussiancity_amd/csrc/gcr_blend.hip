@@ -402,6 +402,92 @@ constexpr int WPASS = 64;                          // list entries a wave stages
 constexpr int WLIST_STRIDE = WPASS + 8;            // u16 slots per row list: entries + pipeline pads
 constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave's sentinel entry
 
+// One list entry against this lane's pixel (cr/backward.cu:505-580).  Branch-free body with THREE selects: what
+// bounds this kernel is VALU issue at ~4 cycles per instruction for this mix (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU,
+// profiles/r03_k7_pmc.txt: v_cndmask with an SGPR-pair mask, v_cmp and the DPP moves cost about twice an FMA), so
+// the step avoids selects on the loop state altogether:
+//   * a lane that upstream would `continue` gets power = 0 (every intermediate stays finite) and alpha_eff = 0;
+//   * with alpha_eff = 0 the transmittance update is exact without a select: rcp(1) = 1, T * 1 = T;
+//   * accum_rec is updated EAGERLY: (last_alpha, last_color, accum_rec) := (alpha_eff, colour, a) where
+//     a = last_alpha * last_color + (1 - last_alpha) * accum_rec is what upstream computes at its next contributing
+//     entry.  After a skipped entry the state reads (0, *, a), whose next blend 0 * c + 1 * a = a is exactly the value
+//     the untouched state would have produced -- same bits, no selects;
+//   * dchannel_dcolor = alpha_eff * T is zero by itself; only dL_dalpha needs masking (one select).
+// The two quotients share the divisor 1 - alpha: one v_rcp_f32 + one Newton step (<= 1 ulp) instead of two IEEE
+// division expansions -- the only place the HIP path leaves gcr-fp32-v2; K7's sums are order-dependent (atomics)
+// and tolerance-checked anyway.
+#define GCR_BWD_STEP(QA, QB, QC)                                                               \
+  {                                                                                            \
+    const float dx = QA.x - pixx, dy = QA.y - pixy;                                            \
+    const float power_raw = gcr_power(QA.z, QA.w, QB.x, dx, dy);                               \
+    const bool in_range = __float_as_uint(QC.z) < last_contributor && !(power_raw > 0.0f) &&   \
+                          !(power_raw < QC.y);                                                 \
+    if (__ballot(in_range) != 0ull && GCR_STEP_ON) { /* else the whole wave skips this step */ \
+      const float power = in_range ? power_raw : 0.0f;                                         \
+      const float G = blend_exp<FAST_EXP>(power);                                              \
+      const float alpha = __builtin_fminf(0.99f, QB.y * G);                                    \
+      const bool use = in_range && !(alpha < 1.0f / 255.0f);                                   \
+      const float a_eff = use ? alpha : 0.0f;                                                  \
+      const float om = 1.f - a_eff;                                                            \
+      const float rc0 = __builtin_amdgcn_rcpf(om);                                             \
+      const float rcp = __builtin_fmaf(rc0, __builtin_fmaf(-om, rc0, 1.0f), rc0);              \
+      T = T * rcp;                                                                             \
+      const float dchannel_dcolor = a_eff * T;                                                 \
+      const float oml = 1.f - last_alpha;                                                      \
+      acc0 = __builtin_fmaf(last_alpha, lc0, oml * acc0);                                      \
+      acc1 = __builtin_fmaf(last_alpha, lc1, oml * acc1);                                      \
+      acc2 = __builtin_fmaf(last_alpha, lc2, oml * acc2);                                      \
+      lc0 = QB.z;                                                                              \
+      lc1 = QB.w;                                                                              \
+      lc2 = QC.x;                                                                              \
+      last_alpha = a_eff;                                                                      \
+      float dL_dalpha = 0.0f;                                                                  \
+      dL_dalpha = __builtin_fmaf(lc0 - acc0, dLp0, dL_dalpha);                                 \
+      dL_dalpha = __builtin_fmaf(lc1 - acc1, dLp1, dL_dalpha);                                 \
+      dL_dalpha = __builtin_fmaf(lc2 - acc2, dLp2, dL_dalpha);                                 \
+      dL_dalpha *= T;                                                                          \
+      dL_dalpha += (neg_T_final * rcp) * bg_dot_dpixel;                                        \
+      dL_dalpha = use ? dL_dalpha : 0.0f;                                                      \
+      const float dL_dG = QB.y * dL_dalpha;                                                    \
+      const float gdx = G * dx, gdy = G * dy;                                                  \
+      const float dG_ddelx = -gdx * QA.z - gdy * QA.w;                                         \
+      const float dG_ddely = -gdy * QB.x - gdx * QA.w;                                         \
+      const float hG = -0.5f * dL_dG;                                                          \
+      float v[9];                                                                              \
+      v[0] = dchannel_dcolor * dLp0;                                                           \
+      v[1] = dchannel_dcolor * dLp1;                                                           \
+      v[2] = dchannel_dcolor * dLp2;                                                           \
+      v[3] = dL_dG * dG_ddelx * ddelx_dx;                                                      \
+      v[4] = dL_dG * dG_ddely * ddely_dy;                                                      \
+      v[5] = gdx * dx * hG;                                                                    \
+      v[6] = gdx * dy * hG;                                                                    \
+      v[7] = gdy * dy * hG;                                                                    \
+      v[8] = G * dL_dalpha;                                                                    \
+      /* reduce-scatter over each 16-lane row, then ONE ds_add_f32: lanes 0..8 of every row */ \
+      /* add their row's sum of term (lane & 15) into the column of the row's entry */         \
+      const float rsum = gcr_row_reduce_scatter9(v, lane);                                     \
+      if (acc_slot >= 0 && GCR_LDS_ADD_ON) atomicAdd(reinterpret_cast<float*>(acc_base + __float_as_uint(QC.w)), rsum); \
+    }                                                                                          \
+  }
+#ifdef GCR_EXPERIMENTS  /* knock-out bit 3: one LDS read per step instead of three (results wrong) */
+#define GCR_BWD_LOAD(QA, QB, QC, OFF)                              \
+  QA = *reinterpret_cast<const float4*>(sEb + (OFF));             \
+  if (!(a.debug_flags & 8)) {                                      \
+    QB = *reinterpret_cast<const float4*>(sEb + (OFF) + 16);       \
+    QC = *reinterpret_cast<const float4*>(sEb + (OFF) + 32);       \
+  } else {                                                         \
+    QB = make_float4(QA.z, 0.5f, QA.x, QA.y);                      \
+    QC = make_float4(QA.w, -5.0f, __uint_as_float(0u), __uint_as_float(0u)); \
+  }
+#else
+#define GCR_BWD_LOAD(QA, QB, QC, OFF)                              \
+  QA = *reinterpret_cast<const float4*>(sEb + (OFF));             \
+  QB = *reinterpret_cast<const float4*>(sEb + (OFF) + 16);         \
+  QC = *reinterpret_cast<const float4*>(sEb + (OFF) + 32);
+#endif
+
+
+
 template <bool FAST_EXP>
 __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[WPASS + 1];
@@ -513,91 +599,6 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
     const float neg_T_final = -T_final;
     float last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;
 
-// One list entry against this lane's pixel (cr/backward.cu:505-580).  Branch-free body with THREE selects: what
-// bounds this kernel is VALU issue at ~4 cycles per instruction for this mix (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU,
-// profiles/r03_k7_pmc.txt: v_cndmask with an SGPR-pair mask, v_cmp and the DPP moves cost about twice an FMA), so
-// the step avoids selects on the loop state altogether:
-//   * a lane that upstream would `continue` gets power = 0 (every intermediate stays finite) and alpha_eff = 0;
-//   * with alpha_eff = 0 the transmittance update is exact without a select: rcp(1) = 1, T * 1 = T;
-//   * accum_rec is updated EAGERLY: (last_alpha, last_color, accum_rec) := (alpha_eff, colour, a) where
-//     a = last_alpha * last_color + (1 - last_alpha) * accum_rec is what upstream computes at its next contributing
-//     entry.  After a skipped entry the state reads (0, *, a), whose next blend 0 * c + 1 * a = a is exactly the value
-//     the untouched state would have produced -- same bits, no selects;
-//   * dchannel_dcolor = alpha_eff * T is zero by itself; only dL_dalpha needs masking (one select).
-// The two quotients share the divisor 1 - alpha: one v_rcp_f32 + one Newton step (<= 1 ulp) instead of two IEEE
-// division expansions -- the only place the HIP path leaves gcr-fp32-v2; K7's sums are order-dependent (atomics)
-// and tolerance-checked anyway.
-#define GCR_BWD_STEP(QA, QB, QC)                                                               \
-  {                                                                                            \
-    const float dx = QA.x - pixx, dy = QA.y - pixy;                                            \
-    const float power_raw = gcr_power(QA.z, QA.w, QB.x, dx, dy);                               \
-    const bool in_range = __float_as_uint(QC.z) < last_contributor && !(power_raw > 0.0f) &&   \
-                          !(power_raw < QC.y);                                                 \
-    if (__ballot(in_range) != 0ull && GCR_STEP_ON) { /* else the whole wave skips this step */ \
-      const float power = in_range ? power_raw : 0.0f;                                         \
-      const float G = blend_exp<FAST_EXP>(power);                                              \
-      const float alpha = __builtin_fminf(0.99f, QB.y * G);                                    \
-      const bool use = in_range && !(alpha < 1.0f / 255.0f);                                   \
-      const float a_eff = use ? alpha : 0.0f;                                                  \
-      const float om = 1.f - a_eff;                                                            \
-      const float rc0 = __builtin_amdgcn_rcpf(om);                                             \
-      const float rcp = __builtin_fmaf(rc0, __builtin_fmaf(-om, rc0, 1.0f), rc0);              \
-      T = T * rcp;                                                                             \
-      const float dchannel_dcolor = a_eff * T;                                                 \
-      const float oml = 1.f - last_alpha;                                                      \
-      acc0 = __builtin_fmaf(last_alpha, lc0, oml * acc0);                                      \
-      acc1 = __builtin_fmaf(last_alpha, lc1, oml * acc1);                                      \
-      acc2 = __builtin_fmaf(last_alpha, lc2, oml * acc2);                                      \
-      lc0 = QB.z;                                                                              \
-      lc1 = QB.w;                                                                              \
-      lc2 = QC.x;                                                                              \
-      last_alpha = a_eff;                                                                      \
-      float dL_dalpha = 0.0f;                                                                  \
-      dL_dalpha = __builtin_fmaf(lc0 - acc0, dLp0, dL_dalpha);                                 \
-      dL_dalpha = __builtin_fmaf(lc1 - acc1, dLp1, dL_dalpha);                                 \
-      dL_dalpha = __builtin_fmaf(lc2 - acc2, dLp2, dL_dalpha);                                 \
-      dL_dalpha *= T;                                                                          \
-      dL_dalpha += (neg_T_final * rcp) * bg_dot_dpixel;                                        \
-      dL_dalpha = use ? dL_dalpha : 0.0f;                                                      \
-      const float dL_dG = QB.y * dL_dalpha;                                                    \
-      const float gdx = G * dx, gdy = G * dy;                                                  \
-      const float dG_ddelx = -gdx * QA.z - gdy * QA.w;                                         \
-      const float dG_ddely = -gdy * QB.x - gdx * QA.w;                                         \
-      const float hG = -0.5f * dL_dG;                                                          \
-      float v[9];                                                                              \
-      v[0] = dchannel_dcolor * dLp0;                                                           \
-      v[1] = dchannel_dcolor * dLp1;                                                           \
-      v[2] = dchannel_dcolor * dLp2;                                                           \
-      v[3] = dL_dG * dG_ddelx * ddelx_dx;                                                      \
-      v[4] = dL_dG * dG_ddely * ddely_dy;                                                      \
-      v[5] = gdx * dx * hG;                                                                    \
-      v[6] = gdx * dy * hG;                                                                    \
-      v[7] = gdy * dy * hG;                                                                    \
-      v[8] = G * dL_dalpha;                                                                    \
-      /* reduce-scatter over each 16-lane row, then ONE ds_add_f32: lanes 0..8 of every row */ \
-      /* add their row's sum of term (lane & 15) into the column of the row's entry */         \
-      const float rsum = gcr_row_reduce_scatter9(v, lane);                                     \
-      if (acc_slot >= 0 && GCR_LDS_ADD_ON) atomicAdd(reinterpret_cast<float*>(acc_base + __float_as_uint(QC.w)), rsum); \
-    }                                                                                          \
-  }
-#ifdef GCR_EXPERIMENTS  /* knock-out bit 3: one LDS read per step instead of three (results wrong) */
-#define GCR_BWD_LOAD(QA, QB, QC, OFF)                              \
-  QA = *reinterpret_cast<const float4*>(sEb + (OFF));             \
-  if (!(a.debug_flags & 8)) {                                      \
-    QB = *reinterpret_cast<const float4*>(sEb + (OFF) + 16);       \
-    QC = *reinterpret_cast<const float4*>(sEb + (OFF) + 32);       \
-  } else {                                                         \
-    QB = make_float4(QA.z, 0.5f, QA.x, QA.y);                      \
-    QC = make_float4(QA.w, -5.0f, __uint_as_float(0u), __uint_as_float(0u)); \
-  }
-#else
-#define GCR_BWD_LOAD(QA, QB, QC, OFF)                              \
-  QA = *reinterpret_cast<const float4*>(sEb + (OFF));             \
-  QB = *reinterpret_cast<const float4*>(sEb + (OFF) + 16);         \
-  QC = *reinterpret_cast<const float4*>(sEb + (OFF) + 32);
-#endif
-
-
     // ---- passes of 64 list entries, back to front: pass slot `lane` holds list entry pos - 1 - lane
     for (int pos = top; pos > (int)lo; pos -= WPASS) {
       const int e_l = pos - 1 - lane;
@@ -692,9 +693,10 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
     }
 #endif
   }
+}
+
 #undef GCR_BWD_STEP
 #undef GCR_BWD_LOAD
-}
 
 }  // namespace
 
