@@ -21,6 +21,7 @@ std::atomic<int> g_deterministic{0};  // 1: fixed-point gradient records (order-
 std::atomic<int> g_bwd_piece{128};  // entries per backward piece of frames rendered for a backward (gcr_camera.backward)
 #ifdef GCR_EXPERIMENTS  // make EXTRA=-DGCR_EXPERIMENTS: timing experiments, never in the shipping library
 std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results are wrong when set
+std::atomic<int> g_k6_debug{0};  // forward blend knock-outs (gcr_blend.hip GCR_K6_*)
 std::atomic<unsigned long long*> g_clock_buf{nullptr};  // K7 per-wave phase clocks (gcr_debug_set_clock_buffer)
 #endif
 
@@ -237,6 +238,7 @@ int gcr_set_option(const char* name, int value) {
   if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.exchange(value);
 #ifdef GCR_EXPERIMENTS
   if (!strcmp(name, "k7_skip_flush")) return g_k7_skip_flush.exchange(value);
+  if (!strcmp(name, "k6_debug")) return g_k6_debug.exchange(value);
 #endif
   if (!strcmp(name, "split_preprocess")) return g_split_preprocess.exchange(value);
   if (!strcmp(name, "sort_in_blend")) return g_sort_in_blend.exchange(value);
@@ -444,6 +446,9 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   b.pairs = pairs;
   b.list_out = list;
   set_piece_args(b, cam, L, R_layout > 0 ? binning : nullptr, geom);
+#ifdef GCR_EXPERIMENTS
+  b.debug_flags = g_k6_debug.load();
+#endif
   {
     StageTimer t(s, ST_BLEND_FWD);
     HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, sort_in_blend, s), "blend forward");

@@ -130,6 +130,13 @@ GCR_DEV uint32_t slot_of_offset(uint32_t off) { return (off * 1366u) >> 16; }
 //     reads; unique keys => rank = position); a longer list -- only possible when the caller's length hint was
 //     stale, the host then switches to the K4 path -- is ranked the same way through global loads: slow, correct.
 //     The sorted indices are also written to `list_out` for the backward.
+#ifdef GCR_EXPERIMENTS  /* knock-outs for timing: bit 0 = no step arithmetic, bit 1 = no chunk loop at all */
+#define GCR_K6_STEP_ON !(a.debug_flags & 1)
+#define GCR_K6_LOOP_ON !(a.debug_flags & 2)
+#else
+#define GCR_K6_STEP_ON true
+#define GCR_K6_LOOP_ON true
+#endif
 template <bool FAST_EXP, bool SORT>
 __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[CHUNK + 1];
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
     const float dx = QA.x - pixx, dy = QA.y - pixy;                                          \
     const float power = __builtin_fmaf(QA.w * dx, dy, __builtin_fmaf(QB.x * dy, dy, (QA.z * dx) * dx)); \
     const bool in_range = !(power > 0.0f) && !(power < QC.y);                                \
-    if (__ballot(in_range) != 0ull) { /* wave-uniform */                                     \
+    if (__ballot(in_range) != 0ull && GCR_K6_STEP_ON) { /* wave-uniform */                   \
       /* lanes outside [pmin, 0] may produce garbage; every use below is behind a select */  \
       const float araw = __builtin_fminf(0.99f, QB.y * blend_exp<FAST_EXP>(power));          \
       const bool valid = in_range && !(araw < 1.0f / 255.0f);                                \
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   QB = *reinterpret_cast<const float4*>(sEb + (OFF) + 16);         \
   QC = *reinterpret_cast<const float2*>(sEb + (OFF) + 32);
 
-  for (int base = 0; base < total; base += cs) {
+  for (int base = 0; base < total && GCR_K6_LOOP_ON; base += cs) {
     // block-wide vote (cr/forward.cu:284-286); also fences the previous chunk's LDS reads
     if (__syncthreads_count(!(Tw > 0.0f)) == 256) break;
     // crossing a piece boundary: checkpoint of the per-pixel state for the backward (|Tw| = T; a finished pixel's
