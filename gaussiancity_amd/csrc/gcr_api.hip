@@ -368,10 +368,12 @@ static void set_piece_args(GcrBlendArgs& b, const gcr_camera* cam, const gcr_lay
   b.work_off = L.bin_work;
   b.mask_off = L.bin_mask;
   b.frame_out = (unsigned long long*)((char*)geom + L.geom_num_rendered);
+#ifdef GCR_EXPERIMENTS
   if (const char* e = getenv("GCR_K6_NOEXTRAS")) {  // A/B only: what the backward's state costs the forward blend
     if (strchr(e, 'w')) { b.ckpt = nullptr; b.work = nullptr; }
     if (strchr(e, 'm')) b.mask_out = nullptr;
   }
+#endif
 }
 
 // Enqueues scatter + per-tile LDS sort + forward blend (the default binning path).
@@ -720,7 +722,9 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     // of zeros): 118 / 117 / 121 / 128 / 136 us backward wall time -- more of them only take issue slots and memory
     // queues away from the walking waves.  256 waves = the same 16k threads.
     unsigned long long cap = 256ull;
-    if (const char* e = getenv("GCR_FILL_BLOCKS")) cap = (unsigned long long)atoi(e);  // experiments only
+#ifdef GCR_EXPERIMENTS
+    if (const char* e = getenv("GCR_FILL_BLOCKS")) cap = (unsigned long long)atoi(e);
+#endif
     fill.blocks = (int)(want < cap ? (want ? want : 1ull) : cap);
   }
 

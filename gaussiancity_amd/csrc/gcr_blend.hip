@@ -730,7 +730,9 @@ hipError_t gcr_launch_blend_bwd(const GcrBlendArgs& a, bool fast_exp, hipStream_
   // one wave per (work item, quadrant) for the piece size the host expects the forward to have used; the number of
   // items is only known on the device, the slot count bounds it
   unsigned long long units = 4ull * gcr_piece_slots(a.R, (unsigned long long)T, (unsigned long long)a.piece);
-  if (const char* env = getenv("GCR_K7_BLOCKS")) units = (unsigned long long)atoll(env);  // experiments only
+#ifdef GCR_EXPERIMENTS
+  if (const char* env = getenv("GCR_K7_BLOCKS")) units = (unsigned long long)atoll(env);
+#endif
   const unsigned int grid = (unsigned int)(units > 0x3fffffffull ? 0x3fffffffull : units) + (unsigned int)a.fill.blocks;
   if (fast_exp)
     k_blend_bwd<true><<<grid, 64, 0, s>>>(a);
