@@ -114,6 +114,35 @@ def test_backward_rejects_misaligned_gradient_records_and_experiment_options_are
     assert lib.gcr_set_option(b"k7_skip_flush", 1) < 0
 
 
+def test_abi_v5_argument_checks_without_a_gpu():
+    """The round-3 additions to the structs are validated before any launch: an output window must lie inside the
+    image; strided gradient outputs need the block they live in; dense rotations must be 16-byte aligned."""
+    lib = N.lib()
+    buf = (C.c_float * 256)()
+    p = (C.addressof(buf) + 63) // 64 * 64
+    R = N.FrameInfo(-1, -1)
+    cam = N.Camera(32, 32, 0.3, 0.3, 1.0, 0, 0, 0, p, p, p, p)
+    cam.win_x, cam.win_y, cam.win_w, cam.win_h = 20, 0, 16, 8           # 20 + 16 > 32
+    g = N.Gaussians(4, 0, p, p, None, p, p, p, None)
+    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), p, 8, p, 8, p, C.byref(R), None) == -1
+    assert b"window" in lib.gcr_last_error()
+    cam.win_x = 0
+    assert lib.gcr_forward_preprocess(C.byref(cam), C.byref(g), p, 8, p, 8, p, C.byref(R), None) == -2   # passes the check
+    cam = N.Camera(16, 16, 0.3, 0.3, 1.0, 0, 0, 0, p, p, p, p)
+    g = N.Gaussians(1, 0, p, None, None, p, p, p, None)
+    gr = N.Grads(p, p, p, p, p, p, None, p, p)
+    gr.stride_means3D = 14                                                 # strided, but no `packed` block
+    rc = lib.gcr_backward(C.byref(cam), C.byref(g), p, p, 1 << 30, None, 0, p, 1 << 30, 0, p, C.byref(gr), None)
+    assert rc == -1 and b"packed" in lib.gcr_last_error()
+    g2 = N.Gaussians(1, 0, p, None, None, p, p, p + 4, None)               # dense rotations, misaligned
+    gr2 = N.Grads(p, p, p, p, p, p, None, p, p)
+    rc = lib.gcr_backward(C.byref(cam), C.byref(g2), p, p, 1 << 30, None, 0, p, 1 << 30, 0, p, C.byref(gr2), None)
+    assert rc == -1 and b"rotations must be 16-byte aligned" in lib.gcr_last_error()
+    assert lib.gcr_set_option(b"bwd_piece", 10) >= 0 and lib.gcr_set_option(b"bwd_piece", 128) == 64     # clamped to 64..256
+    assert lib.gcr_set_option(b"deterministic_backward", 1) == 0 and lib.gcr_grad_record_floats() == 32
+    assert lib.gcr_set_option(b"deterministic_backward", 0) == 1 and lib.gcr_grad_record_floats() == 16
+
+
 def _gcv_header_functions():
     src = open(os.path.join(ROOT, "include", "gcv.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)

@@ -215,6 +215,48 @@ def test_points14_node_equals_the_generic_route(oracle_mod, cuda_device, flip_lr
     assert np.array_equal(res["node"][0].view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
 
 
+@pytest.mark.parametrize("flip_lr,flip_ud,crop", [(True, False, (37, 21, 301, 173)), (False, True, (0, 0, 17, 9)),
+                                                  (True, True, (640, 400, 320, 140)), (False, False, (5, 530, 950, 10))])
+def test_windowed_render_equals_cropping_the_full_frame(oracle_mod, cuda_device, flip_lr, flip_ud, crop):
+    """GaussianRasterizerWrapper.forward(crop=(x, y, w, h)) stores and differentiates only that window of the (mirrored)
+    image (gcr_camera.win_*; tiles outside it are skipped in both directions).  Windows that cut tiles, touch the image
+    border or are a few pixels wide: the image equals the oracle's full frame flipped and cropped, bit for bit, and the
+    [N,14] gradient equals the oracle's for dL/dpixel zero outside the window."""
+    from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper
+    cfg, sc = synth.make_scene("C4")
+    N, W, H = cfg["P"], cfg["W"], cfg["H"]
+    dev = cuda_device
+    pts_np, rot = _c4_points(sc)
+    pos, quat = synth.orbit_poses()[11]
+    wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), flip_lr=flip_lr, flip_ud=flip_ud, device=dev)
+    points = torch.from_numpy(pts_np).to(dev).requires_grad_(True)
+    x, y, w, h = crop
+    img = wr(points, pos, quat, crop=crop)
+    assert tuple(img.shape) == (3, h, w)
+    dwin = np.random.default_rng(3).normal(size=(3, h, w)).astype(np.float32)
+    (img * torch.from_numpy(dwin).to(dev)).sum().backward()
+    rs = wr._get_gaussian_rasterization_settings(pos, quat)
+    rs_cpu = rs._replace(bg=rs.bg.cpu(), view_matrix=rs.view_matrix.cpu(), proj_matrix=rs.proj_matrix.cpu(),
+                         campos=rs.campos.cpu())
+    sco = dict(means3D=sc["means3D"], scales=sc["scales"], rotations=rot, opacities=np.ones((N, 1), np.float32),
+               colors_precomp=sc["colors_precomp"])
+    fr = _frame(oracle_mod, rs_cpu, sco, use_sh=False)
+
+    def view(a):  # the wrapper's flips (each is its own inverse)
+        a = a[:, :, ::-1] if flip_lr else a
+        return a[:, ::-1, :] if flip_ud else a
+
+    want = np.ascontiguousarray(view(fr.out_color)[:, y:y + h, x:x + w])
+    assert np.array_equal(img.detach().cpu().numpy().view(np.uint32), want.view(np.uint32))
+    dfull = np.zeros((3, H, W), np.float32)
+    dfull[:, y:y + h, x:x + w] = dwin
+    gref = fr.backward(np.ascontiguousarray(view(dfull)))
+    g = points.grad.cpu().numpy()
+    got = {"dL_dmean3D": g[:, 0:3], "dL_dopacity": g[:, 3:4], "dL_dscale": g[:, 4:7], "dL_drot": g[:, 7:11],
+           "dL_dcolor": g[:, 11:14]}
+    _check_grads(gref, got, list(got))
+
+
 def test_host_camera_option(oracle_mod, cuda_device):
     """GaussianRasterizerWrapper(host_camera=True): the camera is host arithmetic handed to the kernels by value
     (gcr_camera.host_camera).  The matrices agree with the reference recipe's to rounding; the render is bit-exact
