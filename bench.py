@@ -92,8 +92,12 @@ def main():
                     help="--path visibility: empty-space jumps in the traversal (A/B knob; same outputs)")
     ap.add_argument("--train-step", action="store_true",
                     help="C4 training-step harness (fwd + loss + bwd + gradient all-reduce) instead of the frame loop")
-    ap.add_argument("--host-camera", action="store_true",
-                    help="--train-step: GaussianRasterizerWrapper(host_camera=True) (camera matrices by value, opt-in)")
+    ap.add_argument("--inference-loop", action="store_true",
+                    help="the render loop of scripts/inference.py:655-667 through the wrapper: N points [N,14] -> "
+                         "image -> uint8 HWC frame on the host, per orbit pose (frames.InferenceLoop)")
+    ap.add_argument("--host-camera", nargs="?", const="closed-form", default=None, choices=["closed-form", "reference"],
+                    help="--train-step / --inference-loop: GaussianRasterizerWrapper(host_camera=...): camera matrices on "
+                         "the host, by value (closed form, or the reference's recipe with torch on the host)")
     ap.add_argument("--host-threads", type=int, default=1,
                     help="host threads driving the frame loop, one stream each (frames are independent)")
     ap.add_argument("--streams", type=int, default=None,
@@ -179,6 +183,8 @@ def main():
         return visibility_bench(args, torch, dist, synth, dev, world, rank, barrier, copy_ceiling)
     if args.train_step:
         return train_step_bench(args, torch, dist, N, synth, GaussianRasterizerWrapper, dev, world, rank, barrier)
+    if args.inference_loop:
+        return inference_loop_bench(args, torch, dist, synth, GaussianRasterizerWrapper, dev, world, rank, barrier)
 
     def load_scene(cfg_name, points=None, size=None):
         cfg, sc = synth.make_scene(cfg_name, points)
@@ -890,6 +896,67 @@ def visibility_cpu_baseline(L, inv, synth, rows_gpu, dims, mn, pose, rig, vp_gpu
             "gpu_points_bit_exact_vs_cpu": same_pts, "gpu_first_hit_map_bit_exact_vs_cpu": same_vp}
 
 
+def inference_loop_bench(args, torch, dist, synth, Wrapper, dev, world, rank, barrier):
+    """The product's inference loop around the rasterizer (scripts/inference.py:614-669): for every pose of the orbit,
+    points [N,14] -> GaussianRasterizerWrapper -> [3,H,W] -> uint8 [H,W,3] frame in host memory.  N = 518 400 points
+    (one per pixel of a 960x540 view: what the reference's visible-point pipeline feeds it), precomputed colours,
+    identity rotations, opacity 1.  frames.InferenceLoop alternates the frames over three side streams and pinned
+    frame buffers; ranks take frames round-robin (no collective)."""
+    from gaussiancity_amd.frames import InferenceLoop
+    n_pts = args.points or 518400
+    cfg, sc = synth.make_scene("C4", n_pts)
+    W, H = cfg["W"], cfg["H"]
+    wr = Wrapper(synth.intrinsics(W, H), (W, H), device=dev, host_camera={None: False, "closed-form": True, "reference": "reference"}[args.host_camera])
+    rot = np.zeros((n_pts, 4), np.float32)
+    rot[:, 0] = 1.0
+    pts_np = np.concatenate([sc["means3D"], np.ones((n_pts, 1), np.float32), sc["scales"], rot, sc["colors_precomp"]], axis=1)
+    points = torch.from_numpy(pts_np.astype(np.float32)).to(dev)
+    orbit = synth.orbit_poses()
+    loop = InferenceLoop(lambda p, cp, cq: wr(p, cp, cq), device=dev, n_streams=args.streams)
+    sink = [0]
+
+    def consume(i, frame):  # what a video writer would do with the frame: touch it
+        sink[0] += int(frame[0, 0, 0])
+
+    def run(n):
+        poses = [orbit[(rank + i * world) % len(orbit)] for i in range(n)]
+        with torch.no_grad():
+            loop.run(points, poses, consume=consume)
+
+    run(max(args.warmup, 24))
+    block_s = []
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        block_s.append(el)
+        if sum(block_s) >= 0.5 or len(block_s) >= 16:
+            break
+    elapsed = float(np.median(block_s))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "inference-loop frames/sec (points [N,14] -> wrapper -> uint8 frame on the host)",
+            "value": round(args.steps * world / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "repeats": len(block_s), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "value_min": round(args.steps * world / max(block_s), 3), "value_max": round(args.steps * world / min(block_s), 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (gcity-synth-v1 %s, seed %d)" % (cfg["scene"], cfg["seed"]),
+            "config": {"workload": "%d points [N,14] with precomputed colours, %dx%d, 24-pose orbit, uint8 HWC frames "
+                                   "copied to pinned host memory (scripts/inference.py:655-667)" % (n_pts, W, H),
+                       "parallelism": "frames round-robin over ranks; %d HIP streams per GPU" % loop.n,
+                       "camera": args.host_camera or "the reference's recipe on the device"},
+            "frame_bytes_to_host": 3 * W * H}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, barrier):
     """C4: the reference's G-step shape around the rasterizer -- a 69,809,101-parameter generator
     stand-in under torch's DistributedDataParallel (buckets all-reduced over RCCL while the backward runs, core/train.py:
@@ -901,7 +968,7 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
     cfg, sc = synth.make_scene("C4", args.points)
     W, H = cfg["W"], cfg["H"]
     cw, ch = cfg["crop"]
-    wr = Wrapper(synth.intrinsics(W, H), (W, H), device=dev, host_camera=args.host_camera)
+    wr = Wrapper(synth.intrinsics(W, H), (W, H), device=dev, host_camera={None: False, "closed-form": True, "reference": "reference"}[args.host_camera])
     # [N,14] = xyz, opacity, scale3, rot4, rgb3  (dgr/__init__.py:404-409)
     rot = sc["rotations"][:, [1, 2, 3, 0]]
     pts_np = np.concatenate([sc["means3D"], sc["opacities"], sc["scales"], rot, sc["colors_precomp"]], axis=1)
@@ -996,8 +1063,10 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
                                    "not its arithmetic); no optimizer step" % (cfg["P"], W, H, cw, ch, n_param),
                        "parallelism": "torch DistributedDataParallel(find_unused_parameters=True, bucket_cap_mb=64) over "
                                       "RCCL: buckets all-reduced while the backward runs; one frame per rank per step",
-                       "camera": "host arithmetic, passed to the kernels by value (opt-in)" if args.host_camera
-                                 else "the reference's recipe (scipy + device GEMM + inverse), bit-equal"},
+                       "camera": {None: "the reference's recipe on the device (scipy + H2D + GEMM + inverse with a sync)",
+                                  "closed-form": "closed-form host arithmetic, by value (opt-in)",
+                                  "reference": "the reference's recipe with torch on the host, by value (opt-in, "
+                                               "bit-equal to the golden camera)"}[args.host_camera]},
             "allreduce_ms": round(ar_ms, 4) if ar_ms else None, "allreduce_bytes": nbytes,
             "allreduce_messages": n_msg, "allreduce_bus_GBps": round(bus, 1) if bus else None,
             "rccl": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_DEBUG") if os.environ.get(k)} or None,

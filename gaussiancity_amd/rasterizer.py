@@ -192,7 +192,10 @@ class GaussianRasterizerWrapper(torch.nn.Module):
         the 4x4 product is done in float32 on the host), not bit for bit -- the default path stays bit-equal
         (tests/golden/camera.npz)."""
         super().__init__()
-        self.host_camera = bool(host_camera)
+        # False | True ("closed form") | "reference": the reference's own recipe (scipy, matmul, inverse) evaluated
+        # with torch on the HOST -- bit-equal to what the reference computes on a CPU device (tests/golden/camera.npz),
+        # no device work and no synchronisation; about 50 us of host time instead of 12
+        self.host_camera = host_camera if host_camera == "reference" else bool(host_camera)
         self.flip_lr = flip_lr
         self.flip_ud = flip_ud
         self.z_near = z_near
@@ -245,6 +248,8 @@ class GaussianRasterizerWrapper(torch.nn.Module):
         # matrix rounds differently from inverse() of its contiguous copy); what is handed out is .contiguous():
         # same values, but the native module would otherwise copy the 16 floats of a strided matrix on every
         # forward and backward call (a 2-4 us kernel in the frame's dependency chain each time).
+        if self.host_camera == "reference":
+            return self._reference_recipe_on_host(cam_position, cam_quaternion)
         if self.host_camera:
             return self._host_camera_settings(cam_position, cam_quaternion)
         view = self._get_w2c_matrix(cam_position, cam_quaternion).transpose(0, 1)
@@ -263,6 +268,23 @@ class GaussianRasterizerWrapper(torch.nn.Module):
             prefiltered=False,
             debug=False,
         )
+
+    def _reference_recipe_on_host(self, cam_position, cam_quaternion):
+        """dgr/__init__.py:349-402 operation by operation, on CPU tensors (host_camera="reference")."""
+        dev, self.device = self.device, torch.device("cpu")
+        try:
+            view = self._get_w2c_matrix(cam_position, cam_quaternion).transpose(0, 1)
+        finally:
+            self.device = dev
+        if getattr(self, "_P_cpu_t", None) is None:
+            self._P_cpu_t = self.P.detach().cpu().transpose(0, 1)
+            self._bg_host = torch.zeros(3, dtype=torch.float32)
+        return GaussianRasterizationSettings(
+            img_h=self.sensor_size[1], img_w=self.sensor_size[0],
+            tanfovx=math.tan(self.fov_x * 0.5), tanfovy=math.tan(self.fov_y * 0.5),
+            bg=self._bg_host, scale_modifier=1.0, view_matrix=view.contiguous(),
+            proj_matrix=(view @ self._P_cpu_t).contiguous(), sh_degree=0,
+            campos=view.inverse()[3, :3].contiguous(), prefiltered=False, debug=False)
 
     def _host_camera_settings(self, cam_position, cam_quaternion):
         """The same settings from host arithmetic only (opt-in, see __init__).  Rotation from the quaternion

@@ -40,6 +40,29 @@ def recorder(monkeypatch):
     return rec
 
 
+def test_reference_recipe_on_host_is_bit_equal_to_the_golden_camera():
+    """GaussianRasterizerWrapper(host_camera="reference") evaluates the reference's recipe with torch on the host and
+    hands the matrices to the kernels by value: its settings are the golden ones bit for bit (on any `device`), and the
+    closed-form variant (host_camera=True) agrees to rounding."""
+    g = np.load(os.path.join(GOLD, "camera.npz"))
+    for i in range(int(g["n_tuples"])):
+        ss = tuple(int(v) for v in g["sensor_%d" % i])
+        wr = ga.GaussianRasterizerWrapper(g["K_%d" % i], ss, device=CPU, host_camera="reference")
+        pos, q = g["pos_%d" % i], g["quat_%d" % i]
+        rs = wr._get_gaussian_rasterization_settings(pos, q)
+        assert rs.view_matrix.device.type == "cpu"
+        assert np.array_equal(rs.view_matrix.numpy(), g["view_%d" % i])
+        assert np.array_equal(rs.proj_matrix.numpy(), g["proj_%d" % i])
+        assert np.array_equal(rs.campos.numpy(), g["campos_%d" % i])
+        assert np.array_equal(np.array([rs.tanfovx, rs.tanfovy]), g["tanfov_%d" % i])
+        fast = ga.GaussianRasterizerWrapper(g["K_%d" % i], ss, device=CPU, host_camera=True)
+        rf = fast._get_gaussian_rasterization_settings(pos, q)
+        scale = max(1.0, float(np.abs(g["proj_%d" % i]).max()))
+        assert np.abs(rf.view_matrix.numpy() - g["view_%d" % i]).max() <= 2e-6 * scale
+        assert np.abs(rf.proj_matrix.numpy() - g["proj_%d" % i]).max() <= 2e-6 * scale
+        assert np.abs(rf.campos.numpy() - g["campos_%d" % i]).max() <= 1e-6 * max(1.0, float(np.abs(g["campos_%d" % i]).max()))
+
+
 def test_camera_math_matches_reference():
     g = np.load(os.path.join(GOLD, "camera.npz"))
     for i in range(int(g["n_tuples"])):
