@@ -252,8 +252,13 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
     if (__syncthreads_count(!(Tw > 0.0f)) == 256) break;
     // crossing a piece boundary: checkpoint of the per-pixel state for the backward (|Tw| = T; a finished pixel's
     // checkpoint is never read).  256 x 16 bytes, one coalesced 4 KB store per boundary.
-    if (entered > 0u && a.ckpt != nullptr)
-      a.ckpt[(size_t)(sbase + entered - 1u) * 256u + tid] = make_float4(__builtin_fabsf(Tw), C0, C1, C2);
+    if (entered > 0u && a.ckpt != nullptr) {
+      // (the thread index is re-read behind an opaque barrier so that the store's address arithmetic is done here and
+      // does not sit in registers across the walk: 76 -> 71 VGPRs, seven waves per SIMD again)
+      uint32_t t_op = threadIdx.x;
+      asm volatile("" : "+v"(t_op));
+      a.ckpt[(size_t)(sbase + entered - 1u) * 256u + t_op] = make_float4(__builtin_fabsf(Tw), C0, C1, C2);
+    }
     entered++;
     const int n = min(cs, total - base);
     uint32_t my_mask = 0;
@@ -327,7 +332,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
     // the image may be stored mirrored (the wrapper's flip_lr / flip_ud without a copy kernel) and / or as a window of
     // the frame (the helpers' crop without slice kernels); the per-pixel state is neither
     size_t oplane;
-    const long long out_id = gcr_out_index(a, g.pxi, g.pyi, &oplane);
+    int px_op = g.pxi, py_op = g.pyi;  // opaque copies: the index arithmetic below must not be hoisted above the walk
+    asm volatile("" : "+v"(px_op), "+v"(py_op));
+    const long long out_id = gcr_out_index(a, px_op, py_op, &oplane);
     if (out_id >= 0) {
       a.out_color[out_id] = C0 + Tout * GCR_CAM(a, bg, a.bg, 0);
       a.out_color[oplane + out_id] = C1 + Tout * GCR_CAM(a, bg, a.bg, 1);
