@@ -95,9 +95,11 @@ def main():
     ap.add_argument("--inference-loop", action="store_true",
                     help="the render loop of scripts/inference.py:655-667 through the wrapper: N points [N,14] -> "
                          "image -> uint8 HWC frame on the host, per orbit pose (frames.InferenceLoop)")
-    ap.add_argument("--host-camera", nargs="?", const="closed-form", default=None, choices=["closed-form", "reference"],
-                    help="--train-step / --inference-loop: GaussianRasterizerWrapper(host_camera=...): camera matrices on "
-                         "the host, by value (closed form, or the reference's recipe with torch on the host)")
+    ap.add_argument("--host-camera", nargs="?", const="closed-form", default="reference",
+                    choices=["closed-form", "reference", "device"],
+                    help="--train-step / --inference-loop: GaussianRasterizerWrapper(host_camera=...): the reference's "
+                         "recipe with torch on the host and the matrices by value (the wrapper's default), closed-form host "
+                         "arithmetic, or the recipe on the device (H2D copies + GEMM + inverse with a sync)")
     ap.add_argument("--host-threads", type=int, default=1,
                     help="host threads driving the frame loop, one stream each (frames are independent)")
     ap.add_argument("--streams", type=int, default=None,
@@ -906,7 +908,7 @@ def inference_loop_bench(args, torch, dist, synth, Wrapper, dev, world, rank, ba
     n_pts = args.points or 518400
     cfg, sc = synth.make_scene("C4", n_pts)
     W, H = cfg["W"], cfg["H"]
-    wr = Wrapper(synth.intrinsics(W, H), (W, H), device=dev, host_camera={None: False, "closed-form": True, "reference": "reference"}[args.host_camera])
+    wr = Wrapper(synth.intrinsics(W, H), (W, H), device=dev, host_camera={"device": False, "closed-form": True, "reference": "reference"}[args.host_camera])
     rot = np.zeros((n_pts, 4), np.float32)
     rot[:, 0] = 1.0
     pts_np = np.concatenate([sc["means3D"], np.ones((n_pts, 1), np.float32), sc["scales"], rot, sc["colors_precomp"]], axis=1)
@@ -950,7 +952,7 @@ def inference_loop_bench(args, torch, dist, synth, Wrapper, dev, world, rank, ba
             "config": {"workload": "%d points [N,14] with precomputed colours, %dx%d, 24-pose orbit, uint8 HWC frames "
                                    "copied to pinned host memory (scripts/inference.py:655-667)" % (n_pts, W, H),
                        "parallelism": "frames round-robin over ranks; %d HIP streams per GPU" % loop.n,
-                       "camera": args.host_camera or "the reference's recipe on the device"},
+                       "camera": args.host_camera},
             "frame_bytes_to_host": 3 * W * H}), flush=True)
     if world > 1:
         dist.barrier()
@@ -968,7 +970,7 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
     cfg, sc = synth.make_scene("C4", args.points)
     W, H = cfg["W"], cfg["H"]
     cw, ch = cfg["crop"]
-    wr = Wrapper(synth.intrinsics(W, H), (W, H), device=dev, host_camera={None: False, "closed-form": True, "reference": "reference"}[args.host_camera])
+    wr = Wrapper(synth.intrinsics(W, H), (W, H), device=dev, host_camera={"device": False, "closed-form": True, "reference": "reference"}[args.host_camera])
     # [N,14] = xyz, opacity, scale3, rot4, rgb3  (dgr/__init__.py:404-409)
     rot = sc["rotations"][:, [1, 2, 3, 0]]
     pts_np = np.concatenate([sc["means3D"], sc["opacities"], sc["scales"], rot, sc["colors_precomp"]], axis=1)
@@ -1063,10 +1065,10 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
                                    "not its arithmetic); no optimizer step" % (cfg["P"], W, H, cw, ch, n_param),
                        "parallelism": "torch DistributedDataParallel(find_unused_parameters=True, bucket_cap_mb=64) over "
                                       "RCCL: buckets all-reduced while the backward runs; one frame per rank per step",
-                       "camera": {None: "the reference's recipe on the device (scipy + H2D + GEMM + inverse with a sync)",
+                       "camera": {"device": "the reference's recipe on the device (scipy + H2D + GEMM + inverse with a sync)",
                                   "closed-form": "closed-form host arithmetic, by value (opt-in)",
-                                  "reference": "the reference's recipe with torch on the host, by value (opt-in, "
-                                               "bit-equal to the golden camera)"}[args.host_camera]},
+                                  "reference": "the reference's recipe with torch on the host, by value (the wrapper's "
+                                               "default on a GPU: bit-equal to the golden camera)"}[args.host_camera]},
             "allreduce_ms": round(ar_ms, 4) if ar_ms else None, "allreduce_bytes": nbytes,
             "allreduce_messages": n_msg, "allreduce_bus_GBps": round(bus, 1) if bus else None,
             "rccl": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_DEBUG") if os.environ.get(k)} or None,

@@ -184,17 +184,22 @@ class GaussianRasterizerWrapper(torch.nn.Module):
     """
 
     def __init__(self, K, sensor_size, flip_lr=True, flip_ud=False, z_near=0.01, z_far=50000.0,
-                 device=torch.device("cuda"), host_camera=False):
-        """`host_camera` (not in the reference; default off): camera matrices are computed on the host in closed form
-        and handed to the kernels by value -- no scipy, no host-to-device copies, no GEMM, and no
-        `view.inverse()` (rocsolver + a device synchronisation in the reference's recipe).  The matrices then
-        agree with the reference's to rounding (a rigid transform's inverse translation IS the camera position;
-        the 4x4 product is done in float32 on the host), not bit for bit -- the default path stays bit-equal
-        (tests/golden/camera.npz)."""
+                 device=torch.device("cuda"), host_camera=None):
+        """`host_camera` (not in the reference) says where the per-pose camera matrices are computed and live:
+
+        "reference" (default on a GPU device): the reference's own recipe (scipy, matmul, inverse:
+            dgr/__init__.py:349-402) evaluated with torch on the HOST -- bit-equal to what the reference computes
+            on a CPU device (tests/golden/camera.npz); the settings' tensors are CPU tensors and the native side
+            passes the 38 floats to its kernels by value.  No host-to-device copies, no device GEMM, and no
+            `view.inverse()` on the device (rocsolver + a synchronisation that serialises the frame loop: the
+            inference loop runs 2 490 frames/s with it, 4 915 without, profiles/r03_bench_inference_loop.jsonl).
+        True: closed-form host arithmetic (a rigid transform's inverse translation IS the camera position), ~12 us
+            instead of ~50; agrees with the recipe to rounding, not bit for bit.
+        False (default on a CPU device; "device" semantics of the reference): the recipe on `device`, settings'
+            tensors on `device`."""
         super().__init__()
-        # False | True ("closed form") | "reference": the reference's own recipe (scipy, matmul, inverse) evaluated
-        # with torch on the HOST -- bit-equal to what the reference computes on a CPU device (tests/golden/camera.npz),
-        # no device work and no synchronisation; about 50 us of host time instead of 12
+        if host_camera is None:
+            host_camera = "reference" if torch.device(device).type == "cuda" else False
         self.host_camera = host_camera if host_camera == "reference" else bool(host_camera)
         self.flip_lr = flip_lr
         self.flip_ud = flip_ud

@@ -55,7 +55,8 @@ B="python $R/bench.py --train-step --steps 200 --host-camera closed-form"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_c4_kt -o k -- $B > /dev/null 2>&1 < /dev/null
 python $R/tools/rocpd_stats.py /tmp/${TAG}_c4_kt/k_results.db $O/${TAG}_c4_kernel_trace_stats.txt > /dev/null
 (cd $R && timeout 200 python tools/host_profile_c4.py --host-camera > $O/${TAG}_c4_host_profile.txt 2>/dev/null)
-(cd $R && timeout 200 python tools/host_profile_c4.py > $O/${TAG}_c4_host_profile_reference_camera.txt 2>/dev/null)
+(cd $R && timeout 200 python tools/host_profile_c4.py --device-camera > $O/${TAG}_c4_host_profile_device_camera.txt 2>/dev/null)
+python $R/bench.py --train-step --steps 200 --host-camera device > $O/${TAG}_bench_c4_trainstep_device_camera.json 2>/dev/null
 python $R/bench.py --train-step --steps 200 > $O/${TAG}_bench_c4_trainstep.json 2>/dev/null
 python $R/bench.py --train-step --steps 200 --host-camera closed-form > $O/${TAG}_bench_c4_trainstep_host_camera.json 2>/dev/null
 python $R/bench.py --train-step --steps 200 --host-camera reference > $O/${TAG}_bench_c4_trainstep_host_camera_reference.json 2>/dev/null
@@ -78,7 +79,7 @@ python $R/bench.py > $O/${TAG}_bench_c3.json 2>/dev/null
 python $R/bench.py --config C5 --steps 48 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_c5.json 2>/dev/null
 python $R/bench.py --path visibility > $O/${TAG}_bench_visibility.json 2>/dev/null
 python $R/bench.py --path grid-encoder > $O/${TAG}_bench_grid_encoder.json 2>/dev/null
-for hc in "" "--host-camera reference" "--host-camera closed-form"; do   # the product's inference loop through the wrapper
+for hc in "--host-camera device" "--host-camera reference" "--host-camera closed-form"; do   # the product's inference loop through the wrapper
   python $R/bench.py --inference-loop --steps 240 $hc 2>/dev/null
 done > $O/${TAG}_bench_inference_loop.jsonl
 python $R/bench.py --config C2 --backward --no-secondary --steps 200 > $O/${TAG}_bench_c2_fwd_bwd.json 2>/dev/null

@@ -7,14 +7,15 @@ import numpy as np, torch
 from gaussiancity_amd import helpers, synth
 from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper
 ap = argparse.ArgumentParser()
-ap.add_argument("--host-camera", action="store_true")
+ap.add_argument("--host-camera", action="store_true", help="closed-form host camera")
+ap.add_argument("--device-camera", action="store_true", help="the reference recipe on the device")
 ap.add_argument("--iters", type=int, default=400)
 ap.add_argument("--top", type=int, default=32)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg, sc = synth.make_scene("C4")
 W, H = cfg["W"], cfg["H"]; cw, ch = cfg["crop"]
-wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), device=dev, host_camera=args.host_camera)
+wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), device=dev, host_camera=True if args.host_camera else (False if args.device_camera else None))
 rot = sc["rotations"][:, [1, 2, 3, 0]]
 pts = np.concatenate([sc["means3D"], sc["opacities"], sc["scales"], rot, sc["colors_precomp"]], axis=1).astype(np.float32)
 leaf = torch.from_numpy(pts).to(dev).requires_grad_(True)
