@@ -68,7 +68,8 @@ class Layout(C.Structure):
         ("geom_vis_list", C.c_size_t), ("geom_vis_count", C.c_size_t),
         ("geom_num_rendered", C.c_size_t), ("geom_block_tiles", C.c_size_t), ("geom_total", C.c_size_t),
         ("img_final_T", C.c_size_t), ("img_n_contrib", C.c_size_t), ("img_ranges", C.c_size_t),
-        ("img_tile_cursor", C.c_size_t), ("img_tile_table", C.c_size_t), ("img_total", C.c_size_t),
+        ("img_tile_cursor", C.c_size_t), ("img_tile_table", C.c_size_t), ("img_tile_lazy", C.c_size_t),
+        ("img_total", C.c_size_t),
         ("bin_keys", C.c_size_t * 2), ("bin_vals", C.c_size_t * 2), ("bin_hist", C.c_size_t),
         ("bin_sorted", C.c_size_t), ("bin_work", C.c_size_t), ("bin_mask", C.c_size_t), ("bin_ckpt", C.c_size_t),
         ("bin_total", C.c_size_t),
@@ -165,6 +166,14 @@ def get_layout(P, W, H, R):
 
 def set_option(name, value):
     return lib().gcr_set_option(name.encode(), int(value))
+
+
+def get_option(name):
+    """Current value of a gcr_set_option() option (read by setting it to 0 and restoring: for tests and tools, not
+    for code that races with other threads)."""
+    prev = set_option(name, 0)
+    set_option(name, prev)
+    return prev
 
 
 def stage_ms():

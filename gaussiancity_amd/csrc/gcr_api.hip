@@ -15,6 +15,7 @@ std::atomic<int> g_fast_exp{0};
 std::atomic<int> g_timing{0};
 std::atomic<int> g_force_radix{0};
 std::atomic<int> g_force_global_cursor{0};
+std::atomic<int> g_lazy_sort{1};         // 1: long tile lists are sorted segment by segment, as far as the blend walks (gcr_sort.h)
 std::atomic<int> g_sort_in_blend{0};     // 1: the forward blend sorts short tile lists itself (lower frame latency, lower throughput)
 std::atomic<int> g_split_preprocess{0};  // 1: K1 as two kernels (streaming cull, then exact pass) instead of the fused one
 std::atomic<int> g_deterministic{0};  // 1: fixed-point gradient records (order-independent sums), gcr_internal.h
@@ -143,6 +144,7 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
     const int ng = gcr_tile_table_groups((int)T, GCR_K1_MAX_BLOCKS, &G);  // upper bound on groups
     L->img_tile_table = o;   o = align_up(o + (size_t)ng * T * sizeof(uint32_t));
   }
+  L->img_tile_lazy = o;    o = align_up(o + T * 4 * sizeof(uint32_t));
   L->img_total = o;
 
   const size_t r = (size_t)(R > 0 ? R : 0);
@@ -242,6 +244,7 @@ int gcr_set_option(const char* name, int value) {
 #endif
   if (!strcmp(name, "split_preprocess")) return g_split_preprocess.exchange(value);
   if (!strcmp(name, "sort_in_blend")) return g_sort_in_blend.exchange(value);
+  if (!strcmp(name, "lazy_sort")) return g_lazy_sort.exchange(value != 0);
   if (!strcmp(name, "deterministic_backward")) return g_deterministic.exchange(value != 0);
   if (!strcmp(name, "bwd_piece")) {
     const int v = value < GCR_PIECE_MIN ? GCR_PIECE_MIN : (value > GCR_PIECE_MAX ? GCR_PIECE_MAX : value);
@@ -423,11 +426,12 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   // VALU-bound blend grows by 14 us, while the separate latency-bound sort kernel hides behind the other frame's
   // work) -- so it is off by default.
   const bool sort_in_blend = R_layout > 0 && list_length_hint <= GCR_SORT_IN_BLEND_MAX && g_sort_in_blend.load() != 0;
+  uint4* lazy = (R_layout > 0 && !sort_in_blend && g_lazy_sort.load() != 0) ? (uint4*)(ib + L.img_tile_lazy) : nullptr;
   if (R_layout > 0 && !sort_in_blend) {
     StageTimer t(s, ST_SORT);
     // LDS of the sort sized for 1.5x the expected longest list (longer ones take its run + merge path)
     HIP_TRY(gcr_launch_tile_sort(ranges, T, pairs, (uint64_t*)(bb + L.bin_keys[1]), list,
-                                 list_length_hint + list_length_hint / 2 + 64, frame_guard, s),
+                                 list_length_hint + list_length_hint / 2 + 64, frame_guard, lazy, s),
             "tile sort");
   }
   if (int rc = debug_sync(cam, s, "tile sort")) return rc;
@@ -447,6 +451,7 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   b.frame = frame_guard;
   b.pairs = pairs;
   b.list_out = list;
+  b.lazy = lazy;
   set_piece_args(b, cam, L, R_layout > 0 ? binning : nullptr, geom);
 #ifdef GCR_EXPERIMENTS
   b.debug_flags = g_k6_debug.load();

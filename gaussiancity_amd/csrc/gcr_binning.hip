@@ -2,6 +2,7 @@
 // Integer / byte work, HBM-bound; no MFMA.  wave64 ballots do the intra-wave digit matching.
 #include "gcr_device.h"
 #include "gcr_internal.h"
+#include "gcr_sort.h"
 
 namespace {
 
@@ -301,148 +302,28 @@ __global__ __launch_bounds__(256) void k_scatter_instances(int chunk, const uint
 // One workgroup per tile sorts the tile's n <= capacity keys in LDS and writes the Gaussian
 // indices (low 32 bits) to the sorted list: chunked rank sort + merge for n <= RANK_MERGE_MAX, bitonic network (padded to a
 // power of two with ~0) above.
-// In-LDS bitonic network over s[0, N2) (N2 a power of two >= 2, keys padded with ~0), 256 threads.
-// Wave w owns the contiguous span [w*N2/4, (w+1)*N2/4): a stage whose pairs (a, a|j) stay inside a span
-// (2j <= span) only needs the wave's own LDS ordering, so block barriers are paid only for the few
-// long-stride stages (3 of 55 for N2 = 1024).  Ends with a block barrier.
-GCR_DEV void gcr_bitonic_sort_lds(uint64_t* s, int N2, int tid) {
-  const int half = N2 >> 1, wave_pairs = half >> 2;  // pairs per wave and stage
-  const int lane = tid & 63, w = tid >> 6;
-  const int span = N2 >> 2;
-  bool prev_local = false;
-  for (int k = 2; k <= N2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const bool local = 2 * j <= span;
-      if (!local && prev_local) __syncthreads();  // other waves' spans are about to be read
-      for (int t = lane; t < wave_pairs; t += 64) {
-        const int i = w * wave_pairs + t;
-        const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-        const int b = a | j;
-        const uint64_t x = s[a], y = s[b];
-        const bool ascending = (a & k) == 0;
-        if ((x > y) == ascending) {
-          s[a] = y;
-          s[b] = x;
-        }
-      }
-      if (local)
-        __builtin_amdgcn_wave_barrier();
-      else
-        __syncthreads();
-      prev_local = local;
-    }
-  }
-  __syncthreads();
-}
-
-// A tile list LONGER than the LDS this launch was given (dense general 3DGS scenes beyond the 4096-key maximum;
-// or simply a list that outgrew the caller's length hint -- GaussianCity's own scenes have ~150 entries per
-// tile): the same workgroup sorts it in three steps, everything else of the frame is untouched.
-//   1. runs of `run` keys (= the LDS capacity of the launch, a power of two) are sorted in LDS with the bitonic
-//      network and written back in place;
-//   2. log2(#runs) merge passes ping-pong between the key buffer and its spare half: every thread produces
-//      a contiguous slice of each merged pair, located with a merge-path binary search (keys are unique);
-//   3. the Gaussian indices (low 32 bits) go to the sorted list.
-// Round 1 sent the WHOLE frame to the global radix sort when one list was long (cr/rasterizer_impl.cu:252-260 sorts
-// everything globally; the order produced is the same).
-GCR_DEV void gcr_tile_sort_long(uint64_t* s, uint32_t run0, uint64_t* __restrict__ A, uint64_t* __restrict__ B,
-                                uint32_t* __restrict__ out, uint32_t n, int tid) {
-  // 1. sorted runs
-  for (uint32_t c0 = 0; c0 < n; c0 += run0) {
-    const uint32_t len = min(run0, n - c0);
-    for (uint32_t i = tid; i < run0; i += 256) s[i] = i < len ? A[c0 + i] : ~0ull;
-    __syncthreads();
-    gcr_bitonic_sort_lds(s, (int)run0, tid);
-    for (uint32_t i = tid; i < len; i += 256) A[c0 + i] = s[i];
-    __syncthreads();
-  }
-  // 2. merge passes.  Every pair of runs (a, b) is merged window by window: a window = `run0` consecutive OUTPUT
-  //    keys; merge-path binary searches (one thread per window boundary, all boundaries of the pair at once) say
-  //    which slices of a and b produce it; the two slices (run0 keys together) are loaded into LDS with coalesced
-  //    reads, every key finds its output position as (own index + lower bound in the other slice) by a binary
-  //    search in LDS, and is stored into the window.  Only the boundary searches chase pointers through global
-  //    memory (the first version merged element by element from global loads: dense scene D1 1.39 -> 1.27 ms; what
-  //    remains is the 78-stage bitonic network of the 4096-key runs, LDS-bandwidth-bound with five tiles per CU --
-  //    an LDS radix sort of the runs was measured too: no faster (8 ballots + selects per key and pass), dropped).
-  uint64_t* src = A;
-  uint64_t* dst = B;
-  __shared__ uint32_t win_ia[258];  // a-index of every window boundary of the current pair, 256 windows at a time
-  for (uint32_t run = run0; run < n; run <<= 1) {
-    for (uint32_t p0 = 0; p0 < n; p0 += 2 * run) {
-      const uint32_t la = min(run, n - p0);
-      const uint32_t lb = p0 + run < n ? min(run, n - p0 - run) : 0u;
-      const uint64_t* __restrict__ a = src + p0;
-      const uint64_t* __restrict__ b = src + p0 + run;
-      uint64_t* __restrict__ o = dst + p0;
-      const uint32_t tot = la + lb;
-      if (lb == 0u) {  // an unpaired run at the end: copy
-        for (uint32_t i = tid; i < la; i += 256) o[i] = a[i];
-        continue;
-      }
-      const uint32_t nwin = (tot + run0 - 1) / run0;
-      for (uint32_t w0 = 0; w0 < nwin; w0 += 256) {
-        const uint32_t wn = min(256u, nwin - w0);
-        __syncthreads();  // win_ia / s free again
-        for (uint32_t q = tid; q <= wn; q += 256) {
-          // boundary d = first output index of window w0+q (or `tot`): i keys of a and d-i of b precede it, with
-          // i the smallest index such that a[i] > b[d-1-i] (unique keys: no ties)
-          const uint32_t d = min(tot, (w0 + q) * run0);
-          uint32_t lo = d > lb ? d - lb : 0u, hi = min(d, la);
-          while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (a[mid] < b[d - 1 - mid])
-              lo = mid + 1;
-            else
-              hi = mid;
-          }
-          win_ia[q] = lo;
-        }
-        __syncthreads();
-        for (uint32_t w = 0; w < wn; w++) {
-          const uint32_t d0 = (w0 + w) * run0, d1 = min(tot, d0 + run0);
-          const uint32_t ia0 = win_ia[w], ia1 = win_ia[w + 1];
-          const uint32_t ib0 = d0 - ia0, ib1 = d1 - ia1;
-          const uint32_t na = ia1 - ia0, nb = ib1 - ib0;  // na + nb = d1 - d0 <= run0
-          for (uint32_t i = tid; i < na; i += 256) s[i] = a[ia0 + i];
-          for (uint32_t i = tid; i < nb; i += 256) s[na + i] = b[ib0 + i];
-          __syncthreads();
-          for (uint32_t i = tid; i < na + nb; i += 256) {
-            const uint64_t key = s[i];
-            const bool from_a = i < na;
-            const uint64_t* other = from_a ? s + na : s;
-            uint32_t lo = 0, hi = from_a ? nb : na;  // lower bound of key in the other slice
-            while (lo < hi) {
-              const uint32_t mid = (lo + hi) >> 1;
-              if (other[mid] < key)
-                lo = mid + 1;
-              else
-                hi = mid;
-            }
-            o[d0 + (from_a ? i : i - na) + lo] = key;
-          }
-          __syncthreads();
-        }
-      }
-    }
-    __syncthreads();  // the pass is complete (workgroup-scope visibility of the global stores) before it is read
-    uint64_t* t = src;
-    src = dst;
-    dst = t;
-  }
-  // 3. Gaussian indices
-  for (uint32_t i = tid; i < n; i += 256) out[i] = (uint32_t)src[i];
-}
-
 __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ ranges,
                                                    uint64_t* __restrict__ pairs, uint64_t* __restrict__ pairs_spare,
                                                    uint32_t* __restrict__ list,
-                                                   const unsigned long long* __restrict__ frame, int lds_capacity) {
+                                                   const unsigned long long* __restrict__ frame, int lds_capacity,
+                                                   uint4* __restrict__ lazy) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
   uint64_t* s = reinterpret_cast<uint64_t*>(gcr_smem);
   if (frame != nullptr && frame[2] == 0ull) return;  // speculative launch vetoed
   const int tid = threadIdx.x;
   const uint32_t r0 = ranges[2 * blockIdx.x], r1 = ranges[2 * blockIdx.x + 1];
   const int n = (int)(r1 - r0);
+  if (lazy != nullptr) {
+    // gcr_sort.h "lazy tile sort": a long list gets its first segment here, the forward blend sorts on as far as it walks
+    if (n > GCR_LAZY_MIN) {
+      uint32_t n_sorted = 0;
+      uint64_t L = 0;
+      gcr_lazy_extend(s, pairs + r0, (uint32_t)n, n_sorted, L, list + r0, tid);
+      if (tid == 0) lazy[blockIdx.x] = make_uint4(n_sorted, 0u, (uint32_t)L, (uint32_t)(L >> 32));
+      return;
+    }
+    if (tid == 0) lazy[blockIdx.x] = make_uint4((uint32_t)max(n, 0), 0u, ~0u, ~0u);  // sorted whole below
+  }
   if (n <= 0) return;
   if (n > lds_capacity) {  // longer than the LDS of this launch (a power of two >= 64): sorted runs + merge passes
     gcr_tile_sort_long(s, (uint32_t)lds_capacity, pairs + r0, pairs_spare + r0, list + r0, (uint32_t)n, tid);
@@ -790,16 +671,21 @@ int gcr_tile_sort_capacity(void) { return 4096; }  // 32 KiB of LDS per workgrou
 // `list_length_hint`: the longest list the caller expects.  It only sizes the LDS of the launch (a power of two
 // between 64 and the capacity): lists within it take the in-LDS paths, longer ones the run + merge path through
 // the spare key buffer `pairs_spare` (same size as `pairs`) -- any length is sorted correctly.
+//
+// `lazy` ([T] uint4 states, or null = sort everything): lists longer than GCR_LAZY_MIN only get their first segment
+// (gcr_sort.h); the LDS of the launch is then at most 16 KiB instead of 32.
 hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, uint64_t* pairs, uint64_t* pairs_spare,
                                 uint32_t* list, int64_t list_length_hint, const unsigned long long* frame,
-                                hipStream_t s) {
+                                uint4* lazy, hipStream_t s) {
   if (T <= 0) return hipSuccess;
-  const int cap = gcr_tile_sort_capacity();
+  static_assert(GCR_LAZY_MIN == RANK_MERGE_MAX, "lists the lazy path leaves to this kernel take the rank + merge path");
+  const int cap = lazy != nullptr ? GCR_LAZY_MIN : gcr_tile_sort_capacity();
   size_t n2 = 64;
   while ((int64_t)n2 < list_length_hint && n2 < (size_t)cap) n2 <<= 1;
   // bitonic path: n2 keys; rank/merge path (<= RANK_MERGE_MAX keys): two buffers of n rounded up to 64
-  const size_t lds = n2 <= (size_t)RANK_MERGE_MAX ? 2 * n2 * sizeof(uint64_t) : n2 * sizeof(uint64_t);
-  k_tile_sort<<<T, 256, lds, s>>>(ranges, pairs, pairs_spare, list, frame, (int)n2);
+  size_t lds = n2 <= (size_t)RANK_MERGE_MAX ? 2 * n2 * sizeof(uint64_t) : n2 * sizeof(uint64_t);
+  if (lazy != nullptr && lds < GCR_LAZY_LDS_KEYS * sizeof(uint64_t)) lds = GCR_LAZY_LDS_KEYS * sizeof(uint64_t);
+  k_tile_sort<<<T, 256, lds, s>>>(ranges, pairs, pairs_spare, list, frame, (int)n2, lazy);
   return hipGetLastError();
 }
 

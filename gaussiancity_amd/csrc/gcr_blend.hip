@@ -26,6 +26,7 @@
 #include "gcr_cull.h"
 #include "gcr_device.h"
 #include "gcr_internal.h"
+#include "gcr_sort.h"
 
 namespace {
 
@@ -137,8 +138,31 @@ GCR_DEV uint32_t slot_of_offset(uint32_t off) { return (off * 1366u) >> 16; }
 #define GCR_K6_STEP_ON true
 #define GCR_K6_LOOP_ON true
 #endif
+// K6's call of gcr_lazy_extend(): a real call, so that the rare sort takes no part in the register allocation of the
+// blend loop.  The tile's state comes from and goes back to its uint4 in global memory (no pointers to locals: no stack);
+// it is read and written with device-scope atomics, because a second call of the same workgroup must see what the
+// first one stored, whatever the vector L1 still holds.  Returns the new n_sorted (the same value in every lane).
+__device__ __noinline__ uint32_t k6_lazy_extend(uint64_t* s, const uint64_t* keys, uint32_t n, uint32_t* out, uint4* state) {
+  const int tid = threadIdx.x;
+  uint32_t* w = reinterpret_cast<uint32_t*>(state);
+  uint32_t ns = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint64_t l = (uint64_t)__hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+               ((uint64_t)__hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
+  gcr_lazy_extend(s, keys, n, ns, l, out, tid);
+  if (tid == 0) {
+    __hip_atomic_store(w, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 2, (uint32_t)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 3, (uint32_t)(l >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return ns;
+}
+
+// amdgpu_waves_per_eu(7, 8): the call above constrains the register assignment (what lives across it must sit in
+// callee-saved registers) and the allocator, left alone, ends at 78 VGPRs = six waves per SIMD; told to fit seven, it
+// finds a 71-register assignment without a spill and with the blend steps unchanged instruction for instruction.
 template <bool FAST_EXP, bool SORT>
-__global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_blend_fwd(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[CHUNK + 1];
   __shared__ uint32_t sMask[CHUNK];
   __shared__ uint16_t sList[4][4][LIST_STRIDE];  // [wave][row]: byte offsets into sE, list order
@@ -147,10 +171,6 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   const int tile = blockIdx.x;
   const int tx = tile % a.gx, ty = tile / a.gx;
   const int tid = threadIdx.x;
-  const LaneGeom g = lane_geom(tid, tx, ty);
-  const int lane = g.lane, w = g.w;
-  const bool inside = g.pxi < a.W && g.pyi < a.H;
-  const float pixx = (float)g.pxi, pixy = (float)g.pyi;
   const float tile_x0 = (float)(tx * GCR_TILE_X), tile_y0 = (float)(ty * GCR_TILE_Y);
   const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
   if (!gcr_tile_in_window(a, tx, ty)) {
@@ -168,7 +188,6 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
     return;
   }
   const int total = (int)(r1 - r0);
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
   const char* const sEb = reinterpret_cast<const char*>(sE);
   if (tid == 0) {
     sE[CHUNK].a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -176,7 +195,11 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
     sE[CHUNK].c = make_float4(0.0f, __builtin_inff(), 0.0f, 0.0f);
   }
 
-  float Tw = inside ? 1.0f : -1.0f;
+  float Tw;
+  {
+    const LaneGeom g0 = lane_geom(tid, tx, ty);
+    Tw = (g0.pxi < a.W && g0.pyi < a.H) ? 1.0f : -1.0f;
+  }
   float C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
   uint32_t last_contributor = 0;
   // pieces (gcr_internal.h "backward pieces"): the list is walked in equal pieces of <= a.piece entries
@@ -184,6 +207,10 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   const int cs = (int)gcr_piece_size((uint32_t)total, piece_P);
   const uint32_t sbase = r0 / piece_P + (uint32_t)tile;
   uint32_t entered = 0;  // pieces this workgroup walked into (block-uniform)
+
+  // lazily sorted list (gcr_sort.h): list[r0, r0 + lz_sorted) is in final order; the walk sorts on when it gets there
+  uint32_t lz_sorted = (uint32_t)max(total, 0);
+  if (!SORT && a.lazy != nullptr) lz_sorted = a.lazy[tile].x;
 
   uint32_t sorted_id = 0;  // SORT, total <= CHUNK: the Gaussian of list position `tid`
   if (SORT && total > 0) {
@@ -247,9 +274,36 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
   QB = *reinterpret_cast<const float4*>(sEb + (OFF) + 16);         \
   QC = *reinterpret_cast<const float2*>(sEb + (OFF) + 32);
 
-  for (int base = 0; base < total && GCR_K6_LOOP_ON; base += cs) {
+  // The walk.  OUTER loop: one trip per sorted segment of the list (gcr_sort.h "lazy tile sort": exactly one trip unless
+  // the tile's list is longer than 1024 entries AND the pixels are still alive where the sorted part ends).  The
+  // lane geometry is derived behind an opaque barrier INSIDE it, so that nothing but the per-pixel state (Tw, C,
+  // last_contributor) is live in registers while the rare sort runs: with the geometry computed once above the loop the
+  // sort's registers came on top of everything the blend loop keeps (70 -> 86 VGPRs, five waves per SIMD instead of seven).
+  // The sort itself is a real call (k6_lazy_extend) for the same reason.
+  int base = 0;
+  bool finished = false;  // block-uniform
+  while (base < total && !finished && GCR_K6_LOOP_ON) {
+  if (!SORT) {
+    const uint32_t need = (uint32_t)(base + min(cs, total - base));
+    while (lz_sorted < need) {  // sE is not live here
+      const uint32_t ns = k6_lazy_extend(reinterpret_cast<uint64_t*>(sE), a.pairs + r0, (uint32_t)total,
+                                         const_cast<uint32_t*>(a.list) + r0, a.lazy + tile);
+      lz_sorted = (uint32_t)__builtin_amdgcn_readfirstlane((int)ns);
+    }
+  }
+  int tid_op = threadIdx.x;
+  asm volatile("" : "+v"(tid_op));
+  const LaneGeom g = lane_geom(tid_op, tx, ty);
+  const int lane = g.lane, w = g.w;
+  const float pixx = (float)g.pxi, pixy = (float)g.pyi;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (; base < total; base += cs) {
     // block-wide vote (cr/forward.cu:284-286); also fences the previous chunk's LDS reads
-    if (__syncthreads_count(!(Tw > 0.0f)) == 256) break;
+    if (__syncthreads_count(!(Tw > 0.0f)) == 256) {
+      finished = true;
+      break;
+    }
+    if (!SORT && lz_sorted < (uint32_t)(base + min(cs, total - base))) break;  // sort on, then come back
     // crossing a piece boundary: checkpoint of the per-pixel state for the backward (|Tw| = T; a finished pixel's
     // checkpoint is never read).  256 x 16 bytes, one coalesced 4 KB store per boundary.
     if (entered > 0u && a.ckpt != nullptr) {
@@ -322,9 +376,13 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const GcrBlendArgs a) {
     }
     if (last_off != NO_ENTRY) last_contributor = (uint32_t)base + slot_of_offset(last_off) + 1u;
   }
+  }
 #undef GCR_BLEND_STEP
 #undef GCR_BLEND_LOAD
-  if (inside) {
+  int tid_end = threadIdx.x;
+  asm volatile("" : "+v"(tid_end));
+  const LaneGeom g = lane_geom(tid_end, tx, ty);
+  if (g.pxi < a.W && g.pyi < a.H) {
     const float Tout = __builtin_fabsf(Tw);
     const size_t pix_id = (size_t)a.W * g.pyi + g.pxi;
     a.final_T[pix_id] = Tout;

@@ -171,6 +171,7 @@ struct GcrBlendArgs {
   unsigned long long ckpt_off, work_off;  // fwd: what it publishes (byte offsets in the binning buffer)
   const char* binning_base;        // bwd: checkpoints / work list are found through the frame words
   const unsigned long long* frame_in;  // bwd
+  uint4* lazy;                     // fwd: [T] lazy-sort states (gcr_sort.h) of lists the blend may have to sort on, or null
   unsigned long long R;            // bwd: num_rendered (with `piece`: bounds the number of work items for the grid)
 #ifdef GCR_EXPERIMENTS
   unsigned long long* clock_buf;   // bwd: [grid][4 waves][10] phase clocks (gcr_debug_set_clock_buffer), or null
@@ -218,7 +219,7 @@ hipError_t gcr_launch_scatter_instances(int nblocks, int chunk, const uint32_t* 
 int gcr_tile_sort_capacity(void);  // longest per-tile list the LDS sort accepts
 hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, uint64_t* pairs, uint64_t* pairs_spare,
                                 uint32_t* list, int64_t list_length_hint, const unsigned long long* frame,
-                                hipStream_t s);
+                                uint4* lazy, hipStream_t s);
 // Stable LSD radix sort of R (u64 key, u32 value) pairs on bits [0, end_bit).  Ping-pongs
 // between (k0,v0) and (k1,v1); returns in *sorted_half which half holds the result.
 size_t gcr_sort_hist_bytes(int64_t R, int end_bit);

@@ -155,6 +155,8 @@ typedef struct gcr_layout {
   size_t img_tile_cursor; /* one uint32 per tile, 128 B apart: instance count (after K1), then
                              scatter write cursor */
   size_t img_tile_table;  /* uint32 [groups][T]: per-group tile counts, then exclusive prefixes */
+  size_t img_tile_lazy;   /* uint32[4] per tile {n_sorted, 0, L lo, L hi}: the first n_sorted entries of the tile's
+                             list are in final order, every key >= L is not among them (option "lazy_sort") */
   size_t img_total;
   /* binning buffer (per instance) */
   size_t bin_keys[2]; /* uint64 per instance, ping/pong */
@@ -265,6 +267,10 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *                     gcr_grad_record_floats() then returns 32: size gcr_grads.dL_dconic AFTER setting the option.
  *   "bwd_piece"    entries per backward piece (64..256) of frames rendered with             default 128
  *                     gcr_camera.backward != 0 (include/gcr.h; gcr_internal.h "backward pieces")
+ *   "lazy_sort"    1: tile lists longer than 1024 entries are sorted segment by segment, only as far   default 1
+ *                     as the forward blend walks them (saturating scenes never read most of a long list); the entries
+ *                     behind the last one consumed stay unsorted (gcr_layout.img_tile_lazy says how far the order is
+ *                     final).  0: every list is sorted whole, as the reference does.
  *   "timing"       1: record per-stage HIP events (see gcr_get_stage_ms)             default 0
  * Returns the previous value or <0 if the name is unknown. */
 int gcr_set_option(const char *name, int value);

@@ -64,4 +64,40 @@ def decode(P, W, H, out):
     if R > 0:
         s = L.bin_sorted
         d["point_list"] = bb[L.bin_vals[s]:L.bin_vals[s] + 4 * R].view(np.uint32)
+        if lazy_sort_active():
+            # option "lazy_sort": {n_sorted, 0, L lo, L hi} per tile -- how far each tile's list is in final order
+            d["tile_sorted"] = ib[L.img_tile_lazy:L.img_tile_lazy + 16 * T].view(np.uint32).reshape(T, 4)[:, 0].copy()
     return d
+
+
+def lazy_sort_active():
+    """The tile sort of the default binning path writes the lazy-sort states (not the global radix path, nor the
+    blend's own sort of short lists)."""
+    return bool(N.get_option("lazy_sort")) and not N.get_option("force_radix") and not N.get_option("sort_in_blend")
+
+
+def assert_point_list(d, fr):
+    """The sorted instance list against the oracle's.  Under option "lazy_sort" a tile's list is final only as far as
+    `tile_sorted` says: that prefix must be the oracle's, cover everything the tile's pixels consumed, and be the whole
+    list for tiles of up to 1024 entries."""
+    ref = fr.point_list[:fr.R]
+    got = d["point_list"]
+    ns = d.get("tile_sorted")
+    if ns is None:
+        np.testing.assert_array_equal(got, ref)
+        return
+    r0 = fr.ranges[:, 0].astype(np.int64)
+    n = fr.ranges[:, 1].astype(np.int64) - r0
+    ns = ns.astype(np.int64)
+    assert (ns <= n).all() and (ns[n <= 1024] == n[n <= 1024]).all() and (ns[n > 1024] >= 1).all()
+    gx = (fr.W + 15) // 16
+    H16, W16 = ((fr.H + 15) // 16) * 16, gx * 16
+    nc = np.zeros((H16, W16), np.int64)
+    nc[:fr.H, :fr.W] = fr.n_contrib.reshape(fr.H, fr.W)
+    consumed = nc.reshape(H16 // 16, 16, gx, 16).max(axis=(1, 3)).reshape(-1)
+    assert (ns >= consumed).all(), "a tile consumed entries behind its sorted prefix"
+    # one flat comparison of all the final prefixes
+    pos = np.arange(fr.R, dtype=np.int64)
+    tile_of = np.repeat(np.arange(len(n)), n)
+    final = pos - r0[tile_of] < ns[tile_of]
+    np.testing.assert_array_equal(got[final], ref[final])

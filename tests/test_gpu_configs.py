@@ -313,7 +313,10 @@ def test_c5_20m_4k_forward_vs_oracle_and_list_properties(oracle_mod, cuda_device
     L = G.N.get_layout(P, W, H, R)
     T = ((W + 15) // 16) * ((H + 15) // 16)
     plist = binning[L.bin_vals[L.bin_sorted]:L.bin_vals[L.bin_sorted] + 4 * R].view(torch.int32).cpu().numpy().view(np.uint32)
-    np.testing.assert_array_equal(plist, fr.point_list[:R])
+    d = {"point_list": plist}
+    if G.lazy_sort_active():   # lists beyond 1024 entries are final only as far as the blend walked them
+        d["tile_sorted"] = img[L.img_tile_lazy:L.img_tile_lazy + 16 * T].view(torch.int32).view(T, 4)[:, 0].cpu().numpy().view(np.uint32)
+    G.assert_point_list(d, fr)
     ranges = img[L.img_ranges:L.img_ranges + 8 * T].view(torch.int32).view(T, 2).cpu().numpy().view(np.uint32)
     np.testing.assert_array_equal(ranges, fr.ranges)
     # idempotence at this size (second run takes the speculative path)
@@ -419,6 +422,19 @@ def test_dense_3dgs_like_scene_long_lists(oracle_mod, cuda_device):
     assert lens.mean() > 2000 and (lens > 4096).sum() >= 3 and fr.consumed_entries() < 0.8 * fr.R
     for _ in range(2):   # staged, then speculative with the long-list hint
         args, out = G.run_forward(rs, sc, cuda_device)
-        _check_forward(fr, G.decode(P, W, H, out), P, True)
+        d = G.decode(P, W, H, out)
+        _check_forward(fr, d, P, True)
+    # option "lazy_sort" (default): this is the scene it is for -- most of what was emitted is never sorted, and some
+    # tiles were sorted on by the blend behind their first segment
+    ns = d["tile_sorted"].astype(np.int64)
+    assert ns[lens > 1024].sum() < 0.6 * lens[lens > 1024].sum() and (ns > 1024).any()
     dpix = synth.grad_image(W, H, 7)
     _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device), ALL_GRADS)
+    # ... and sorting every list whole gives the same image and the same per-pixel state
+    prev = G.N.set_option("lazy_sort", 0)
+    try:
+        _, out_full = G.run_forward(rs, sc, cuda_device)
+        _check_forward(fr, G.decode(P, W, H, out_full), P, True)
+    finally:
+        G.N.set_option("lazy_sort", prev)
+    assert torch.equal(out_full[1].view(torch.int32), out[1].view(torch.int32))

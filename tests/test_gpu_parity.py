@@ -45,7 +45,7 @@ def _check_forward(fr, d, P, use_sh, has_cov3d_state=True):
     if has_cov3d_state:
         assert np.array_equal(d["cov3D"][vis].view(np.uint32), fr.cov3D[:P][vis].view(np.uint32))
     if fr.R > 0:
-        np.testing.assert_array_equal(d["point_list"], fr.point_list[:fr.R])
+        G.assert_point_list(d, fr)
     np.testing.assert_array_equal(d["ranges"], fr.ranges)
     np.testing.assert_array_equal(d["n_contrib"], fr.n_contrib)
     assert np.array_equal(d["final_T"].view(np.uint32), fr.final_T.view(np.uint32)), "final_T not bit-exact"
@@ -143,7 +143,7 @@ def test_fast_exp_mode_within_tolerance(oracle_mod, cuda_device, name, P, W, H, 
         N.set_option("fast_exp", prev)
     assert d["R"] == fr.R
     np.testing.assert_array_equal(d["radii"], fr.radii)
-    np.testing.assert_array_equal(d["point_list"], fr.point_list[:fr.R])
+    G.assert_point_list(d, fr)
     tol = GRAD_TOL * max(1.0, float(np.abs(fr.out_color).max()))
     off = np.abs(d["out_color"] - fr.out_color).max(axis=0) > tol
     flips = int(off.sum()) + int((d["n_contrib"] != fr.n_contrib).sum())
@@ -250,7 +250,7 @@ def test_sort_is_stable_on_depth_ties(oracle_mod, cuda_device):
     args, out = G.run_forward(rs, sc, cuda_device, use_sh=False)
     d = G.decode(P, W, H, out)
     assert fr.R > 1000
-    np.testing.assert_array_equal(d["point_list"], fr.point_list[:fr.R])
+    G.assert_point_list(d, fr)
     assert np.array_equal(d["out_color"].view(np.uint32), fr.out_color.view(np.uint32))
 
 
@@ -268,10 +268,11 @@ def test_both_binning_paths(oracle_mod, cuda_device, force_radix, force_cursor):
     N.set_option("force_global_cursor", force_cursor)
     try:
         args, out = G.run_forward(rs, sc, cuda_device)
+        d = G.decode(P, W, H, out)   # (while the options still say which path wrote the state)
     finally:
         N.set_option("force_radix", 0)
         N.set_option("force_global_cursor", 0)
-    _check_forward(fr, G.decode(P, W, H, out), P, True)
+    _check_forward(fr, d, P, True)
     dpix = np.random.default_rng(2).normal(size=(3, H, W)).astype(np.float32)
     _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device),
                  ["dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"])
@@ -404,13 +405,17 @@ print("MANY_PASSES_OK")
     assert r.returncode == 0 and "MANY_PASSES_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("lazy", [0, 1], ids=["sorted_whole", "lazy_sort"])
 @pytest.mark.parametrize("P,spread,longest", [(9000, 2.0, 4096), (60000, 4.0, 3 * 4096)],
                          ids=["two_runs", "many_runs_three_merge_passes"])
-def test_tile_list_longer_than_lds_capacity(oracle_mod, cuda_device, P, spread, longest):
-    """Lists beyond the LDS sort capacity (4096): those tiles are sorted by the per-tile long-list sort
-    (4096-key runs + merge passes through HBM) while the other tiles stay on the LDS path -- no whole-frame
-    fallback -- and everything still matches the oracle bit for bit.  First call: staged path (the host
-    learns the longest list); second call: speculative with a long-list hint."""
+def test_tile_list_longer_than_lds_capacity(oracle_mod, cuda_device, P, spread, longest, lazy):
+    """Lists beyond the LDS sort capacity (4096).  Option "lazy_sort" off: those tiles are sorted by the per-tile
+    long-list sort (4096-key runs + merge passes through HBM) while the other tiles stay on the LDS path -- no
+    whole-frame fallback.  On (the default): they are sorted segment by segment as far as the blend walks them; the
+    Gaussians here are nearly transparent, so the walk goes on through many segments.  Either way everything matches
+    the oracle bit for bit.  First call: staged path (the host learns the longest list); second call: speculative
+    with a long-list hint."""
+    from gaussiancity_amd import _native as N
     from gaussiancity_amd import ext
     W, H = 48, 48
     rs = scenes.camera(W, H)
@@ -419,10 +424,52 @@ def test_tile_list_longer_than_lds_capacity(oracle_mod, cuda_device, P, spread, 
     lens = fr.ranges[:, 1].astype(np.int64) - fr.ranges[:, 0]
     assert lens.max() > longest and (lens[lens > 0] <= 4096).any()   # long AND short tiles in the same frame
     ext._capacity_hint.pop((cuda_device.index, P, W, H), None)
+    prev = N.set_option("lazy_sort", lazy)
+    try:
+        for _ in range(2):
+            args, out = G.run_forward(rs, sc, cuda_device, use_sh=False)
+            d = G.decode(P, W, H, out)
+            _check_forward(fr, d, P, False)
+            if lazy:   # more than one segment was sorted somewhere (the blend itself sorted on)
+                assert (d["tile_sorted"] > 1024).any()
+            else:
+                assert "tile_sorted" not in d
+        dpix = np.random.default_rng(8).normal(size=(3, H, W)).astype(np.float32)
+        _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device),
+                     ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dscale", "dL_drot"])
+    finally:
+        N.set_option("lazy_sort", prev)
+
+
+@pytest.mark.parametrize("case", ["one_tile_300k", "equal_depths"])
+def test_lazy_sort_when_samples_cannot_separate_the_keys(oracle_mod, cuda_device, case):
+    """gcr_sort.h "lazy tile sort", the rare branches: (a) 300 000 entries in ONE tile -- the 256 samples lie more than
+    a segment apart, so the segment bound is found by bisecting the key interval; (b) thousands of Gaussians at three
+    distinct depths -- the keys differ in the index half only, segments end in the middle of a depth class and the
+    order inside a class must still be ascending index (cr/rasterizer_impl.cu:255-260, stable sort).  Low opacities
+    keep the pixels alive, so the blend sorts on through several segments.  Image, per-pixel state and the final
+    prefix of every list against the oracle, gradients within tolerance."""
+    if case == "one_tile_300k":
+        P, W, H = 300_000, 16, 16
+        rs = scenes.camera(W, H)
+        sc = scenes.blob_scene(P, 97, 0, spread=0.6, smin=0.3, smax=1.5, omin=0.002, omax=0.01)
+    else:
+        P, W, H = 6000, 64, 48
+        rs = scenes.camera(W, H)
+        sc = scenes.blob_scene(P, 99, 0, smin=1.0, smax=4.0, omin=0.002, omax=0.01)
+        sc["means3D"][:] = sc["means3D"][0]
+        sc["means3D"][::3, 0] += 3.0
+        sc["means3D"][1::3, 0] -= 3.0
+    fr = _frame(oracle_mod, rs, sc, use_sh=False)
+    lens = fr.ranges[:, 1].astype(np.int64) - fr.ranges[:, 0]
+    assert lens.max() > (250_000 if case == "one_tile_300k" else 3000)
+    assert int(fr.n_contrib.max()) > 2048          # the walk needs more than two segments somewhere
     for _ in range(2):
-        args, out = G.run_forward(rs, sc, cuda_device, use_sh=False)
-        _check_forward(fr, G.decode(P, W, H, out), P, False)
-    dpix = np.random.default_rng(8).normal(size=(3, H, W)).astype(np.float32)
+        args, out = G.run_forward(rs, sc, cuda_device, use_sh=False, for_backward=True)
+        d = G.decode(P, W, H, out)
+        _check_forward(fr, d, P, False)
+        assert (d["tile_sorted"] > 2048).any()
+    dpix = np.random.default_rng(9).normal(size=(3, H, W)).astype(np.float32)
     _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device),
                  ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dscale", "dL_drot"])
 
@@ -567,12 +614,23 @@ def test_full_size_properties(cuda_device):
     assert ranges[nz[0], 0] == 0 and ranges[nz[-1], 1] == R
     assert np.array_equal(ranges[nz[1:], 0], ranges[nz[:-1], 1])  # segments tile [0, R) without gaps
     plist = binning[L.bin_vals[L.bin_sorted]:L.bin_vals[L.bin_sorted] + 4 * R].view(torch.int32).long()
+    # option "lazy_sort": a list longer than 1024 entries is in final order only as far as its `n_sorted` says (what
+    # lies behind it was never written: mask it out before it is used as an index)
+    final = torch.ones(R, dtype=torch.bool, device=plist.device)
+    if G.lazy_sort_active():
+        ns = img[L.img_tile_lazy:L.img_tile_lazy + 16 * T].view(torch.int32).view(T, 4)[:, 0].long()
+        lens_t = torch.from_numpy(lens).to(plist.device)
+        assert bool((ns <= lens_t).all()) and bool((ns[lens_t <= 1024] == lens_t[lens_t <= 1024]).all())
+        order_t = torch.from_numpy(order).to(plist.device)
+        tile_of = torch.repeat_interleave(order_t, lens_t[order_t])   # tile of every list position
+        final = torch.arange(R, device=plist.device) - torch.from_numpy(ranges[:, 0]).to(plist.device)[tile_of] < ns[tile_of]
+        plist = torch.where(final, plist, plist[0])
     depth = geom[L.geom_rec:L.geom_rec + P * 48].view(torch.float32).view(P, 12)[:, 9]
     dkey = depth[plist].view(torch.int32).long()  # positive floats: the bit pattern orders like the value
     key = (dkey << 32) | plist
     seg_start = torch.zeros(R, dtype=torch.bool, device=key.device)
     seg_start[torch.from_numpy(ranges[nz, 0]).to(key.device)] = True
-    assert bool(((key[1:] > key[:-1]) | seg_start[1:]).all()), "a tile list is not (depth, index)-sorted"
+    assert bool(((key[1:] > key[:-1]) | seg_start[1:] | ~final[1:]).all()), "a tile list is not (depth, index)-sorted"
     radii = out[2]
     assert bool((radii[plist] > 0).all())
     # n_contrib never exceeds the tile's list length
