@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
     if (n > GCR_LAZY_MIN) {
       uint32_t n_sorted = 0;
       uint64_t L = 0;
-      gcr_lazy_extend(s, pairs + r0, (uint32_t)n, n_sorted, L, list + r0, tid);
+      gcr_lazy_extend<GCR_LAZY_CAP_K4>(s, pairs + r0, (uint32_t)n, n_sorted, L, list + r0, tid);
       if (tid == 0) lazy[blockIdx.x] = make_uint4(n_sorted, 0u, (uint32_t)L, (uint32_t)(L >> 32));
       return;
     }
@@ -684,7 +684,8 @@ hipError_t gcr_launch_tile_sort(const uint32_t* ranges, int T, uint64_t* pairs, 
   while ((int64_t)n2 < list_length_hint && n2 < (size_t)cap) n2 <<= 1;
   // bitonic path: n2 keys; rank/merge path (<= RANK_MERGE_MAX keys): two buffers of n rounded up to 64
   size_t lds = n2 <= (size_t)RANK_MERGE_MAX ? 2 * n2 * sizeof(uint64_t) : n2 * sizeof(uint64_t);
-  if (lazy != nullptr && lds < GCR_LAZY_LDS_KEYS * sizeof(uint64_t)) lds = GCR_LAZY_LDS_KEYS * sizeof(uint64_t);
+  if (lazy != nullptr && lds < gcr_lazy_lds_keys(GCR_LAZY_CAP_K4) * sizeof(uint64_t))
+    lds = gcr_lazy_lds_keys(GCR_LAZY_CAP_K4) * sizeof(uint64_t);
   k_tile_sort<<<T, 256, lds, s>>>(ranges, pairs, pairs_spare, list, frame, (int)n2, lazy);
   return hipGetLastError();
 }

@@ -148,7 +148,7 @@ __device__ __noinline__ uint32_t k6_lazy_extend(uint64_t* s, const uint64_t* key
   uint32_t ns = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint64_t l = (uint64_t)__hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
                ((uint64_t)__hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
-  gcr_lazy_extend(s, keys, n, ns, l, out, tid);
+  gcr_lazy_extend<GCR_LAZY_CAP_K6>(s, keys, n, ns, l, out, tid);
   if (tid == 0) {
     __hip_atomic_store(w, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(w + 2, (uint32_t)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -154,16 +154,22 @@ GCR_DEV void gcr_tile_sort_long(uint64_t* s, uint32_t run0, uint64_t* __restrict
 // The key buffer is only read; the tile sort kernel extracts the first segment, K6 the following ones (its workgroup is
 // about to gather those entries anyway).  Entries behind the last one consumed stay unsorted.
 constexpr int GCR_LAZY_MIN = 1024;      // lists up to this length are sorted whole by the tile sort kernel
-constexpr int GCR_LAZY_CAP = 1024;      // keys per segment (LDS)
 constexpr int GCR_LAZY_SAMPLES = 256;
-constexpr int GCR_LAZY_TARGET = 768;    // keys a sampled segment aims at
-constexpr int GCR_LAZY_LDS_KEYS = GCR_LAZY_CAP + GCR_LAZY_SAMPLES + 3;  // 64-bit LDS words gcr_lazy_extend() needs
+// keys per segment (LDS capacity; a sampled segment aims at 3/4 of it): what K6 can hold in its record buffer, and the
+// first segment the tile sort kernel extracts
+constexpr int GCR_LAZY_CAP_K6 = 1024;
+#ifndef GCR_LAZY_CAP_K4
+#define GCR_LAZY_CAP_K4 1024
+#endif
+constexpr int gcr_lazy_lds_keys(int cap) { return cap + GCR_LAZY_SAMPLES + 3; }  // 64-bit LDS words gcr_lazy_extend() needs
 
-// Appends the next segment of the tile's order to out[n_sorted ...].  `s`: GCR_LAZY_LDS_KEYS 64-bit LDS words nobody
+// Appends the next segment of the tile's order to out[n_sorted ...].  `s`: gcr_lazy_lds_keys(CAP) 64-bit LDS words nobody
 // else is using (the function starts and ends with a workgroup barrier); keys[0, n): the tile's unsorted keys;
 // n_sorted < n and L as above, both updated.
+template <int GCR_LAZY_CAP>
 GCR_DEV void gcr_lazy_extend(uint64_t* s, const uint64_t* keys, uint32_t n, uint32_t& n_sorted, uint64_t& L,
                              uint32_t* out, int tid) {
+  constexpr int GCR_LAZY_TARGET = GCR_LAZY_CAP * 3 / 4;
   uint64_t* samp = s + GCR_LAZY_CAP;                                                        // c[0, m): candidates
   uint32_t* cnt_w = reinterpret_cast<uint32_t*>(s + GCR_LAZY_CAP + GCR_LAZY_SAMPLES);       // compaction counter
   unsigned long long* lo_w = reinterpret_cast<unsigned long long*>(s + GCR_LAZY_CAP + GCR_LAZY_SAMPLES + 1);
@@ -174,7 +180,7 @@ GCR_DEV void gcr_lazy_extend(uint64_t* s, const uint64_t* keys, uint32_t n, uint
   uint32_t m = 0, j = 0;
   uint64_t U = ~0ull;  // no key is ~0: depth bits of a positive float in the high half
   __syncthreads();
-  if (rem > (uint32_t)GCR_LAZY_CAP) {  // (then n > 1024: the 256 sample positions are distinct)
+  if (rem > (uint32_t)GCR_LAZY_CAP) {  // (then n > 256: the 256 sample positions are distinct)
     const uint64_t k = keys[((uint64_t)tid * n) >> 8];
     const bool cand = k >= L;
     const uint64_t mine = cand ? k : ~0ull;
