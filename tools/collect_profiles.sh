@@ -77,6 +77,8 @@ done
 # ---- bench lines ---------------------------------------------------------------------------------------------------
 python $R/bench.py > $O/${TAG}_bench_c3.json 2>/dev/null
 python $R/bench.py --config C5 --steps 48 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_c5.json 2>/dev/null
+python $R/bench.py --config D1 --steps 48 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_d1.json 2>/dev/null   # dense stress scene (lazy tile sort)
+python $R/bench.py --config D1 --steps 48 --no-secondary --no-cpu-baseline --sort-whole > $O/${TAG}_bench_d1_sorted_whole.json 2>/dev/null
 python $R/bench.py --path visibility > $O/${TAG}_bench_visibility.json 2>/dev/null
 python $R/bench.py --path grid-encoder > $O/${TAG}_bench_grid_encoder.json 2>/dev/null
 for hc in "--host-camera device" "--host-camera reference" "--host-camera closed-form"; do   # the product's inference loop through the wrapper
