@@ -1,5 +1,6 @@
 // gcr_binning.hip -- tile binning for gfx950: K3 key emit, K4 stable LSD radix sort, K5 ranges.
 // Integer / byte work, HBM-bound; no MFMA.  wave64 ballots do the intra-wave digit matching.
+#include <stdlib.h>
 #include "gcr_device.h"
 #include "gcr_internal.h"
 #include "gcr_sort.h"
@@ -63,10 +64,10 @@ __global__ __launch_bounds__(256) void k_emit(int P, const uint32_t* __restrict_
 // order the reference gets from its stable radix sort on tile<<32|depth over instances emitted
 // in index order (cr/rasterizer_impl.cu:66-99,255-260).
 constexpr int RANK_MERGE_MAX = 1024;  // chunked rank sort + merge below, bitonic network above
-// Threads per workgroup of the tile-table kernels (template parameter TT_THREADS): 512 while two tables fit a CU's
-// LDS (T*4 B <= 64 KiB), 1024 when a table only leaves room for one workgroup per CU (4K images: 130 KiB) so that
-// the CU still runs 16 waves (C5: count 60 -> 57 us, scatter 203 -> 197 us; the scatter there is bound by its
-// 8-byte stores landing in 32-byte sectors, not by occupancy).
+// Threads per workgroup of the tile-table kernels (template parameter TT_THREADS): 1024, one workgroup per CU, 256
+// groups (gcr_tile_table_groups: fewer, fatter groups = fewer table rows through HBM; rounds 1-2 ran 512 groups of 512
+// threads while two tables fit a CU's LDS).  At 4K a table (130 KiB) only leaves room for one workgroup per CU anyway;
+// the scatter there is bound by its 8-byte stores landing in 32-byte sectors, not by occupancy.
 constexpr int TT_MAX_GROUP = 64;  // K1 blocks per group (host guarantees G <= this)
 constexpr int TT_MAX_TBLOCKS = 640;  // 64-tile blocks: T <= 40960 > the LDS limit of 150 KiB / 4 B
 
@@ -547,8 +548,13 @@ hipError_t gcr_launch_emit(int P, const uint32_t* tiles_touched, const uint32_t*
 int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out) {
   const size_t lds = (size_t)T * sizeof(uint32_t);
   if (lds > 150 * 1024 || (T + 63) / 64 > TT_MAX_TBLOCKS) return 0;
-  const int per_cu = lds > 64 * 1024 ? 1 : 2;
-  int ng = 256 * per_cu;
+  // One 1024-thread workgroup per CU.  Round 3 A/B at C3 (same box, experiment build): 512 groups of 512 threads (two
+  // tables per CU) 4 407-4 432 frames/s, 256 groups of 1024 threads 4 470-4 550 -- half the table rows to write, scan and
+  // read back (count + column scan 22.3 -> 18.9 us, scatter 28.7 -> 25.7 us alone); 192 / 128 groups the same, 64 slower.
+  int ng = 256;
+#ifdef GCR_EXPERIMENTS
+  if (const char* e = getenv("GCR_TT_GROUPS")) ng = atoi(e);
+#endif
   if (ng > nblocks_k1) ng = nblocks_k1;
   if (ng < 1) ng = 1;
   int G = (nblocks_k1 + ng - 1) / ng;
@@ -569,7 +575,7 @@ static hipError_t tile_table_attr() {
   }();
   return done;
 }
-static inline bool tile_table_wide(int T) { return (size_t)T * sizeof(uint32_t) > 64 * 1024; }
+static inline bool tile_table_wide(int) { return true; }  // (the 512-thread instantiations remain for A/B builds)
 
 hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,
