@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const uint32_t need = (uint32_t)(base + min(cs, total - base));
     while (lz_sorted < need) {  // sE is not live here
       const uint32_t ns = k6_lazy_extend(reinterpret_cast<uint64_t*>(sE), a.pairs + r0, (uint32_t)total,
-                                         const_cast<uint32_t*>(a.list) + r0, a.lazy + tile);
+                                         a.list_out + r0, a.lazy + tile);  // (list_out == list on this path)
       lz_sorted = (uint32_t)__builtin_amdgcn_readfirstlane((int)ns);
     }
   }
