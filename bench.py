@@ -550,12 +550,16 @@ def main():
             torch.cuda.synchronize()
             ms2 = 1e3 * (time.perf_counter() - t1) / n2
             # per-stage times: the same frames again with HIP events around every stage (a few us per frame)
+            # (two passes, the smaller average per stage: one preempted frame in 24 otherwise doubles a 10 us stage)
             N.set_option("timing", 1)
-            N.stage_ms()
-            for i in range(n2):
-                fb(3 + i)
-            torch.cuda.synchronize()
-            st2 = N.stage_ms()
+            st2 = None
+            for _ in range(2):
+                N.stage_ms()
+                for i in range(n2):
+                    fb(3 + i)
+                torch.cuda.synchronize()
+                st = N.stage_ms()
+                st2 = st if st2 is None else {k: min(v, st[k]) for k, v in st2.items()}
             N.set_option("timing", 0)
             R2, Rp2, Pv2 = frame_statistics(fwd2, list(range(3, 3 + n2)), P2, W2, H2)
             ab2 = algorithmic_bytes(P2, Pv2, R2, Rp2, W2, H2, sc2["shs"].shape[1], True)
