@@ -1,0 +1,154 @@
+"""Randomised parity sweep: many small seeded frames with random sizes, Gaussian counts, extents, opacities, SH degrees,
+camera poses, backgrounds, scale modifiers, training / inference frames and library options, each compared with the CPU oracle -- image, per-pixel state and radii bit for bit, the final prefix of every
+tile list, the eight gradient tensors within 1e-4 * max.  One JSON line per failing case, a summary at the end.
+
+    python tools/fuzz_parity.py [--cases 300] [--seed 1] [--max-seconds 240]
+
+(tests/test_gpu_fuzz.py runs a fixed 40-case slice of the same generator under pytest -m gpu.)
+
+Gradient tolerance.  1e-4 * max (the north-star bar) for scenes whose largest scale stays within 8 -- anisotropy up to
+40:1, harsher than any BASELINE scene.  Beyond that (scales up to 14 against 0.2: near-degenerate 2D covariances,
+1 / det^2 in the conic gradient) fp32 itself is the limit: in the first 400-case sweep 8 such cases exceeded 1e-4 * max
+by up to 12x in dL_drot / dL_dscale / dL_dmean3D, and for the three of them that were re-computed in float64
+(oracle/dense_f64.py; cases 58, 202, 317 of seed 1) the fp32 ORACLE is just as far from the float64 gradient (58: oracle
+vs float64 0.0648 on dL_drot, GPU vs oracle 0.0625; 317: 0.00116 vs 0.00161; 202: 0.00235 vs 0.00253) -- different
+summation orders of an ill-conditioned sum, not a defect of either.  Those cases are held to 5e-3 * max.  Dense frames
+(thousands of overlapping Gaussians per tile) with scales within 8: 3 of 1 200 cases of seed 2 exceeded 1e-4 * max, by
+at most 2.3x (dL_dscale / dL_drot); case 373 in float64: the oracle is 20x further from the float64 gradient (0.0057
+on dL_dscale) than the GPU is from the oracle (0.0003) -- held to 3e-4 * max.  The forward is bit-exact everywhere
+(1 600 cases of seeds 1 and 2).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+GRAD_TOL = 1e-4
+GRAD_TOL_DENSE = 3e-4             # thousands of overlapping Gaussians per tile (see the module docstring)
+GRAD_TOL_ILL_CONDITIONED = 5e-3   # scenes with scales beyond 8
+GRADS = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
+
+
+def draw_case(rng):
+    """One random frame description (plain dict, JSON-able)."""
+    W = int(rng.choice([16, 17, 31, 48, 64, 97, 160, 208, 333]))
+    H = int(rng.choice([16, 23, 32, 48, 75, 128, 176]))
+    regime = str(rng.choice(["sparse", "medium", "dense", "translucent_pile", "opaque_pile"]))
+    P = {"sparse": int(rng.integers(0, 200)), "medium": int(rng.integers(200, 4000)),
+         "dense": int(rng.integers(4000, 20000)), "translucent_pile": int(rng.integers(3000, 40000)),
+         "opaque_pile": int(rng.integers(3000, 40000))}[regime]
+    pile = regime.endswith("pile")
+    in_blend = int(rng.random() < 0.15)   # (the blend's own sort of short lists leaves no lazy-sort state to check against)
+    return dict(
+        W=W, H=H, P=P, regime=regime, seed=int(rng.integers(1, 1 << 30)),
+        deg=int(rng.integers(0, 4)), use_sh=bool(rng.random() < 0.7),
+        spread=float(rng.uniform(1.0, 6.0) if pile else rng.uniform(10.0, 60.0)),
+        smin=float(rng.uniform(0.2, 1.0)), smax=float(rng.uniform(1.5, 14.0)),
+        omin=float(0.003 if regime == "translucent_pile" else rng.uniform(0.01, 0.5)),
+        omax=float(0.03 if regime == "translucent_pile" else rng.uniform(0.5, 1.0)),
+        pose=int(rng.integers(0, 24)), radius=float(rng.uniform(30.0, 90.0)), altitude=float(rng.uniform(10.0, 80.0)),
+        bg=[float(x) for x in rng.uniform(0, 1, 3)], scale_modifier=float(rng.choice([1.0, 1.0, 0.5, 1.7])),
+        backward=bool(rng.random() < 0.6), train_frame=bool(rng.random() < 0.5),
+        piece=int(rng.choice([64, 96, 128, 192, 256])), lazy=0 if in_blend else int(rng.random() < 0.8),
+        sort_in_blend=in_blend, split_preprocess=int(rng.random() < 0.15),
+        deterministic=int(rng.random() < 0.15))
+
+
+def run_case(c, O, G, scenes, N, dev):
+    """Returns a list of failure strings (empty = the case agrees with the oracle)."""
+    rs = scenes.camera(c["W"], c["H"], pose_index=c["pose"], radius=c["radius"], altitude=c["altitude"])
+    rs = rs._replace(sh_degree=c["deg"], bg=torch.tensor(c["bg"], dtype=torch.float32), scale_modifier=c["scale_modifier"])
+    sc = scenes.blob_scene(c["P"], c["seed"], c["deg"], spread=c["spread"], smin=c["smin"], smax=c["smax"],
+                           omin=c["omin"], omax=c["omax"])
+    kw = scenes.settings_kwargs(rs)
+    extra = dict(shs=sc["shs"]) if c["use_sh"] else dict(colors_precomp=sc["colors_precomp"])
+    fr = O.Frame(**kw, means3D=sc["means3D"], opacities=sc["opacities"], scales=sc["scales"], rotations=sc["rotations"],
+                 **extra)
+    fails = []
+    opts = dict(bwd_piece=c["piece"], lazy_sort=c["lazy"], sort_in_blend=c["sort_in_blend"],
+                split_preprocess=c["split_preprocess"], deterministic_backward=c["deterministic"])
+    prev = {k: N.set_option(k, v) for k, v in opts.items()}
+    try:
+        args, out = G.run_forward(rs, sc, dev, use_sh=c["use_sh"], for_backward=c["train_frame"])
+        if c["P"] == 0:   # nothing to decode: no state buffers, the image is the background
+            if out[0] != 0 or not np.array_equal(out[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32)):
+                fails.append("empty frame: R or image")
+            return fails
+        d = G.decode(c["P"], c["W"], c["H"], out)
+        if d["R"] != fr.R:
+            fails.append("R %d != %d" % (d["R"], fr.R))
+        if not np.array_equal(d["radii"], fr.radii):
+            fails.append("radii")
+        if not fails and fr.R > 0:
+            try:
+                G.assert_point_list(d, fr)
+            except AssertionError as e:
+                fails.append("point_list: " + str(e)[:120])
+        if not np.array_equal(d["n_contrib"], fr.n_contrib):
+            fails.append("n_contrib (%d pixels)" % int((d["n_contrib"] != fr.n_contrib).sum()))
+        if not np.array_equal(d["final_T"].view(np.uint32), fr.final_T.view(np.uint32)):
+            fails.append("final_T")
+        if not np.array_equal(d["out_color"].view(np.uint32), fr.out_color.view(np.uint32)):
+            fails.append("image (max diff %g)" % float(np.abs(d["out_color"] - fr.out_color).max()))
+        if c["backward"] and not fails:
+            dpix = np.random.default_rng(c["seed"] + 5).normal(size=(3, c["H"], c["W"])).astype(np.float32)
+            gref, ggpu = fr.backward(dpix), G.run_backward(args, out, dpix, dev)
+            for n in GRADS:
+                if n == "dL_dsh" and not c["use_sh"]:
+                    continue
+                if n == "dL_dcolor" and c["use_sh"]:
+                    continue
+                ref, got = gref[n], ggpu[n].reshape(gref[n].shape)
+                rel = GRAD_TOL_ILL_CONDITIONED if c["smax"] > 8.0 else (
+                    GRAD_TOL_DENSE if c["regime"] in ("dense", "translucent_pile", "opaque_pile") else GRAD_TOL)
+                tol = rel * max(1.0, float(np.abs(ref).max()))
+                err = float(np.abs(ref - got).max()) if ref.size else 0.0
+                if not (err <= tol) or not np.isfinite(got).all():
+                    fails.append("%s err %.3g > %.3g" % (n, err, tol))
+    finally:
+        for k, v in prev.items():
+            N.set_option(k, v)
+    return fails
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-seconds", type=float, default=240.0)
+    a = ap.parse_args()
+    import gpu_util as G
+    import scenes
+    from gaussiancity_amd import _native as N
+    from oracle import oracle as O
+    O.build()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(a.seed)
+    t0, bad, done, by_regime = time.time(), 0, 0, {}
+    for i in range(a.cases):
+        if time.time() - t0 > a.max_seconds:
+            break
+        c = draw_case(rng)
+        try:
+            fails = run_case(c, O, G, scenes, N, dev)
+        except Exception as e:  # a crash is a failure of the case, not of the sweep
+            fails = ["exception %s: %s" % (type(e).__name__, str(e)[:200])]
+        done += 1
+        by_regime[c["regime"]] = by_regime.get(c["regime"], 0) + 1
+        if fails:
+            bad += 1
+            print(json.dumps({"case": i, "fails": fails, "desc": c}), flush=True)
+    print(json.dumps({"cases": done, "failed": bad, "seconds": round(time.time() - t0, 1), "seed": a.seed,
+                      "by_regime": by_regime}), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
