@@ -1,6 +1,7 @@
 """Randomised parity sweep: many small seeded frames with random sizes, Gaussian counts, extents, opacities, SH degrees,
-camera poses, backgrounds, scale modifiers, training / inference frames and library options, each compared with the CPU oracle -- image, per-pixel state and radii bit for bit, the final prefix of every
-tile list, the eight gradient tensors within 1e-4 * max.  One JSON line per failing case, a summary at the end.
+camera poses, backgrounds, scale modifiers, training / inference frames and library options, each compared with the
+CPU oracle -- image, per-pixel state and radii bit for bit, the final prefix of every tile list, the eight gradient
+tensors within tolerance.  One JSON line per failing case, a summary at the end.
 
     python tools/fuzz_parity.py [--cases 300] [--seed 1] [--max-seconds 240]
 
