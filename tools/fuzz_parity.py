@@ -3,7 +3,10 @@ camera poses, backgrounds, scale modifiers, training / inference frames and libr
 CPU oracle -- image, per-pixel state and radii bit for bit, the final prefix of every tile list, the eight gradient
 tensors within tolerance.  One JSON line per failing case, a summary at the end.
 
-    python tools/fuzz_parity.py [--cases 300] [--seed 1] [--max-seconds 240]
+    python tools/fuzz_parity.py [--cases 300] [--wrapper-cases 150] [--seed 1] [--max-seconds 240]
+
+A second sweep calls GaussianRasterizerWrapper on random [N,14] tensors (row strides, column offsets, flips, crop
+windows, the three camera modes) and compares its single autograd node with the reference's route on the same GPU.
 
 (tests/test_gpu_fuzz.py runs a fixed 40-case slice of the same generator under pytest -m gpu.)
 
@@ -78,8 +81,8 @@ def run_case(c, O, G, scenes, N, dev):
     prev = {k: N.set_option(k, v) for k, v in opts.items()}
     try:
         args, out = G.run_forward(rs, sc, dev, use_sh=c["use_sh"], for_backward=c["train_frame"])
-        if c["P"] == 0:   # nothing to decode: no state buffers, the image is the background
-            if out[0] != 0 or not np.array_equal(out[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32)):
+        if c["P"] == 0:   # the binding's short-circuit (dgr/rasterize_points.cu:71): no state, R = 0, an image of ZEROS
+            if out[0] != 0 or tuple(out[1].shape) != (3, c["H"], c["W"]) or float(out[1].abs().max()) != 0.0:
                 fails.append("empty frame: R or image")
             return fails
         d = G.decode(c["P"], c["W"], c["H"], out)
@@ -119,11 +122,79 @@ def run_case(c, O, G, scenes, N, dev):
     return fails
 
 
+def draw_wrapper_case(rng):
+    """One random call of GaussianRasterizerWrapper on an [N,14] tensor: size, pose, flips, crop window, row stride."""
+    W = int(rng.choice([33, 64, 100, 160, 251, 320]))
+    H = int(rng.choice([17, 48, 75, 128, 180]))
+    crop = None
+    if rng.random() < 0.6:
+        w, h = int(rng.integers(1, W + 1)), int(rng.integers(1, H + 1))
+        crop = [int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1)), w, h]
+    return dict(W=W, H=H, N=int(rng.integers(1, 6000)), seed=int(rng.integers(1, 1 << 30)), pose=int(rng.integers(0, 24)),
+                flip_lr=bool(rng.random() < 0.5), flip_ud=bool(rng.random() < 0.5), crop=crop,
+                stride=int(rng.choice([14, 14, 16, 20, 31])), col0=int(rng.integers(0, 3)),
+                spread=float(rng.uniform(8.0, 50.0)), smax=float(rng.uniform(1.5, 6.0)),
+                backward=bool(rng.random() < 0.7), host_camera=[None, True, False][int(rng.integers(0, 3))])
+
+
+def run_wrapper_case(c, dev):
+    """The wrapper's single autograd node (strided [N,14] input in place, mirrored / windowed store, packed gradient)
+    against the reference's route on the same GPU (five slices -> GaussianRasterizer -> torch.flip -> slice crop): the
+    image must be bit-equal, the [N,14] gradient equal within the atomics' tolerance."""
+    import scenes
+    from gaussiancity_amd import synth
+    from gaussiancity_amd.rasterizer import GaussianRasterizer, GaussianRasterizerWrapper
+    sc = scenes.blob_scene(c["N"], c["seed"], 0, spread=c["spread"], smin=0.4, smax=c["smax"])
+    pts = np.concatenate([sc["means3D"], sc["opacities"], sc["scales"], sc["rotations"], sc["colors_precomp"]], axis=1)
+    stride = max(c["stride"], c["col0"] + 14)
+    wide = torch.zeros((c["N"], stride), dtype=torch.float32, device=dev)
+    wide[:, c["col0"]:c["col0"] + 14] = torch.from_numpy(pts.astype(np.float32)).to(dev)
+    wr = GaussianRasterizerWrapper(synth.intrinsics(c["W"], c["H"]), (c["W"], c["H"]), flip_lr=c["flip_lr"],
+                                   flip_ud=c["flip_ud"], device=dev, host_camera=c["host_camera"])
+    pos, quat = synth.orbit_poses(24, 60.0, 50.0)[c["pose"]]
+    oh, ow = (c["crop"][3], c["crop"][2]) if c["crop"] else (c["H"], c["W"])
+    dpix = torch.from_numpy(np.random.default_rng(c["seed"] + 1).normal(size=(3, oh, ow)).astype(np.float32)).to(dev)
+
+    class Foreign(GaussianRasterizer):  # not `type(...) is GaussianRasterizer`: takes the reference's route
+        pass
+
+    res = {}
+    for name in ("node", "generic"):
+        leaf = wide.clone().requires_grad_(c["backward"])
+        points = leaf[:, c["col0"]:c["col0"] + 14]
+        rz = wr.get_gaussian_rasterizer(pos, quat)
+        if name == "generic":
+            img = wr(points, gaussian_rasterizer=Foreign(rz.raster_settings))
+            if c["crop"]:
+                x, y, w, h = c["crop"]
+                img = img[:, y:y + h, x:x + w]
+        else:
+            img = wr(points, gaussian_rasterizer=rz, crop=tuple(c["crop"]) if c["crop"] else None)
+        if c["backward"]:
+            (img * dpix).sum().backward()
+        res[name] = (img.detach().cpu().numpy(), leaf.grad.cpu().numpy() if c["backward"] else None)
+    fails = []
+    a, b = res["node"][0], res["generic"][0]
+    if a.shape != b.shape or not np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32)):
+        fails.append("image differs (shapes %s %s)" % (a.shape, b.shape))
+    if c["backward"] and not fails:
+        gn, gg = res["node"][1], res["generic"][1]
+        err = float(np.abs(gn - gg).max())
+        if not err <= GRAD_TOL_DENSE * max(1.0, float(np.abs(gg).max())):
+            fails.append("gradient err %.3g (max %.3g)" % (err, float(np.abs(gg).max())))
+        outside = np.ones(gn.shape[1], bool)
+        outside[c["col0"]:c["col0"] + 14] = False
+        if np.abs(gn[:, outside]).max(initial=0.0) != 0.0:
+            fails.append("gradient written outside the 14 columns")
+    return fails
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-seconds", type=float, default=240.0)
+    ap.add_argument("--wrapper-cases", type=int, default=150)
     a = ap.parse_args()
     import gpu_util as G
     import scenes
@@ -148,7 +219,22 @@ def main():
             print(json.dumps({"case": i, "fails": fails, "desc": c}), flush=True)
     print(json.dumps({"cases": done, "failed": bad, "seconds": round(time.time() - t0, 1), "seed": a.seed,
                       "by_regime": by_regime}), flush=True)
-    return 1 if bad else 0
+    # second sweep: the wrapper's own node (strides, flips, windows, camera modes) against the reference's route
+    t1, wbad, wdone = time.time(), 0, 0
+    for i in range(a.wrapper_cases):
+        if time.time() - t1 > a.max_seconds:
+            break
+        c = draw_wrapper_case(rng)
+        try:
+            fails = run_wrapper_case(c, dev)
+        except Exception as e:
+            fails = ["exception %s: %s" % (type(e).__name__, str(e)[:200])]
+        wdone += 1
+        if fails:
+            wbad += 1
+            print(json.dumps({"wrapper_case": i, "fails": fails, "desc": c}), flush=True)
+    print(json.dumps({"wrapper_cases": wdone, "failed": wbad, "seconds": round(time.time() - t1, 1)}), flush=True)
+    return 1 if bad or wbad else 0
 
 
 if __name__ == "__main__":
