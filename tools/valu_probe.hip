@@ -92,6 +92,22 @@ __global__ __launch_bounds__(256) void k_probe(float* out, int iters, float seed
 #define S(r) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(r) : "v"(m), "v"(c));
       REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
 #undef S
+    } else if (KIND == 19) {  // v_cmp_lt_u64 -> vcc (the rank loops of the tile sort compare 64-bit keys)
+#define S(r) asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(r), "v"(pm) : "vcc");
+      REP8(S(p0) S(p1) S(p2) S(p3) S(p4) S(p5) S(p6) S(p7))
+#undef S
+    } else if (KIND == 20) {  // v_cmp_lt_u32 -> vcc
+#define S(r) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(r), "v"(c) : "vcc");
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 21) {  // v_addc_co_u32 (count += carry)
+#define S(r) asm volatile("v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r) : : "vcc");
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 22) {  // v_cmp_lt_u64 -> vcc followed by v_addc_co_u32: one rank step
+#define S(r, q) asm volatile("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r) : "v"(q), "v"(pm) : "vcc");
+      REP8(S(a0, p0) S(a1, p1) S(a2, p2) S(a3, p3) S(a4, p4) S(a5, p5) S(a6, p6) S(a7, p7))
+#undef S
     } else if (KIND == 18) {  // v_fma_f32 with two literal-free inline constants (VOP3, 3 VGPR reads vs 2)
 #define S(r) asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(r) : "v"(m));
       REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
@@ -160,6 +176,10 @@ int main(int argc, char** argv) {
   run<13>("v_cndmask_b32 (dst != src)", out, blocks, iters, mhz);
   run<11>("v_fma_f32 / v_cndmask_b32 interleaved", out, blocks, iters, mhz);
   run<15>("v_cmp_lt_f32 -> vcc", out, blocks, iters, mhz);
+  run<19>("v_cmp_lt_u64 -> vcc", out, blocks, iters, mhz);
+  run<20>("v_cmp_lt_u32 -> vcc", out, blocks, iters, mhz);
+  run<21>("v_addc_co_u32", out, blocks, iters, mhz);
+  run<22>("v_cmp_lt_u64 + v_addc_co_u32 (two instructions)", out, blocks, iters, mhz);
   hipFree(out);
   return 0;
 }
