@@ -108,6 +108,18 @@ __global__ __launch_bounds__(256) void k_probe(float* out, int iters, float seed
 #define S(r, q) asm volatile("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r) : "v"(q), "v"(pm) : "vcc");
       REP8(S(a0, p0) S(a1, p1) S(a2, p2) S(a3, p3) S(a4, p4) S(a5, p5) S(a6, p6) S(a7, p7))
 #undef S
+    } else if (KIND == 23) {  // v_add_f32 with a DPP quad permute on src0 (K7's reduce-scatter, xor-1 / xor-2 levels)
+#define S(r) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 24) {  // v_add_f32 with a DPP row shift and a bank mask (xor-4 / xor-8 levels)
+#define S(r) asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(r));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 25) {  // v_mov_b32 with DPP
+#define S(r, q) asm volatile("v_mov_b32_dpp %0, %1 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(r) : "v"(q));
+      REP8(S(a0, b0) S(a1, b1) S(a2, b2) S(a3, b3) S(a4, b4) S(a5, b5) S(a6, b6) S(a7, b7))
+#undef S
     } else if (KIND == 18) {  // v_fma_f32 with two literal-free inline constants (VOP3, 3 VGPR reads vs 2)
 #define S(r) asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(r) : "v"(m));
       REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
@@ -176,6 +188,9 @@ int main(int argc, char** argv) {
   run<13>("v_cndmask_b32 (dst != src)", out, blocks, iters, mhz);
   run<11>("v_fma_f32 / v_cndmask_b32 interleaved", out, blocks, iters, mhz);
   run<15>("v_cmp_lt_f32 -> vcc", out, blocks, iters, mhz);
+  run<23>("v_add_f32_dpp quad_perm", out, blocks, iters, mhz);
+  run<24>("v_add_f32_dpp row_shr:4 bank_mask", out, blocks, iters, mhz);
+  run<25>("v_mov_b32_dpp row_shl:4 bank_mask", out, blocks, iters, mhz);
   run<19>("v_cmp_lt_u64 -> vcc", out, blocks, iters, mhz);
   run<20>("v_cmp_lt_u32 -> vcc", out, blocks, iters, mhz);
   run<21>("v_addc_co_u32", out, blocks, iters, mhz);
