@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-seconds", type=float, default=240.0)
     ap.add_argument("--wrapper-cases", type=int, default=150)
+    ap.add_argument("--forward-only", action="store_true", help="skip the gradient comparison (same cases, same order)")
     a = ap.parse_args()
     import gpu_util as G
     import scenes
@@ -208,6 +209,8 @@ def main():
         if time.time() - t0 > a.max_seconds:
             break
         c = draw_case(rng)
+        if a.forward_only:
+            c["backward"] = False
         try:
             fails = run_case(c, O, G, scenes, N, dev)
         except Exception as e:  # a crash is a failure of the case, not of the sweep
