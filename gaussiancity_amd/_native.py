@@ -17,12 +17,27 @@ EXPORTED_SYMBOLS = (
     "gcr_abi_version", "gcr_last_error", "gcr_geometry_bytes", "gcr_image_bytes",
     "gcr_binning_bytes", "gcr_get_layout", "gcr_forward", "gcr_forward_preprocess", "gcr_forward_render",
     "gcr_backward", "gcr_mark_visible", "gcr_rasterize_forward", "gcr_set_option",
-    "gcr_get_stage_ms", "gcr_grad_record_floats",
+    "gcr_get_stage_ms", "gcr_grad_record_floats", "gcr_grad_record_floats_opt", "gcr_binning_bytes_lean",
+    "gcr_forward_async", "gcr_ticket_poll", "gcr_ticket_wait", "gcr_host_words_alloc", "gcr_host_words_free", "gcr_rescue_count",
 )
 GRAD_REC_FLOATS = 16  # gcr_grad_record_floats() by default (32 under option "deterministic_backward": ext asks per call)
 
 STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "ranges", "blend_fwd", "blend_bwd",
                "preprocess_bwd")
+
+
+class Options(C.Structure):
+    """gcr_options: per-call overrides of the gcr_set_option() defaults (-1 = the default)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "fast_exp", "lazy_sort", "sort_in_blend", "bwd_piece", "deterministic_backward", "split_preprocess",
+        "force_radix", "force_global_cursor")]
+
+    def __init__(self, **kw):
+        super().__init__(*([-1] * 8))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise TypeError("unknown rasterizer option %r" % k)
+            setattr(self, k, int(v))
 
 
 class Camera(C.Structure):
@@ -37,7 +52,8 @@ class Camera(C.Structure):
         ("host_camera", C.c_int32),  # bg/view/proj/campos are host pointers (copied into the kernel arguments)
         ("flip_x", C.c_int32), ("flip_y", C.c_int32),  # mirrored image store / gradient load
         ("win_x", C.c_int32), ("win_y", C.c_int32), ("win_w", C.c_int32), ("win_h", C.c_int32),  # output window
-        ("backward", C.c_int32),  # hint: a backward call will follow (sizes the forward's checkpoint pieces)
+        ("backward", C.c_int32),  # 1: a backward call will follow (the forward blend leaves its per-piece state)
+        ("options", C.POINTER(Options)),  # per-call options or NULL
     ]
 
 
@@ -72,7 +88,7 @@ class Layout(C.Structure):
         ("img_total", C.c_size_t),
         ("bin_keys", C.c_size_t * 2), ("bin_vals", C.c_size_t * 2), ("bin_hist", C.c_size_t),
         ("bin_sorted", C.c_size_t), ("bin_work", C.c_size_t), ("bin_mask", C.c_size_t), ("bin_ckpt", C.c_size_t),
-        ("bin_total", C.c_size_t),
+        ("bin_total", C.c_size_t), ("bin_lean_total", C.c_size_t),
     ]
 
 
@@ -80,7 +96,8 @@ class FrameInfo(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("max_tile_instances", C.c_int64)]
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
+TICKET_WORDS = 8  # 64-bit pinned host words per asynchronous frame (include/gcr.h, gcr_forward_async)
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 _lib = None
@@ -123,6 +140,23 @@ def lib():
     L.gcr_forward.argtypes = [C.POINTER(Camera), C.POINTER(Gaussians), C.c_void_p, C.c_size_t,
                               C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
                               C.c_void_p, C.c_void_p, C.POINTER(FrameInfo), C.c_void_p]
+    L.gcr_binning_bytes_lean.restype = C.c_size_t
+    L.gcr_binning_bytes_lean.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    L.gcr_host_words_alloc.restype = C.c_void_p
+    L.gcr_host_words_alloc.argtypes = [C.c_size_t]
+    L.gcr_host_words_free.restype = None
+    L.gcr_host_words_free.argtypes = [C.c_void_p]
+    L.gcr_forward_async.restype = C.c_int
+    L.gcr_forward_async.argtypes = [C.POINTER(Camera), C.POINTER(Gaussians), C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.gcr_ticket_poll.restype = C.c_int
+    L.gcr_ticket_poll.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.POINTER(FrameInfo)]
+    L.gcr_ticket_wait.restype = C.c_int
+    L.gcr_ticket_wait.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_void_p, C.POINTER(FrameInfo)]
+    L.gcr_rescue_count.restype = C.c_long
+    L.gcr_grad_record_floats_opt.restype = C.c_int
+    L.gcr_grad_record_floats_opt.argtypes = [C.POINTER(Options)]
     L.gcr_forward_render.restype = C.c_int
     L.gcr_forward_render.argtypes = [C.POINTER(Camera), C.POINTER(Gaussians), C.c_void_p,
                                      C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
@@ -164,15 +198,26 @@ def get_layout(P, W, H, R):
     return out
 
 
+_option_mirror = {}  # name -> last value set through set_option() (the library has no getter)
+
+
 def set_option(name, value):
-    return lib().gcr_set_option(name.encode(), int(value))
+    prev = lib().gcr_set_option(name.encode(), int(value))
+    if prev >= 0:
+        _option_mirror[name] = int(value)
+    return prev
 
 
 def get_option(name):
-    """Current value of a gcr_set_option() option (read by setting it to 0 and restoring: for tests and tools, not
-    for code that races with other threads)."""
-    prev = set_option(name, 0)
-    set_option(name, prev)
+    """Current process-wide default of a gcr_set_option() option.  Options set through this module are mirrored here;
+    one that never was is read once by setting it to 0 and restoring it (not for code that races with other threads:
+    tests and tools).  Per-call values travel in gcr_options (ext.options), not here."""
+    if name in _option_mirror:
+        return _option_mirror[name]
+    prev = lib().gcr_set_option(name.encode(), 0)
+    lib().gcr_set_option(name.encode(), prev)
+    if prev >= 0:
+        _option_mirror[name] = prev
     return prev
 
 

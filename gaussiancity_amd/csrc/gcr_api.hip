@@ -2,9 +2,14 @@
 // stage sequencing on the caller's HIP stream, error reporting, optional per-stage timing.
 // Stage order follows cr/rasterizer_impl.cu:178-283 (forward) and :287-338 (backward).
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "gcr_internal.h"
 
@@ -25,6 +30,35 @@ std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results ar
 std::atomic<int> g_k6_debug{0};  // forward blend knock-outs (gcr_blend.hip GCR_K6_*)
 std::atomic<unsigned long long*> g_clock_buf{nullptr};  // K7 per-wave phase clocks (gcr_debug_set_clock_buffer)
 #endif
+
+// One call's options: the process-wide defaults above, overridden field by field by gcr_camera.options (ABI v6).
+// Resolved once at the top of every entry point and handed down by value -- nothing below reads the globals.
+struct Opts {
+  int fast_exp, lazy_sort, sort_in_blend, bwd_piece, deterministic, split_preprocess, force_radix, force_global_cursor;
+};
+Opts resolve_options(const gcr_options* o) {
+  Opts r;
+  r.fast_exp = g_fast_exp.load();
+  r.lazy_sort = g_lazy_sort.load();
+  r.sort_in_blend = g_sort_in_blend.load();
+  r.bwd_piece = g_bwd_piece.load();
+  r.deterministic = g_deterministic.load();
+  r.split_preprocess = g_split_preprocess.load();
+  r.force_radix = g_force_radix.load();
+  r.force_global_cursor = g_force_global_cursor.load();
+  if (o != nullptr) {
+    if (o->fast_exp >= 0) r.fast_exp = o->fast_exp != 0;
+    if (o->lazy_sort >= 0) r.lazy_sort = o->lazy_sort != 0;
+    if (o->sort_in_blend >= 0) r.sort_in_blend = o->sort_in_blend != 0;
+    if (o->bwd_piece >= 0)
+      r.bwd_piece = o->bwd_piece < GCR_PIECE_MIN ? GCR_PIECE_MIN : (o->bwd_piece > GCR_PIECE_MAX ? GCR_PIECE_MAX : o->bwd_piece);
+    if (o->deterministic_backward >= 0) r.deterministic = o->deterministic_backward != 0;
+    if (o->split_preprocess >= 0) r.split_preprocess = o->split_preprocess != 0;
+    if (o->force_radix >= 0) r.force_radix = o->force_radix != 0;
+    if (o->force_global_cursor >= 0) r.force_global_cursor = o->force_global_cursor != 0;
+  }
+  return r;
+}
 
 enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PRE_BWD, ST_COUNT };
 
@@ -160,6 +194,7 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   L->bin_hist = o;     o = align_up(o + gcr_sort_hist_bytes((int64_t)r, end_bit));
   // (tile, piece) slots of the backward blend, sized for the smallest piece the option "bwd_piece" admits
   const size_t slots = r ? (size_t)gcr_piece_slots(r, T, GCR_PIECE_MIN) : 0;
+  L->bin_lean_total = o;  // a frame that never sees gcr_backward needs nothing behind this point
   L->bin_work = o;       o = align_up(o + slots * 16);
   L->bin_mask = o;       o = align_up(o + r * sizeof(uint16_t));
   L->bin_ckpt = o;       o = align_up(o + slots * (size_t)GCR_CKPT_BYTES);
@@ -209,6 +244,9 @@ void gcr_debug_set_clock_buffer(void* dev_ptr) { g_clock_buf.store((unsigned lon
 
 int gcr_abi_version(void) { return GCR_ABI_VERSION; }
 int gcr_grad_record_floats(void) { return g_deterministic.load() ? GCR_GRAD_REC_FLOATS_DET : GCR_GRAD_REC_FLOATS; }
+int gcr_grad_record_floats_opt(const gcr_options* options) {
+  return resolve_options(options).deterministic ? GCR_GRAD_REC_FLOATS_DET : GCR_GRAD_REC_FLOATS;
+}
 const char* gcr_last_error(void) { return g_err.c_str(); }
 
 size_t gcr_geometry_bytes(int32_t P) {
@@ -225,6 +263,11 @@ size_t gcr_binning_bytes(int64_t R, int32_t W, int32_t H) {
   gcr_layout L;
   compute_layout(0, W, H, R, &L);
   return L.bin_total;
+}
+size_t gcr_binning_bytes_lean(int64_t R, int32_t W, int32_t H) {
+  gcr_layout L;
+  compute_layout(0, W, H, R, &L);
+  return L.bin_lean_total;
 }
 int gcr_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* out) {
   if (!out) return fail(GCR_ERR_INVALID_ARGUMENT, "null layout");
@@ -280,7 +323,7 @@ static inline int stride_or(int32_t s, int dense) { return s > 0 ? (int)s : dens
 // Enqueues K1 + tile counting + tile scan; leaves {R, longest list, go flag} in the geometry
 // buffer (*frame_dev_out).  cap_* only influence the go flag used by speculative launches.
 // `host_R` (optional): pinned word that receives (seq << 32 | num_rendered) as soon as K1 is done.
-static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes,
+static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes,
                               void* img, size_t img_bytes, int32_t* radii, unsigned long long cap_instances,
                               unsigned long long cap_list, unsigned long long** frame_dev_out, hipStream_t s,
                               unsigned long long* host_R = nullptr, unsigned int seq = 0) {
@@ -320,12 +363,12 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
   // candidate list / counts of K1a live in the arrays only the radix fallback needs later
   a.cand_list = (uint32_t*)(gb + L.geom_tiles_touched);
   a.cand_count = (uint32_t*)(gb + L.geom_block_sums);
-  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(g_split_preprocess.load() != 0), &a.nblocks, &a.chunk);
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(op.split_preprocess != 0), &a.nblocks, &a.chunk);
   unsigned long long* frame = (unsigned long long*)(gb + L.geom_num_rendered);
   a.block_tiles = (unsigned long long*)(gb + L.geom_block_tiles);
   *frame_dev_out = frame;
   int G = 1;
-  const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, a.nblocks, &G);
+  const int NG = op.force_global_cursor ? 0 : gcr_tile_table_groups(T, a.nblocks, &G);
   uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
   uint32_t* ranges = (uint32_t*)(ib + L.img_ranges);
   if (NG > 0) {
@@ -333,7 +376,7 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
     a.tile_count = nullptr;
     {
       StageTimer t(s, ST_PRE);
-      HIP_TRY(gcr_launch_preprocess(a, g_split_preprocess.load() != 0, s), "preprocess");
+      HIP_TRY(gcr_launch_preprocess(a, op.split_preprocess != 0, s), "preprocess");
     }
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
@@ -346,7 +389,7 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
     {
       StageTimer t(s, ST_PRE);
       HIP_TRY(hipMemsetAsync(a.tile_count, 0, sizeof(uint32_t) * GCR_CURSOR_STRIDE * (size_t)T, s), "tile count memset");
-      HIP_TRY(gcr_launch_preprocess(a, g_split_preprocess.load() != 0, s), "preprocess");
+      HIP_TRY(gcr_launch_preprocess(a, op.split_preprocess != 0, s), "preprocess");
     }
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
@@ -358,18 +401,20 @@ static int enqueue_preprocess(const gcr_camera* cam, const gcr_gaussians* g, voi
 
 // Where the forward blend leaves its checkpoints (gcr_internal.h "backward pieces").  `binning` may be null when
 // nothing can be rendered (R_layout == 0): the tiles are empty then and the backward never launches its blend.
-static void set_piece_args(GcrBlendArgs& b, const gcr_camera* cam, const gcr_layout& L, void* binning, void* geom) {
-  char* bb = (char*)binning;
+static void set_piece_args(const Opts& op, GcrBlendArgs& b, bool want_state, const gcr_layout& L, void* binning,
+                           void* geom) {
+  char* bb = want_state ? (char*)binning : nullptr;  // no state: the blend runs its instantiation without it
   // Measured (tools/piece_probe.py): the backward blend balances best with 128-entry pieces (C2: 111 -> 95 us), which
   // cost the forward blend ~10 % (more staging rounds, more sentinel steps) -- so only frames announced as training
   // frames pay for them.
-  b.piece = cam->backward ? g_bwd_piece.load() : GCR_PIECE_MAX;
+  b.piece = want_state ? op.bwd_piece : GCR_PIECE_MAX;
   b.ckpt = bb ? (float4*)(bb + L.bin_ckpt) : nullptr;
   b.work = bb ? (uint4*)(bb + L.bin_work) : nullptr;
   b.mask_out = bb ? (uint16_t*)(bb + L.bin_mask) : nullptr;
   b.ckpt_off = L.bin_ckpt;
   b.work_off = L.bin_work;
   b.mask_off = L.bin_mask;
+  b.carve_bytes = L.bin_total;
   b.frame_out = (unsigned long long*)((char*)geom + L.geom_num_rendered);
 #ifdef GCR_EXPERIMENTS
   if (const char* e = getenv("GCR_K6_NOEXTRAS")) {  // A/B only: what the backward's state costs the forward blend
@@ -381,7 +426,7 @@ static void set_piece_args(GcrBlendArgs& b, const gcr_camera* cam, const gcr_lay
 
 // Enqueues scatter + per-tile LDS sort + forward blend (the default binning path).
 // `frame_guard` (device {R, max, go}) makes the three kernels no-ops when go == 0.
-static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, void* geom, void* binning, void* img,
+static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_gaussians* g, void* geom, void* binning, void* img,
                               int64_t R_layout, int64_t list_length_hint, bool speculative,
                               unsigned long long cap_instances, unsigned long long cap_list, float* out_color,
                               hipStream_t s, unsigned long long* host_longest = nullptr) {
@@ -400,9 +445,9 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   unsigned long long* frame_dev = (unsigned long long*)(gb + L.geom_num_rendered);
   const unsigned long long* frame_guard = speculative ? frame_dev : nullptr;
   int nblocks, chunk;
-  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(g_split_preprocess.load() != 0), &nblocks, &chunk);
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(op.split_preprocess != 0), &nblocks, &chunk);
   int G = 1;
-  const int NG = g_force_global_cursor.load() ? 0 : gcr_tile_table_groups(T, nblocks, &G);
+  const int NG = op.force_global_cursor ? 0 : gcr_tile_table_groups(T, nblocks, &G);
   {
     StageTimer t(s, ST_EMIT);
     if (NG > 0) {
@@ -425,8 +470,8 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   // 0.273 ms (one launch less on the critical path), but 4 870 -> 4 580 frames/s with two frames in flight (the
   // VALU-bound blend grows by 14 us, while the separate latency-bound sort kernel hides behind the other frame's
   // work) -- so it is off by default.
-  const bool sort_in_blend = R_layout > 0 && list_length_hint <= GCR_SORT_IN_BLEND_MAX && g_sort_in_blend.load() != 0;
-  uint4* lazy = (R_layout > 0 && !sort_in_blend && g_lazy_sort.load() != 0) ? (uint4*)(ib + L.img_tile_lazy) : nullptr;
+  const bool sort_in_blend = R_layout > 0 && list_length_hint <= GCR_SORT_IN_BLEND_MAX && op.sort_in_blend != 0;
+  uint4* lazy = (R_layout > 0 && !sort_in_blend && op.lazy_sort != 0) ? (uint4*)(ib + L.img_tile_lazy) : nullptr;
   if (R_layout > 0 && !sort_in_blend) {
     StageTimer t(s, ST_SORT);
     // LDS of the sort sized for 1.5x the expected longest list (longer ones take its run + merge path)
@@ -452,18 +497,18 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
   b.pairs = pairs;
   b.list_out = list;
   b.lazy = lazy;
-  set_piece_args(b, cam, L, R_layout > 0 ? binning : nullptr, geom);
+  set_piece_args(op, b, cam->backward == 1, L, R_layout > 0 ? binning : nullptr, geom);
 #ifdef GCR_EXPERIMENTS
   b.debug_flags = g_k6_debug.load();
 #endif
   {
     StageTimer t(s, ST_BLEND_FWD);
-    HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, sort_in_blend, s), "blend forward");
+    HIP_TRY(gcr_launch_blend_fwd(b, op.fast_exp != 0, sort_in_blend, s), "blend forward");
   }
   return debug_sync(cam, s, "blend forward");
 }
 
-// pinned landing zone + event for the asynchronous {R, max, go} read-back (per host thread)
+// pinned landing zone of the {R, longest list} read-back (per host thread; the synchronous entry point's own words)
 // num_rendered reaches the host WITHOUT a copy: the exact projection pass accumulates it and the first workgroup
 // of the kernel that follows stores (frame tag << 32 | R) into a pinned, coherent host word the host thread polls.  Compared with
 // the reference's blocking cudaMemcpy (cr/rasterizer_impl.cu:236) -- and with round 1's 24-byte async copy +
@@ -471,22 +516,33 @@ static int enqueue_render_lds(const gcr_camera* cam, const gcr_gaussians* g, voi
 // scatter, the sort and the blend of the frame are enqueued but still to run), and a frame costs no
 // hipMemcpyAsync / hipEventRecord / hipEventSynchronize calls.  pinned[1] receives the frame's longest tile list
 // from the scatter kernel; nobody waits for it, the next call uses it as its length hint.
+static unsigned long long* host_words_alloc(size_t n) {
+  unsigned long long* p = nullptr;
+  // Portable: the same host thread may render on another device later (ext._on_device) and that device's
+  // kernels store into the same words
+  if (n == 0 || hipHostMalloc((void**)&p, n * sizeof(unsigned long long),
+                              hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
+    return nullptr;
+  for (size_t i = 0; i < n; i++) p[i] = 0ull;
+  return p;
+}
 struct FrameReadback {
   unsigned long long* pinned = nullptr;  // [0] = seq << 32 | R, [1] = longest list of the most recent scatter
   unsigned int seq = 0;
   int ensure() {
     if (!pinned) {
-      // Portable: the same host thread may render on another device later (ext._on_device) and that device's
-      // kernels store into the same word
-      if (hipHostMalloc((void**)&pinned, 8 * sizeof(unsigned long long),
-                        hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
-        return fail(GCR_ERR_DEVICE, "hipHostMalloc for the frame read-back failed");
-      for (int i = 0; i < 8; i++) pinned[i] = 0ull;
+      pinned = host_words_alloc(8);
+      if (!pinned) return fail(GCR_ERR_DEVICE, "hipHostMalloc for the frame read-back failed");
     }
     return 0;
   }
 };
 thread_local FrameReadback g_readback;
+
+unsigned long long* gcr_host_words_alloc(size_t n_words) { return host_words_alloc(n_words); }
+void gcr_host_words_free(unsigned long long* words) {
+  if (words) (void)hipHostFree(words);
+}
 
 int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* geom,
                            size_t geom_bytes, void* img, size_t img_bytes, int32_t* radii,
@@ -496,9 +552,10 @@ int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* 
   info_host->num_rendered = 0;
   info_host->max_tile_instances = 0;
   if (g->P == 0) return 0;  // dgr/rasterize_points.cu:71
+  const Opts op = resolve_options(cam->options);
   hipStream_t s = (hipStream_t)hip_stream;
   unsigned long long* frame = nullptr;
-  if (int rc = enqueue_preprocess(cam, g, geom, geom_bytes, img, img_bytes, radii, ~0ull, ~0ull, &frame, s)) return rc;
+  if (int rc = enqueue_preprocess(op, cam, g, geom, geom_bytes, img, img_bytes, radii, ~0ull, ~0ull, &frame, s)) return rc;
   unsigned long long r[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(r, frame, sizeof(r), hipMemcpyDeviceToHost, s), "num_rendered copy");
   HIP_TRY(hipStreamSynchronize(s), "num_rendered sync");  // cr/rasterizer_impl.cu:236-238
@@ -507,6 +564,12 @@ int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* 
   info_host->num_rendered = (int64_t)r[0];
   info_host->max_tile_instances = (int64_t)r[1];
   return 0;
+}
+
+// bytes a forward needs in `binning` for `capacity` instances: the lean carve for frames that never see a backward
+static size_t forward_binning_need(const gcr_camera* cam, int64_t capacity) {
+  return cam->backward != 1 ? gcr_binning_bytes_lean(capacity, cam->img_w, cam->img_h)
+                             : gcr_binning_bytes(capacity, cam->img_w, cam->img_h);
 }
 
 int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes, void* binning,
@@ -520,25 +583,26 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
   if (!out_color) return fail(GCR_ERR_INVALID_ARGUMENT, "out_color is null");
   if (binning_capacity < 0 || binning_capacity > 0x7fffffffll)
     return fail(GCR_ERR_INVALID_ARGUMENT, "binning_capacity out of range");
-  if (binning_capacity > 0 && (!binning || binning_bytes < gcr_binning_bytes(binning_capacity, cam->img_w, cam->img_h)))
+  if (binning_capacity > 0 && (!binning || binning_bytes < forward_binning_need(cam, binning_capacity)))
     return fail(GCR_ERR_BUFFER_TOO_SMALL, "binning buffer smaller than gcr_binning_bytes(binning_capacity)");
   if (int rc = g_readback.ensure()) return rc;
+  const Opts op = resolve_options(cam->options);
   hipStream_t s = (hipStream_t)hip_stream;
-  const bool speculate = binning_capacity > 0 && !g_force_radix.load() && !cam->debug;
+  const bool speculate = binning_capacity > 0 && !op.force_radix && !cam->debug;
   // The longest-list guess only sizes the LDS of the tile sort (any length is sorted correctly), so the
   // speculation can only be vetoed by num_rendered exceeding the binning capacity.
   const int64_t list_hint = tile_list_capacity > 0 ? tile_list_capacity : (int64_t)gcr_tile_sort_capacity();
   FrameReadback& rb = g_readback;
   const unsigned int seq = ++rb.seq ? rb.seq : ++rb.seq;  // never 0: the word starts out as 0
   unsigned long long* frame = nullptr;
-  if (int rc = enqueue_preprocess(cam, g, geom, geom_bytes, img, img_bytes, radii,
+  if (int rc = enqueue_preprocess(op, cam, g, geom, geom_bytes, img, img_bytes, radii,
                                   speculate ? (unsigned long long)binning_capacity : 0ull, ~0ull, &frame, s,
                                   rb.pinned, seq))
     return rc;
   if (speculate) {
     // Everything else of the frame is enqueued before the host knows R: the kernels read the
     // tile ranges from device memory and are vetoed by frame[2] if the capacity guess was short.
-    if (int rc = enqueue_render_lds(cam, g, geom, binning, img, binning_capacity, list_hint, true,
+    if (int rc = enqueue_render_lds(op, cam, g, geom, binning, img, binning_capacity, list_hint, true,
                                     (unsigned long long)binning_capacity, ~0ull, out_color, s, rb.pinned + 1))
       return rc;
   }
@@ -576,13 +640,268 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
   return 1;  // GCR_RETRY_RENDER: call gcr_forward_render with a binning buffer sized for info_host
 }
 
+// ------------------------------------------------------------------------------------ asynchronous frames + rescue
+// gcr_forward_async (include/gcr.h): the frame is enqueued and the call returns.  What the synchronous entry point
+// does on the host when the capacity guess was short -- allocate an exactly sized buffer, render again -- is done here
+// by a RESCUE THREAD, while the frame's last kernel (k_frame_gate) holds the caller's stream: words[3] = seq is the
+// gate's call for help, words[2] = seq releases it, words[5] = seq says the rescue failed, words[6] = seq that the
+// frame was rendered by the rescue (its state is not in the caller's binning buffer).  The thread is started by the
+// first asynchronous call, sleeps while no asynchronous frame is outstanding and otherwise looks at the outstanding
+// frames' words every 100 us; a frame that fitted (the overwhelming majority: the caller's guess carries a margin)
+// leaves the list as soon as its num_rendered is known.
+struct AsyncFrame {
+  unsigned long long* words;
+  unsigned int seq;
+  int device;
+  gcr_camera cam;
+  gcr_options opt;
+  bool has_opt;
+  float camvals[38];  // view 16 | proj 16 | campos 3 | bg 3 when cam.host_camera (the caller's host arrays may be gone)
+  gcr_gaussians g;
+  void* geom;
+  size_t geom_bytes;
+  void* img;
+  size_t img_bytes;
+  float* out_color;
+  int64_t capacity;
+  std::chrono::steady_clock::time_point born;
+};
+
+class RescueService {
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<AsyncFrame> frames_;
+  bool started_ = false;
+  hipStream_t streams_[64] = {};
+  void* scratch_[64] = {};        // per device: the rescue's binning buffer, kept from one rescue to the next (grow only)
+  size_t scratch_bytes_[64] = {};
+  std::atomic<long> rescued_{0};
+
+  static void publish(unsigned long long* w, int idx, unsigned int seq) {
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    ((volatile unsigned long long*)w)[idx] = (unsigned long long)seq;
+  }
+
+  void rescue(AsyncFrame& f) {
+    volatile unsigned long long* w = f.words;
+    const unsigned long long R = w[0] & 0xffffffffull;
+    bool ok = false;
+    void* stale = nullptr;  // a scratch buffer that was too small: freed AFTER the gate is released (hipFree waits for
+    //                         every stream of the device, the caller's -- which the gate is holding -- included)
+    do {
+      if (R > 0x7fffffffull) break;
+      if (hipSetDevice(f.device) != hipSuccess) break;
+      const int d = f.device & 63;
+      if (!streams_[d] && hipStreamCreateWithFlags(&streams_[d], hipStreamNonBlocking) != hipSuccess) break;
+      hipStream_t s = streams_[d];
+      gcr_camera cam = f.cam;
+      cam.backward = 0;  // the temporary buffer dies with the rescue: no backward state (gcr_forward_render with
+      //                    out_color == NULL rebuilds it in a buffer of the caller's when a backward follows)
+      cam.options = f.has_opt ? &f.opt : nullptr;
+      if (cam.host_camera) {
+        cam.view_matrix = f.camvals;
+        cam.proj_matrix = f.camvals + 16;
+        cam.campos = f.camvals + 32;
+        cam.bg = f.camvals + 35;
+      }
+      gcr_layout L;
+      compute_layout(f.g.P, cam.img_w, cam.img_h, 0, &L);
+      gcr_frame_info info;
+      info.num_rendered = (int64_t)R;
+      unsigned long long longest = 0;
+      if (hipMemcpyAsync(&longest, (char*)f.geom + L.geom_num_rendered + 8, 8, hipMemcpyDeviceToHost, s) != hipSuccess) break;
+      if (hipStreamSynchronize(s) != hipSuccess) break;
+      info.max_tile_instances = (int64_t)longest;
+      const size_t bytes = gcr_binning_bytes_lean((int64_t)R, cam.img_w, cam.img_h);
+      if (scratch_bytes_[d] < bytes) {
+        stale = scratch_[d];
+        scratch_[d] = nullptr;
+        scratch_bytes_[d] = 0;
+        if (hipMalloc(&scratch_[d], bytes + bytes / 2) != hipSuccess) {
+          scratch_[d] = nullptr;
+          break;
+        }
+        scratch_bytes_[d] = bytes + bytes / 2;
+      }
+      if (gcr_forward_render(&cam, &f.g, f.geom, f.geom_bytes, scratch_[d], scratch_bytes_[d], f.img, f.img_bytes, &info,
+                             f.out_color, s) < 0)
+        break;
+      if (hipStreamSynchronize(s) != hipSuccess) break;
+      ok = true;
+    } while (false);
+    if (!ok) publish(f.words, 5, f.seq);
+    publish(f.words, 6, f.seq);
+    publish(f.words, 2, f.seq);  // releases the gate
+    rescued_.fetch_add(1);
+    if (stale) (void)hipFree(stale);
+  }
+
+  void run() {
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return !frames_.empty(); });
+      const auto now = std::chrono::steady_clock::now();
+      for (auto it = frames_.begin(); it != frames_.end();) {
+        volatile unsigned long long* w = it->words;
+        const unsigned long long v = w[0];
+        if ((unsigned int)(v >> 32) == it->seq) {
+          if ((v & 0xffffffffull) <= (unsigned long long)it->capacity) {  // fitted: its gate lets the stream pass
+            it = frames_.erase(it);
+            continue;
+          }
+          if ((unsigned int)w[3] == it->seq) {  // the gate is holding the stream: every kernel of the frame is done
+            AsyncFrame f = *it;
+            frames_.erase(it);
+            lk.unlock();
+            rescue(f);
+            lk.lock();
+            break;  // iterators are gone: rescan on the next round
+          }
+        } else if (now - it->born > std::chrono::seconds(120)) {  // a frame whose stream died: stop looking at it
+          it = frames_.erase(it);
+          continue;
+        }
+        ++it;
+      }
+      lk.unlock();
+      std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+  }
+
+ public:
+  void add(const AsyncFrame& f) {
+    std::lock_guard<std::mutex> lk(mu_);
+    // the caller reuses a word set only for a frame whose ticket it has resolved: an older entry on the same words is
+    // finished (or abandoned)
+    for (auto it = frames_.begin(); it != frames_.end();) it = it->words == f.words ? frames_.erase(it) : it + 1;
+    frames_.push_back(f);
+    if (!started_) {
+      started_ = true;
+      std::thread([this] { run(); }).detach();
+    }
+    cv_.notify_one();
+  }
+  long rescued() const { return rescued_.load(); }
+};
+// never destroyed: the detached thread may outlive static destruction at process exit
+static RescueService& rescue_service() {
+  static RescueService* r = new RescueService();
+  return *r;
+}
+
+long gcr_rescue_count(void) { return rescue_service().rescued(); }  // diagnostics: frames that needed the rescue so far
+
+int gcr_forward_async(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes, void* binning,
+                      size_t binning_bytes, int64_t binning_capacity, int64_t tile_list_capacity, void* img,
+                      size_t img_bytes, int32_t* radii, float* out_color, unsigned long long* words_host, uint32_t seq,
+                      void* hip_stream) {
+  if (int rc = check_inputs(cam, g)) return rc;
+  if (!words_host || seq == 0u) return fail(GCR_ERR_INVALID_ARGUMENT, "words_host must be non-null and seq non-zero");
+  if (g->P == 0) {  // dgr/rasterize_points.cu:71: nothing to do; the ticket resolves to 0 at once
+    ((volatile unsigned long long*)words_host)[1] = 0ull;
+    ((volatile unsigned long long*)words_host)[0] = (unsigned long long)seq << 32;
+    return 0;
+  }
+  if (!out_color) return fail(GCR_ERR_INVALID_ARGUMENT, "out_color is null");
+  const Opts op = resolve_options(cam->options);
+  if (binning_capacity <= 0 || binning_capacity > 0x7fffffffll || op.force_radix || cam->debug)
+    return fail(GCR_ERR_INVALID_ARGUMENT,
+                "gcr_forward_async needs a capacity guess > 0 and neither force_radix nor debug: use gcr_forward");
+  if (!binning || binning_bytes < forward_binning_need(cam, binning_capacity))
+    return fail(GCR_ERR_BUFFER_TOO_SMALL, "binning buffer smaller than gcr_binning_bytes(binning_capacity)");
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int64_t list_hint = tile_list_capacity > 0 ? tile_list_capacity : (int64_t)gcr_tile_sort_capacity();
+  unsigned long long* frame = nullptr;
+  if (int rc = enqueue_preprocess(op, cam, g, geom, geom_bytes, img, img_bytes, radii, (unsigned long long)binning_capacity,
+                                  ~0ull, &frame, s, words_host, seq))
+    return rc;
+  if (int rc = enqueue_render_lds(op, cam, g, geom, binning, img, binning_capacity, list_hint, true,
+                                  (unsigned long long)binning_capacity, ~0ull, out_color, s, words_host + 1))
+    return rc;
+  AsyncFrame f;
+  memset((void*)&f, 0, sizeof(f));
+  f.words = words_host;
+  f.seq = seq;
+  if (hipGetDevice(&f.device) != hipSuccess) f.device = 0;
+  f.cam = *cam;
+  f.has_opt = cam->options != nullptr;
+  if (f.has_opt) f.opt = *cam->options;
+  f.cam.options = nullptr;
+  if (cam->host_camera) {
+    memcpy(f.camvals, cam->view_matrix, 16 * sizeof(float));
+    memcpy(f.camvals + 16, cam->proj_matrix, 16 * sizeof(float));
+    memcpy(f.camvals + 32, cam->campos, 3 * sizeof(float));
+    memcpy(f.camvals + 35, cam->bg, 3 * sizeof(float));
+  }
+  f.g = *g;
+  f.geom = geom;
+  f.geom_bytes = geom_bytes;
+  f.img = img;
+  f.img_bytes = img_bytes;
+  f.out_color = out_color;
+  f.capacity = binning_capacity;
+  f.born = std::chrono::steady_clock::now();
+  rescue_service().add(f);
+  // about two seconds of polling before a gate gives up (~5 us per poll: a PCIe round trip + two s_sleep 127)
+  HIP_TRY(gcr_launch_frame_gate(frame, words_host, seq, 400000u, s), "frame gate");
+  return 0;
+}
+
+static int ticket_state(const unsigned long long* words_host, uint32_t seq, int64_t capacity, gcr_frame_info* info) {
+  volatile const unsigned long long* w = words_host;
+  const unsigned long long v = w[0];
+  if ((unsigned int)(v >> 32) != seq) return 1;
+  const unsigned long long R = v & 0xffffffffull;
+  if (R > 0x7fffffffull)
+    return fail(GCR_ERR_OVERFLOW, "num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)");
+  if (R > (unsigned long long)capacity) {  // the frame needed the rescue: resolved when that is complete
+    if ((unsigned int)w[5] == seq) return fail(GCR_ERR_DEVICE, "the overflow rescue of an asynchronous frame failed");
+    if ((unsigned int)w[2] != seq) {
+      if ((unsigned int)w[4] == seq)
+        return fail(GCR_ERR_DEVICE, "an asynchronous frame overflowed its binning buffer and was not rescued in time");
+      return 1;
+    }
+  }
+  if (info) {
+    info->num_rendered = (int64_t)R;
+    info->max_tile_instances = (int64_t)w[1];
+  }
+  return 0;
+}
+
+int gcr_ticket_poll(const unsigned long long* words_host, uint32_t seq, int64_t binning_capacity,
+                    gcr_frame_info* info_host) {
+  if (!words_host || seq == 0u) return fail(GCR_ERR_INVALID_ARGUMENT, "words_host must be non-null and seq non-zero");
+  return ticket_state(words_host, seq, binning_capacity, info_host);
+}
+
+int gcr_ticket_wait(const unsigned long long* words_host, uint32_t seq, int64_t binning_capacity, void* hip_stream,
+                    gcr_frame_info* info_host) {
+  if (!words_host || seq == 0u) return fail(GCR_ERR_INVALID_ARGUMENT, "words_host must be non-null and seq non-zero");
+  hipStream_t s = (hipStream_t)hip_stream;
+  for (unsigned long spins = 0;; ) {
+    const int st = ticket_state(words_host, seq, binning_capacity, info_host);
+    if (st != 1) return st;
+    gcr_cpu_relax();
+    if ((++spins & 0xfffffu) == 0 && hip_stream != nullptr) {  // every ~1M polls: is the stream still alive?
+      const hipError_t q = hipStreamQuery(s);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail_hip(q, "ticket wait");
+      if (q == hipSuccess && ticket_state(words_host, seq, binning_capacity, info_host) == 1)
+        return fail(GCR_ERR_DEVICE, "the stream finished without publishing num_rendered");
+    }
+  }
+}
+
 int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes,
                        void* binning, size_t binning_bytes, void* img, size_t img_bytes,
                        const gcr_frame_info* info, float* out_color, void* hip_stream) {
-  if (int rc = check_inputs(cam, g)) return rc;
+  // (binning, sort and blend read the geometry state K1 left, none of the Gaussians' input arrays: a backward that
+  // re-renders a frame's state has no opacities to hand in, cr/rasterizer.h:39-48)
+  if (int rc = check_inputs(cam, g, false)) return rc;
   if (g->P == 0) return 0;
-  if (!geom || !img || !out_color || !info)
-    return fail(GCR_ERR_INVALID_ARGUMENT, "geom/img/out_color/info must be non-null");
+  if (!geom || !img || !info) return fail(GCR_ERR_INVALID_ARGUMENT, "geom/img/info must be non-null");
+  if (!out_color && cam->backward != 1)
+    return fail(GCR_ERR_INVALID_ARGUMENT, "out_color may only be NULL for a state-only pass (gcr_camera.backward == 1)");
   const int64_t R = info->num_rendered;
   if (R < 0 || R > 0x7fffffffll) return fail(GCR_ERR_INVALID_ARGUMENT, "R out of range");
   if (R > 0 && !binning) return fail(GCR_ERR_INVALID_ARGUMENT, "binning buffer is null");
@@ -590,12 +909,14 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   compute_layout(g->P, cam->img_w, cam->img_h, R, &L);
   if (geom_bytes < L.geom_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "geometry buffer too small");
   if (img_bytes < L.img_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "image buffer too small");
-  if (R > 0 && binning_bytes < L.bin_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "binning buffer too small");
+  if (R > 0 && binning_bytes < (cam->backward == 1 ? L.bin_total : L.bin_lean_total))
+    return fail(GCR_ERR_BUFFER_TOO_SMALL, "binning buffer too small");
+  const Opts op = resolve_options(cam->options);
   hipStream_t s = (hipStream_t)hip_stream;
   // Tile lists beyond the LDS sort capacity are sorted by the same workgroup with runs + merge passes; every
   // other tile stays on the LDS path (no whole-frame fallback for a long list).
-  if (R == 0 || !g_force_radix.load())
-    return enqueue_render_lds(cam, g, geom, binning, img, R, info->max_tile_instances, false, ~0ull, ~0ull, out_color, s);
+  if (R == 0 || !op.force_radix)
+    return enqueue_render_lds(op, cam, g, geom, binning, img, R, info->max_tile_instances, false, ~0ull, ~0ull, out_color, s);
 
   // "force_radix" (A/B and test option): the reference's own scheme -- emit tile|depth keys in index
   // order, stable global radix sort, boundary scan.
@@ -609,7 +930,7 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   const uint32_t* vis_list = (const uint32_t*)(gb + L.geom_vis_list);
   const uint32_t* vis_count = (const uint32_t*)(gb + L.geom_vis_count);
   int nblocks, chunk;
-  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(g_split_preprocess.load() != 0), &nblocks, &chunk);
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(op.split_preprocess != 0), &nblocks, &chunk);
   uint64_t* k0 = (uint64_t*)(bb + L.bin_keys[0]);
   uint64_t* k1 = (uint64_t*)(bb + L.bin_keys[1]);
   uint32_t* v0 = (uint32_t*)(bb + L.bin_vals[0]);
@@ -649,10 +970,10 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   b.final_T = (float*)(ib + L.img_final_T);
   b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
   b.out_color = out_color;
-  set_piece_args(b, cam, L, binning, geom);
+  set_piece_args(op, b, cam->backward == 1, L, binning, geom);
   {
     StageTimer t(s, ST_BLEND_FWD);
-    HIP_TRY(gcr_launch_blend_fwd(b, g_fast_exp.load() != 0, false, s), "blend forward");
+    HIP_TRY(gcr_launch_blend_fwd(b, op.fast_exp != 0, false, s), "blend forward");
   }
   return debug_sync(cam, s, "blend forward");
 }
@@ -681,20 +1002,27 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   if (any_grad_stride && (!gr->packed || gr->packed_floats <= 0))
     return fail(GCR_ERR_INVALID_ARGUMENT, "strided gradient outputs need the block they live in (gcr_grads.packed)");
   if (R < 0 || R > 0x7fffffffll) return fail(GCR_ERR_INVALID_ARGUMENT, "R out of range");
+  if (cam->backward != 1)
+    return fail(GCR_ERR_INVALID_ARGUMENT,
+                "gcr_backward needs a frame rendered with gcr_camera.backward == 1 (pass the same value here); for a frame "
+                "rendered without it call gcr_forward_render(out_color = NULL, backward = 1) first");
   gcr_layout L;
   compute_layout(g->P, cam->img_w, cam->img_h, R, &L);
   if (geom_bytes < L.geom_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "geometry buffer too small");
   if (img_bytes < L.img_total) return fail(GCR_ERR_BUFFER_TOO_SMALL, "image buffer too small");
+  // (the forward may have carved the buffer for a larger capacity: the blend kernel checks the carve the forward
+  // published against binning_bytes on the device and poisons the gradients instead of reading out of bounds)
   if (R > 0 && (!binning || binning_bytes < L.bin_total))
     return fail(GCR_ERR_BUFFER_TOO_SMALL, "binning buffer too small");
+  const Opts op = resolve_options(cam->options);
   hipStream_t s = (hipStream_t)hip_stream;
   const char *gb = (const char*)geom, *bb = (const char*)binning, *ib = (const char*)img;
   const int gx = (cam->img_w + GCR_BLOCK_X - 1) / GCR_BLOCK_X;
   const int gy = (cam->img_h + GCR_BLOCK_Y - 1) / GCR_BLOCK_Y;
   int nblocks_k1 = 0, chunk_k1 = 0;
-  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(g_split_preprocess.load() != 0), &nblocks_k1, &chunk_k1);
+  gcr_preprocess_grid(g->P, gcr_preprocess_resident_blocks(op.split_preprocess != 0), &nblocks_k1, &chunk_k1);
 
-  const int det = g_deterministic.load();  // the caller sized dL_dconic with gcr_grad_record_floats() under the same option
+  const int det = op.deterministic;  // the caller sized dL_dconic with gcr_grad_record_floats_opt() under the same options
 
   // Every output is written here (the reference asks its caller for nine zero-filled tensors,
   // dgr/rasterize_points.cu:118-126): zeros are streamed over the dense arrays by extra workgroups of the K7
@@ -749,11 +1077,7 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     b.bg = cam->bg;
     b.flip_x = cam->flip_x != 0; b.flip_y = cam->flip_y != 0;
     b.win_x = cam->win_x; b.win_y = cam->win_y; b.win_w = cam->win_w; b.win_h = cam->win_h;
-  b.win_x = cam->win_x; b.win_y = cam->win_y; b.win_w = cam->win_w; b.win_h = cam->win_h;
     fill_cam(b.cam, cam);
-  b.flip_x = cam->flip_x != 0; b.flip_y = cam->flip_y != 0;
-  b.win_x = cam->win_x; b.win_y = cam->win_y; b.win_w = cam->win_w; b.win_h = cam->win_h;
-  fill_cam(b.cam, cam);
     b.final_T = (float*)(ib + L.img_final_T);
     b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
     b.dL_dpix = dL_dpix;
@@ -762,12 +1086,13 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     b.binning_base = bb;
     b.frame_in = (const unsigned long long*)(gb + L.geom_num_rendered);
     b.R = (unsigned long long)R;
-    b.piece = g_bwd_piece.load();  // sizes the grid only: the kernel takes the forward's piece size from frame_in
+    b.piece = op.bwd_piece;  // sizes the grid only: the kernel takes the forward's piece size from frame_in
+    b.binning_bytes = (unsigned long long)binning_bytes;
 #ifdef GCR_EXPERIMENTS
     b.debug_flags = g_k7_skip_flush.load();  // bit 0: no global flush, bit 1: no zero fill, bit 2: no LDS adds
     b.clock_buf = g_clock_buf.load();
 #endif
-    HIP_TRY(gcr_launch_blend_bwd(b, g_fast_exp.load() != 0, s), "blend backward");
+    HIP_TRY(gcr_launch_blend_bwd(b, op.fast_exp != 0, s), "blend backward");
   } else {
     HIP_TRY(gcr_launch_fill(fill, s), "gradient zero fill");
   }
@@ -787,6 +1112,8 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   a.vis_list = (const uint32_t*)(gb + L.geom_vis_list);
   a.vis_count = (const uint32_t*)(gb + L.geom_vis_count);
   a.nblocks = nblocks_k1; a.chunk = chunk_k1;
+  a.frame = R > 0 ? (const unsigned long long*)(gb + L.geom_num_rendered) : nullptr;
+  a.binning_bytes = (unsigned long long)binning_bytes;
   a.grad_rec = (const float4*)gr->dL_dconic;
   a.deterministic = det;
   a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dcolor = gr->dL_dcolors; a.dL_dopacity = gr->dL_dopacity;

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
         frame[0] = total;
         frame[1] = 0ull;
         frame[2] = 0ull;
+        frame[GCR_FRAME_PIECE] = 0ull;  // no backward state yet (set by a forward blend that writes it)
         if (host_word != nullptr)
           gcr_store_to_host(host_word, ((unsigned long long)seq << 32) | (total > 0xffffffffull ? 0xffffffffull : total));
       }
@@ -533,7 +534,74 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint64_t* __restrict_
   if (idx == R - 1) ranges[2 * currtile + 1] = (uint32_t)R;
 }
 
+// The radix path leaves an untouched tile at (0, 0) (cr/rasterizer_impl.cu:262-264 zeroes `ranges` first), which is all
+// the reference's blend needs.  The backward pieces of this build address their slots as floor(start / P) + tile
+// (gcr_internal.h), which needs CONTIGUOUS ranges: an empty tile must sit at (e, e) with e = the end of the last
+// non-empty tile before it -- what the tile-table path produces by construction.  One workgroup, running prefix
+// maximum of the range ends (they are non-decreasing over the non-empty tiles).
+__global__ __launch_bounds__(256) void k_ranges_make_contiguous(uint32_t* __restrict__ ranges, int T) {
+  __shared__ uint32_t wmax[4];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0u;
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 256) {
+    const int t = t0 + tid;
+    const uint32_t r0 = t < T ? ranges[2 * t] : 0u, r1 = t < T ? ranges[2 * t + 1] : 0u;
+    uint32_t v = r1;  // inclusive prefix maximum of the ends over the 256 tiles of this round
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(v, o, 64);
+      if (lane >= o) v = u > v ? u : v;
+    }
+    if (lane == 63) wmax[w] = v;
+    __syncthreads();
+    uint32_t before = carry_s;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < w) before = wmax[k] > before ? wmax[k] : before;
+    const uint32_t incl = v > before ? v : before;
+    // end of the last non-empty tile strictly before t
+    uint32_t prev = __shfl_up(incl, 1, 64);
+    if (lane == 0) prev = before;
+    if (t < T && r0 == r1) {
+      ranges[2 * t] = prev;
+      ranges[2 * t + 1] = prev;
+    }
+    __syncthreads();
+    if (tid == 255) carry_s = incl;
+    __syncthreads();
+  }
+}
+
+// Last kernel of an ASYNCHRONOUS frame (gcr_forward_async, include/gcr.h), one wave.  A frame that fitted its binning
+// buffer: the go flag is set, return -- the stream goes on.  A frame the scatter kernel vetoed (num_rendered larger
+// than the caller's capacity guess): nothing was rendered; tell the host (words[3] = seq) and hold the stream until the
+// library's rescue thread has rendered the frame with an exactly sized buffer on its own stream (words[2] = seq), so
+// that everything the caller enqueued behind this frame sees the finished image.  The wait is bounded (about two
+// seconds): a gate that gives up says so in words[4] and the ticket resolves to an error instead of a hung device.
+__global__ __launch_bounds__(64) void k_frame_gate(const unsigned long long* __restrict__ frame,
+                                                   unsigned long long* __restrict__ words, unsigned int seq,
+                                                   unsigned int max_polls) {
+  if (threadIdx.x != 0) return;
+  if (frame[2] != 0ull) return;
+  gcr_store_to_host(words + 3, (unsigned long long)seq);
+  for (unsigned int i = 0; i < max_polls; i++) {
+    const unsigned long long v = __hip_atomic_load(words + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned int)v == seq) return;
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
+  }
+  gcr_store_to_host(words + 4, (unsigned long long)seq);
+}
+
 }  // namespace
+
+hipError_t gcr_launch_frame_gate(const unsigned long long* frame, unsigned long long* words, unsigned int seq,
+                                 unsigned int max_polls, hipStream_t s) {
+  k_frame_gate<<<1, 64, 0, s>>>(frame, words, seq, max_polls);
+  return hipGetLastError();
+}
 
 hipError_t gcr_launch_emit(int P, const uint32_t* tiles_touched, const uint32_t* block_offsets,
                            const float4* rec, int gx, uint64_t* keys, uint32_t* vals,
@@ -738,5 +806,6 @@ hipError_t gcr_launch_tile_ranges(const uint64_t* keys, int64_t R, uint32_t* ran
   if (e != hipSuccess) return e;
   if (R <= 0) return hipSuccess;
   k_tile_ranges<<<(unsigned)((R + 255) / 256), 256, 0, s>>>(keys, R, ranges);
+  k_ranges_make_contiguous<<<1, 256, 0, s>>>(ranges, T);
   return hipGetLastError();
 }

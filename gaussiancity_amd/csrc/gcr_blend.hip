@@ -161,7 +161,12 @@ __device__ __noinline__ uint32_t k6_lazy_extend(uint64_t* s, const uint64_t* key
 // amdgpu_waves_per_eu(7, 8): the call above constrains the register assignment (what lives across it must sit in
 // callee-saved registers) and the allocator, left alone, ends at 78 VGPRs = six waves per SIMD; told to fit seven, it
 // finds a 71-register assignment without a spill and with the blend steps unchanged instruction for instruction.
-template <bool FAST_EXP, bool SORT>
+//
+// STATE (template): the backward's per-piece state -- checkpoints at the piece boundaries, work items, the block mask
+// of every staged entry -- is written only by frames rendered with gcr_camera.backward == 1.  Every other frame (the
+// headline inference workload) runs the instantiation without a single instruction of it; gcr_backward on such a
+// frame regenerates the state with one more pass of this kernel (a.out_color == nullptr: no pixel is stored).
+template <bool FAST_EXP, bool SORT, bool STATE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_blend_fwd(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[CHUNK + 1];
   __shared__ uint32_t sMask[CHUNK];
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
   if (!gcr_tile_in_window(a, tx, ty)) {
     // none of this tile's pixels is wanted (gcr_camera.win_*): nothing to blend, and no work for the backward either
-    if (a.work != nullptr) {
+    if (STATE && a.work != nullptr) {
       const uint32_t P0 = (uint32_t)a.piece, sb = r0 / P0 + (uint32_t)tile, ns = r1 / P0 + 1u - r0 / P0;
       for (uint32_t k = tid; k < ns; k += 256u) a.work[sb + k] = make_uint4(GCR_NO_TILE, 0u, 0u, 0u);
       if (tile == 0 && tid == 0) {
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         a.frame_out[GCR_FRAME_CKPT_OFF] = a.ckpt_off;
         a.frame_out[GCR_FRAME_WORK_OFF] = a.work_off;
         a.frame_out[GCR_FRAME_MASK_OFF] = a.mask_off;
+        a.frame_out[GCR_FRAME_CARVE] = a.carve_bytes;
       }
     }
     return;
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     if (!SORT && lz_sorted < (uint32_t)(base + min(cs, total - base))) break;  // sort on, then come back
     // crossing a piece boundary: checkpoint of the per-pixel state for the backward (|Tw| = T; a finished pixel's
     // checkpoint is never read).  256 x 16 bytes, one coalesced 4 KB store per boundary.
-    if (entered > 0u && a.ckpt != nullptr) {
+    if (STATE && entered > 0u && a.ckpt != nullptr) {
       // (the thread index is re-read behind an opaque barrier so that the store's address arithmetic is done here and
       // does not sit in registers across the walk: 76 -> 71 VGPRs, seven waves per SIMD again)
       uint32_t t_op = threadIdx.x;
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
       sE[tid].c = make_float4(q2.x, pmin, 0.0f, 0.0f);
     }
     sMask[tid] = my_mask;
-    if (tid < n && a.mask_out != nullptr) a.mask_out[r0 + base + tid] = (uint16_t)my_mask;  // reused by the backward
+    if (STATE && tid < n && a.mask_out != nullptr) a.mask_out[r0 + base + tid] = (uint16_t)my_mask;  // reused by the backward
     __syncthreads();
     if (__ballot(Tw > 0.0f) == 0ull) continue;  // this wave's quadrant is finished; keep voting
     // compact the chunk into this wave's four row lists (ascending list order is preserved)
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   int tid_end = threadIdx.x;
   asm volatile("" : "+v"(tid_end));
   const LaneGeom g = lane_geom(tid_end, tx, ty);
-  if (g.pxi < a.W && g.pyi < a.H) {
+  if (g.pxi < a.W && g.pyi < a.H && (!STATE || a.out_color != nullptr)) {  // (state-only pass: pixels already stored)
     const float Tout = __builtin_fabsf(Tw);
     const size_t pix_id = (size_t)a.W * g.pyi + g.pxi;
     a.final_T[pix_id] = Tout;
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
       a.out_color[2 * oplane + out_id] = C2 + Tout * GCR_CAM(a, bg, a.bg, 2);
     }
   }
-  if (a.work != nullptr) {
+  if (STATE && a.work != nullptr) {
     // a tile that crossed a boundary also leaves its final colour (without background) in its last slot: a
     // backward piece that starts from a checkpoint needs C_final - C_prefix
     if (entered >= 2u)
@@ -412,11 +418,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     for (uint32_t k = tid; k < nslots; k += 256u)
       a.work[sbase + k] = k < entered ? make_uint4((uint32_t)tile, r0, (uint32_t)total, k) : make_uint4(GCR_NO_TILE, 0u, 0u, 0u);
   }
-  if (a.work != nullptr && tile == 0 && tid == 0) {
+  if (STATE && a.work != nullptr && tile == 0 && tid == 0) {
     a.frame_out[GCR_FRAME_PIECE] = piece_P;
     a.frame_out[GCR_FRAME_CKPT_OFF] = a.ckpt_off;
     a.frame_out[GCR_FRAME_WORK_OFF] = a.work_off;
     a.frame_out[GCR_FRAME_MASK_OFF] = a.mask_off;
+    a.frame_out[GCR_FRAME_CARVE] = a.carve_bytes;
   }
 }
 
@@ -579,8 +586,10 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
   unsigned long long clk[GCR_K7_NCLK] = {};
 #endif
   GCR_K7_CLK(0)
+  // a frame rendered without the backward's state (gcr_camera.backward == 0), or whose carve does not fit the buffer
+  // this call was handed: nothing to walk -- the preprocess gradient kernel turns the survivors' gradients into NaN
+  if (!gcr_frame_has_state(a.frame_in, a.binning_bytes)) return;
   const uint32_t piece_P = (uint32_t)a.frame_in[GCR_FRAME_PIECE];
-  if (piece_P == 0u) return;
   // (slot, quadrant) units: every slot of the forward's piece grid holds a work item or GCR_NO_TILE
   const unsigned long long nunits = 4ull * gcr_piece_slots(a.R, (unsigned long long)(a.gx * a.gy), piece_P);
   const float4* __restrict__ ckpt = reinterpret_cast<const float4*>(a.binning_base + a.frame_in[GCR_FRAME_CKPT_OFF]);
@@ -772,19 +781,27 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
 
 }  // namespace
 
+template <bool FAST_EXP, bool SORT>
+static void launch_blend_fwd_state(const GcrBlendArgs& a, int T, hipStream_t s) {
+  if (a.work != nullptr)  // the backward's state is wanted (gcr_camera.backward == 1, or gcr_backward's regeneration pass)
+    k_blend_fwd<FAST_EXP, SORT, true><<<T, 256, 0, s>>>(a);
+  else
+    k_blend_fwd<FAST_EXP, SORT, false><<<T, 256, 0, s>>>(a);
+}
+
 hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool fast_exp, bool sort_in_kernel, hipStream_t s) {
   const int T = a.gx * a.gy;
   if (T <= 0) return hipSuccess;
   if (sort_in_kernel) {
     if (fast_exp)
-      k_blend_fwd<true, true><<<T, 256, 0, s>>>(a);
+      launch_blend_fwd_state<true, true>(a, T, s);
     else
-      k_blend_fwd<false, true><<<T, 256, 0, s>>>(a);
+      launch_blend_fwd_state<false, true>(a, T, s);
   } else {
     if (fast_exp)
-      k_blend_fwd<true, false><<<T, 256, 0, s>>>(a);
+      launch_blend_fwd_state<true, false>(a, T, s);
     else
-      k_blend_fwd<false, false><<<T, 256, 0, s>>>(a);
+      launch_blend_fwd_state<false, false>(a, T, s);
   }
   return hipGetLastError();
 }

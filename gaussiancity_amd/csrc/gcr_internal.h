@@ -73,6 +73,8 @@ struct GcrPreprocessBwdArgs {
   const uint32_t *vis_list, *vis_count;  // K1's per-block survivor lists
   int nblocks, chunk;
   const float4* grad_rec;  // K7's per-Gaussian accumulation records (GCR_GRAD_REC_FLOATS each)
+  const unsigned long long* frame;  // device frame words (null when nothing was rendered): a frame without backward
+  unsigned long long binning_bytes; //   state, or one whose carve exceeds the buffer handed in, gets NaN gradients
   float *dL_dmean2D, *dL_dcolor, *dL_dopacity;  // written here from the records (API outputs)
   float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
   int deterministic;                            // grad_rec holds fixed-point records (GCR_GRAD_REC_FLOATS_DET)
@@ -140,6 +142,13 @@ static inline __host__ __device__ unsigned long long gcr_piece_slots(unsigned lo
 #define GCR_FRAME_CKPT_OFF 4
 #define GCR_FRAME_WORK_OFF 5
 #define GCR_FRAME_MASK_OFF 7  // byte offset of the per-instance block masks (uint16, sorted-list order)
+#define GCR_FRAME_CARVE 6     // bytes of the binning buffer as the forward carved it (for ITS capacity): a backward
+                              // that is handed a smaller buffer must not follow the offsets above
+// Has the forward left the backward's state in a buffer of `binning_bytes`?  (frame word 3 is zeroed by the count
+// kernel of every frame and set by a forward blend that writes the state.)
+static inline __host__ __device__ bool gcr_frame_has_state(const unsigned long long* frame, unsigned long long binning_bytes) {
+  return frame[GCR_FRAME_PIECE] != 0ull && frame[GCR_FRAME_CARVE] <= binning_bytes;
+}
 
 struct GcrBlendArgs {
   const uint32_t* ranges;  // [T][2]
@@ -169,6 +178,8 @@ struct GcrBlendArgs {
   unsigned long long mask_off;     // fwd: its byte offset in the binning buffer (published in the frame words)
   unsigned long long* frame_out;   // fwd: device frame words; [3..7] published by the first tile
   unsigned long long ckpt_off, work_off;  // fwd: what it publishes (byte offsets in the binning buffer)
+  unsigned long long carve_bytes;         // fwd: ... and the size of the carve they belong to
+  unsigned long long binning_bytes;       // bwd: size of the buffer behind binning_base
   const char* binning_base;        // bwd: checkpoints / work list are found through the frame words
   const unsigned long long* frame_in;  // bwd
   uint4* lazy;                     // fwd: [T] lazy-sort states (gcr_sort.h) of lists the blend may have to sort on, or null
@@ -186,6 +197,9 @@ hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, bool split, hipStre
 hipError_t gcr_launch_zero_grad_records(int nblocks, int chunk, const uint32_t* vis_list, const uint32_t* vis_count,
                                         float4* grad_rec, int rec_quads, hipStream_t s);
 hipError_t gcr_launch_fill(const GcrFillArgs& f, hipStream_t s);
+// last kernel of an asynchronous frame (gcr_binning.hip k_frame_gate)
+hipError_t gcr_launch_frame_gate(const unsigned long long* frame, unsigned long long* words, unsigned int seq,
+                                 unsigned int max_polls, hipStream_t s);
 hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long long* total,
                                       hipStream_t s);
 // fallback binning: per-Gaussian tile counts from radii + record rect, then emit in index order

@@ -763,6 +763,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ curs
     frame[0] = total;
     frame[1] = mm;
     frame[2] = (total <= cap_instances && (unsigned long long)mm <= cap_list) ? 1ull : 0ull;
+    frame[GCR_FRAME_PIECE] = 0ull;  // no backward state yet (set by a forward blend that writes it)
   }
 }
 
@@ -785,6 +786,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
   }
 #pragma unroll
   for (int i = 0; i < 3; i++) cp[i] = gcr_uniform(GCR_CAM(a, campos, a.campos, i));
+  // gcr_backward on a frame whose forward left no backward state (gcr_camera.backward == 0), or whose state does not
+  // fit the buffer handed in: the blend gradient kernel did nothing -- say so with NaN, never with plausible zeros
+  const bool poison = a.frame != nullptr && !gcr_frame_has_state(a.frame, a.binning_bytes);
   const uint32_t nvis = a.vis_count[blockIdx.x];
   const uint32_t* __restrict__ my_list = a.vis_list + (size_t)blockIdx.x * a.chunk;
   for (uint32_t it = threadIdx.x; it < nvis; it += 256) {
@@ -835,6 +839,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
     g0 = make_float4(f[0], f[1], f[2], f[3]);
     g1 = make_float4(f[4], f[5], f[6], f[7]);
     g2 = make_float4(f[8], 0.0f, 0.0f, 0.0f);
+  }
+  if (poison) {
+    const float nan = __builtin_nanf("");
+    g0 = make_float4(nan, nan, nan, nan);
+    g1 = g0;
+    g2 = g0;
   }
   const float dcx = g1.z, dcy = g1.w, dcz = g2.x;
   a.dL_dmean2D[3 * (size_t)idx] = g1.x;

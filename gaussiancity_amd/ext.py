@@ -25,9 +25,11 @@ NUM_CHANNELS = 3  # cr/config.h:15
 # allocated for 1.5x that before the frame starts, which lets gcr_forward enqueue the whole frame
 # without a mid-frame host stall.  A wrong guess only costs the staged path for that frame.
 # Bounded (least recently used first out): a training loop whose point count changes every step
-# would otherwise grow the table without limit.
+# would otherwise grow the table without limit.  One table per process, read and written under a lock: the frame
+# loop may be driven by several host threads (bench.py --host-threads, nn.DataParallel-style callers, core/test.py:41).
 _CAPACITY_HINT_MAX = 64
 _capacity_hint = collections.OrderedDict()
+_hint_lock = threading.Lock()
 
 
 # Debug aid (the GPU tests switch it on): hand gcr_backward NaN-filled outputs instead of whatever the caching
@@ -46,18 +48,148 @@ def set_backward_hint(flag):
 
 
 def _hint_get(key):
-    v = _capacity_hint.get(key)
-    if v is None:
-        return 0, 0
-    _capacity_hint.move_to_end(key)
-    return v
+    """(num_rendered, longest tile list) of the most recent resolved frame with this key, or (0, 0)."""
+    with _hint_lock:
+        v = _capacity_hint.get(key)
+        if v is None:
+            return 0, 0
+        _capacity_hint.move_to_end(key)
+        return v
 
 
 def _hint_put(key, value):
-    _capacity_hint[key] = value
-    _capacity_hint.move_to_end(key)
-    while len(_capacity_hint) > _CAPACITY_HINT_MAX:
-        _capacity_hint.popitem(last=False)
+    with _hint_lock:
+        _capacity_hint[key] = value
+        _capacity_hint.move_to_end(key)
+        while len(_capacity_hint) > _CAPACITY_HINT_MAX:
+            _capacity_hint.popitem(last=False)
+
+
+# ---- per-call options (gcr_options, ABI v6) ---------------------------------------------------------------------------
+class options:
+    """`with ext.options(fast_exp=1, bwd_piece=64): ...` -- the native calls of THIS thread inside the block carry these
+    gcr_options (include/gcr.h); other threads, and the process-wide defaults of gcr_set_option, are untouched.  The
+    forward and the backward of a frame must run under the same options."""
+
+    def __init__(self, **kw):
+        self.opt = N.Options(**kw)
+        self.prev = None
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "options", None)
+        _tls.options = self.opt
+        return self
+
+    def __exit__(self, *a):
+        _tls.options = self.prev
+        return False
+
+
+def _current_options():
+    return getattr(_tls, "options", None)
+
+
+# ---- asynchronous frames: num_rendered as a ticket (gcr_forward_async) ------------------------------------------------
+# The reference returns num_rendered as a Python int, which blocks its caller in every frame until K1 + the scan have
+# run (cr/rasterizer_impl.cu:236-238) -- although nothing in GaussianCity's Python looks at the number except the
+# backward of the same frame (dgr/__init__.py:404-420).  The autograd functions of gaussiancity_amd.rasterizer therefore
+# take a FrameTicket instead: the whole frame is enqueued, the call returns, and the number is read from a pinned host
+# word when (if) somebody asks for it -- int(ticket), or the backward.  rasterize_gaussians() itself keeps the reference's
+# contract and returns an int.
+_RING = 32  # asynchronous frames a host thread may have outstanding (the ring's oldest ticket is waited for first)
+# capacity guess of an asynchronous frame from the newest num_rendered this thread has seen for the same (device, P, W,
+# H): the host runs ahead of the device, so that number may be a few frames old -- twice it, plus a constant
+_ASYNC_FACTOR, _ASYNC_MARGIN = 2, 65536
+
+
+class FrameTicket:
+    """Lazy num_rendered of one frame.  int(ticket) / ticket.wait() block until the device has published it (and, for a
+    frame that overflowed its capacity guess, until the library's rescue has re-rendered it); .done() never blocks."""
+
+    __slots__ = ("words", "addr", "seq", "capacity", "stream", "key", "stateful", "_R", "_longest", "_lib")
+
+    def __init__(self, lib, words, addr, seq, capacity, stream, key, stateful, R=None, longest=0):
+        self._lib, self.words, self.addr, self.seq, self.capacity = lib, words, addr, seq, capacity
+        self.stream, self.key, self.stateful = stream, key, stateful
+        self._R, self._longest = R, longest
+
+    def _resolve(self, block):
+        if self._R is not None:
+            return True
+        v = self.words[0]
+        if (v >> 32) != self.seq or (v & 0xFFFFFFFF) > self.capacity:  # not yet / overflow: the library's protocol
+            info = N.FrameInfo()
+            if block:
+                rc = N.check(self._lib.gcr_ticket_wait(self.addr, self.seq, self.capacity, self.stream, C.byref(info)),
+                             "gcr_ticket_wait")
+            else:
+                rc = N.check(self._lib.gcr_ticket_poll(self.addr, self.seq, self.capacity, C.byref(info)), "gcr_ticket_poll")
+            if rc != 0:
+                return False
+            self._R, self._longest = int(info.num_rendered), int(info.max_tile_instances)
+        else:
+            if (v & 0xFFFFFFFF) > 0x7FFFFFFF:
+                raise RuntimeError("num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)")
+            self._R, self._longest = int(v & 0xFFFFFFFF), int(self.words[1])
+        if self.key is not None and self._R > 0:
+            _hint_put(self.key, (self._R, self._longest))
+        self.words = None  # the ring slot may be reused
+        return True
+
+    def done(self):
+        return self._resolve(False)
+
+    def wait(self):
+        self._resolve(True)
+        return self._R
+
+    @property
+    def rescued(self):
+        """True when the frame did not fit its binning buffer: the image is right (the library re-rendered it), the
+        binning state in the caller's buffer is not -- a backward re-bins first (rasterize_*_backward do)."""
+        return self.wait() > self.capacity
+
+    __int__ = wait
+    __index__ = wait
+
+    def __repr__(self):
+        return "FrameTicket(%s)" % (self._R if self._R is not None else "pending")
+
+
+class _TicketRing:
+    """Per host thread: _RING sets of eight pinned host words (gcr_host_words_alloc) handed out round-robin."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.base = lib.gcr_host_words_alloc(N.TICKET_WORDS * _RING)
+        if not self.base:
+            raise RuntimeError("gcr_host_words_alloc failed (pinned host memory for the frame tickets)")
+        self.words = [(C.c_uint64 * N.TICKET_WORDS).from_address(self.base + 8 * N.TICKET_WORDS * i) for i in range(_RING)]
+        self.tickets = [None] * _RING
+        self.next = 0
+        self.seq = 0
+
+    def take(self):
+        i = self.next
+        self.next = (i + 1) % _RING
+        old = self.tickets[i]
+        if old is not None:
+            old.wait()  # back-pressure: at most _RING frames of this thread are unresolved
+        self.seq = (self.seq % 0xFFFFFFFE) + 1  # never 0
+        return i, self.words[i], self.base + 8 * N.TICKET_WORDS * i, self.seq
+
+    def harvest(self):
+        """Resolve whatever has been published (never blocks): keeps the capacity hints fresh."""
+        for t in self.tickets:
+            if t is not None and t._R is None:
+                t.done()
+
+
+def _ring(lib):
+    r = getattr(_tls, "ring", None)
+    if r is None:
+        r = _tls.ring = _TicketRing(lib)
+    return r
 
 
 def _dev_f32(t, name, device):
@@ -100,6 +232,10 @@ def _camera(device, bg, view, proj, campos, tan_fovx, tan_fovy, H, W, scale_modi
     cam.flip_x = int(bool(flip_x))
     cam.flip_y = int(bool(flip_y))
     cam.backward = int(bool(for_backward))
+    opt = _current_options()
+    if opt is not None:
+        cam.options = C.pointer(opt)
+        keep.append(opt)
     if window is not None:  # (x, y, w, h) of the mirrored image: gcr_camera.win_*
         cam.win_x, cam.win_y, cam.win_w, cam.win_h = (int(v) for v in window)
     return cam, keep
@@ -157,35 +293,126 @@ class _on_device:
         return False
 
 
-def _forward(L, device, cam, g, P, H, W):
-    """gcr_forward (+ the staged retry) with torch-owned buffers; returns the reference's six-tuple."""
+_size_cache = {}  # (P,) / (W, H) -> gcr_geometry_bytes / gcr_image_bytes: pure functions, two ctypes calls saved per frame
+
+# What the backward must know about the frame it is handed and the reference's signature has no room for: was the
+# forward rendered WITH the backward's state (gcr_camera.backward), and did it fit its binning buffer?  Keyed by the
+# geometry buffer's address -- the buffer is alive from the forward to the backward of a frame, so its entry is this
+# frame's; a later forward that gets the same block overwrites it.  Bounded, locked.
+_FRAME_META_MAX = 512
+_frame_meta = collections.OrderedDict()
+_meta_lock = threading.Lock()
+
+
+def _meta_put(geom, stateful, ticket_or_R, longest):
+    with _meta_lock:
+        _frame_meta[geom.data_ptr()] = (stateful, ticket_or_R, longest)
+        _frame_meta.move_to_end(geom.data_ptr())
+        while len(_frame_meta) > _FRAME_META_MAX:
+            _frame_meta.popitem(last=False)
+
+
+def _meta_get(geom):
+    with _meta_lock:
+        return _frame_meta.get(geom.data_ptr())
+
+
+def _forward(L, device, cam, g, P, H, W, ticket=False):
+    """One frame with torch-owned buffers; returns the reference's six-tuple.
+
+    ticket=False: gcr_forward (+ the staged retry) -- the first element is num_rendered as an int, which costs the one
+    host wait of the frame (the reference's contract).  ticket=True: gcr_forward_async -- the first element is a
+    FrameTicket and the call returns as soon as the frame is enqueued; the first frames of a (device, P, W, H) key, whose
+    num_rendered cannot be guessed yet, and the debug / force_radix modes take the synchronous path and come back with
+    a resolved ticket."""
     byte = dict(dtype=torch.uint8, device=device)
+    stateful = cam.backward == 1
     # every pixel / every radius is written by the kernels, so no zero-fill launches are needed
     out_color = torch.empty((NUM_CHANNELS, cam.win_h, cam.win_w) if cam.win_w else (NUM_CHANNELS, H, W),
                             dtype=torch.float32, device=device)
     radii = torch.empty((P,), dtype=torch.int32, device=device)
     stream = _stream(device)
-    geom = torch.empty((L.gcr_geometry_bytes(P),), **byte)
-    img = torch.empty((L.gcr_image_bytes(W, H),), **byte)
-    info = N.FrameInfo()
+    gbytes = _size_cache.get(P)
+    if gbytes is None:
+        gbytes = _size_cache[P] = L.gcr_geometry_bytes(P)
+    ibytes = _size_cache.get((W, H))
+    if ibytes is None:
+        ibytes = _size_cache[(W, H)] = L.gcr_image_bytes(W, H)
+    if len(_size_cache) > 256:
+        _size_cache.clear()
+    geom = torch.empty((gbytes,), **byte)
+    img = torch.empty((ibytes,), **byte)
     key = (device.index, P, W, H)
-    capacity, list_cap = _hint_get(key)
-    binning = torch.empty((L.gcr_binning_bytes(capacity, W, H) if capacity else 0,), **byte)
-    rc = N.check(L.gcr_forward(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
+    ring = None
+    if ticket:
+        ring = _ring(L)
+        ring.harvest()
+    R_seen, list_cap = _hint_get(key)
+    nbytes = L.gcr_binning_bytes if stateful else L.gcr_binning_bytes_lean
+    opt = _current_options()
+    if ticket and R_seen > 0 and not cam.debug and not (opt.force_radix > 0 if opt is not None
+                                                         else N.get_option("force_radix")):
+        # The guess is made from a frame that may be several frames old (the host runs ahead of the device): twice its
+        # num_rendered.  A frame that still does not fit is rendered correctly by the library's rescue (include/gcr.h).
+        capacity = _ASYNC_FACTOR * R_seen + _ASYNC_MARGIN
+        binning = torch.empty((nbytes(capacity, W, H),), **byte)
+        slot, words, addr, seq = ring.take()
+        N.check(L.gcr_forward_async(C.byref(cam), C.byref(g), geom.data_ptr(), gbytes, binning.data_ptr(), binning.numel(),
+                                    capacity, list_cap, img.data_ptr(), ibytes, radii.data_ptr(), out_color.data_ptr(),
+                                    addr, seq, stream),
+                "gcr_forward_async")
+        t = FrameTicket(L, words, addr, seq, capacity, stream, key, stateful)
+        ring.tickets[slot] = t
+        _meta_put(geom, stateful, t, list_cap)
+        return t, out_color, radii, geom, binning, img
+    info = N.FrameInfo()
+    capacity = R_seen + R_seen // 2 + 4096 if R_seen > 0 else 0
+    binning = torch.empty((nbytes(capacity, W, H) if capacity else 0,), **byte)
+    rc = N.check(L.gcr_forward(C.byref(cam), C.byref(g), geom.data_ptr(), gbytes,
                                binning.data_ptr() if capacity else None, binning.numel(), capacity,
-                               list_cap, img.data_ptr(), img.numel(), radii.data_ptr(), out_color.data_ptr(),
+                               list_cap, img.data_ptr(), ibytes, radii.data_ptr(), out_color.data_ptr(),
                                C.byref(info), stream),
                  "gcr_forward")
     R = int(info.num_rendered)
     if rc == 1:  # GCR_RETRY_RENDER: no/too small a guess, or a tile list beyond the LDS sort
-        binning = torch.empty((L.gcr_binning_bytes(R, W, H),), **byte)
-        N.check(L.gcr_forward_render(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(),
+        capacity = R
+        binning = torch.empty((nbytes(R, W, H),), **byte)
+        N.check(L.gcr_forward_render(C.byref(cam), C.byref(g), geom.data_ptr(), gbytes,
                                      binning.data_ptr(), binning.numel(), img.data_ptr(),
-                                     img.numel(), C.byref(info), out_color.data_ptr(), stream),
+                                     ibytes, C.byref(info), out_color.data_ptr(), stream),
                 "gcr_forward_render")
     longest = int(info.max_tile_instances)
-    _hint_put(key, (R + R // 2 + 4096, longest))  # the library adds its own margin to the longest list
+    _hint_put(key, (R, longest))  # the library adds its own margin to the longest list
+    _meta_put(geom, stateful, R, longest)
+    if ticket:
+        R = FrameTicket(L, None, None, 0, max(capacity, R), stream, None, stateful, R=R, longest=longest)
     return R, out_color, radii, geom, binning, img
+
+
+def _state_for_backward(L, device, cam, g, geom, binning, img, R, W, H):
+    """What gcr_backward needs besides the arguments of the reference: num_rendered as an int, and a binning buffer that
+    holds the forward blend's per-piece state.  A frame that was rendered as an inference frame (gcr_camera.backward
+    == 0) or that overflowed its capacity guess (FrameTicket.rescued) is binned again, state only, into an exactly
+    sized buffer -- rare paths, both pinned by tests.  Returns (R, binning)."""
+    meta = _meta_get(geom)
+    stateful, longest = True, 0
+    if isinstance(R, FrameTicket):
+        t, R = R, R.wait()
+        stateful, longest = t.stateful and not t.rescued, t._longest
+    elif meta is not None and not isinstance(meta[1], FrameTicket) and int(meta[1]) == int(R):
+        stateful, longest = meta[0], meta[2]
+    elif meta is not None and isinstance(meta[1], FrameTicket) and meta[1].wait() == int(R):
+        stateful, longest = meta[0] and not meta[1].rescued, meta[1]._longest
+    R = int(R)
+    if stateful or R == 0:
+        return R, binning
+    binning = torch.empty((L.gcr_binning_bytes(R, W, H),), dtype=torch.uint8, device=device)
+    info = N.FrameInfo(R, int(longest))
+    N.check(L.gcr_forward_render(C.byref(cam), C.byref(g), geom.data_ptr(), geom.numel(), binning.data_ptr(),
+                                 binning.numel(), img.data_ptr(), img.numel(), C.byref(info), None, _stream(device)),
+            "gcr_forward_render (state only)")
+    return R, binning
+
 
 
 def _empty_frame(device, H, W):
@@ -196,20 +423,22 @@ def _empty_frame(device, H, W):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
-                        image_width, sh, degree, campos, prefiltered, debug, _for_backward=None):
+                        image_width, sh, degree, campos, prefiltered, debug, _for_backward=None, _ticket=False):
     """RasterizeGaussiansCUDA (dgr/rasterize_points.cu:37-93, dgr/rasterize_points.h:18-28).
 
     Returns (num_rendered:int, out_color[3,H,W], radii[P] int32, geomBuffer, binningBuffer,
     imgBuffer) -- the three buffers are opaque uint8 tensors to be handed back to
     rasterize_gaussians_backward.
 
-    `_for_backward` (keyword, not part of the reference's positional signature above) is a pure performance hint:
-    None = what set_backward_hint() announced for this thread (RasterizeGaussiansFunction does, when an input requires
-    a gradient).  The forward blend then leaves its checkpoints in the smaller pieces the backward balances best with
-    (gcr_camera.backward).
+    `_for_backward` (keyword, not part of the reference's positional signature above) never changes a result: True
+    (the default -- whoever calls this function may call the backward next, as the reference's autograd function does) =
+    the forward blend leaves the backward's per-piece state behind (gcr_camera.backward); False = an inference frame,
+    which does not pay for a backward it never runs (rasterize_gaussians_backward still works on such a frame: it bins
+    it again, state only).  None = what set_backward_hint() announced for this thread, else True.
     """
-    if _for_backward is None:
-        _for_backward = getattr(_tls, "backward", False)
+    if _for_backward is None:  # the reference's contract: whoever calls this may call the backward next
+        _for_backward = getattr(_tls, "backward", None)
+        _for_backward = True if _for_backward is None else _for_backward
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if not means3D.is_cuda:
@@ -218,15 +447,24 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     device = means3D.device
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
     if P == 0:
-        return _empty_frame(device, H, W)
+        e = _empty_frame(device, H, W)
+        return ((FrameTicket(L, None, None, 0, 0, None, None, False, R=0),) + e[1:]) if _ticket else e
     with _on_device(device):
         cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
                               tan_fovy, H, W, scale_modifier, degree, prefiltered, debug, _for_backward)
         g, keep_g = _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations,
                                cov3D_precomp)
-        out = _forward(L, device, cam, g, P, H, W)
+        out = _forward(L, device, cam, g, P, H, W, _ticket)
         del keep_c, keep_g
     return out
+
+
+def rasterize_gaussians_ticket(*args, _for_backward=False):
+    """rasterize_gaussians() without the host wait: same arguments, same six-tuple, but the first element is a
+    FrameTicket (int(ticket) blocks until the number is known) and the call returns as soon as the frame is enqueued.
+    What gaussiancity_amd.rasterizer's autograd functions call: the reference's Python never looks at num_rendered
+    except in the backward of the same frame (dgr/__init__.py:85-108)."""
+    return rasterize_gaussians(*args, _for_backward=_for_backward, _ticket=True)
 
 
 # ---- GaussianCity's own call shape: points [N,14] = xyz(3) opacity(1) scale(3) rotation(4) rgb(3) ---------------------
@@ -255,7 +493,7 @@ def _points14_gaussians(points):
 
 
 def rasterize_points14(points, background, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
-                       image_width, campos, flip_x=False, flip_y=False, for_backward=False, window=None):
+                       image_width, campos, flip_x=False, flip_y=False, for_backward=False, window=None, ticket=False):
     """Forward of GaussianRasterizerWrapper's call shape on the [N,14] tensor in place (precomputed colours, SH degree
     0).  Same six-tuple as rasterize_gaussians; the image comes out already mirrored if flip_x / flip_y ask for it, and
     as the `window` = (x, y, w, h) of that mirrored image if one is given (tiles outside it are not blended)."""
@@ -264,11 +502,12 @@ def rasterize_points14(points, background, scale_modifier, viewmatrix, projmatri
     device = pts.device
     P, H, W = int(pts.size(0)), int(image_height), int(image_width)
     if P == 0:
-        return _empty_frame(device, *((window[3], window[2]) if window is not None else (H, W)))
+        e = _empty_frame(device, *((window[3], window[2]) if window is not None else (H, W)))
+        return ((FrameTicket(L, None, None, 0, 0, None, None, False, R=0),) + e[1:]) if ticket else e
     with _on_device(device):
         cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W,
                               scale_modifier, 0, False, False, for_backward, flip_x, flip_y, window)
-        out = _forward(L, device, cam, g, P, H, W)
+        out = _forward(L, device, cam, g, P, H, W, ticket)
         del keep_c, pts
     return out
 
@@ -292,7 +531,8 @@ def rasterize_points14_backward(points, radii, background, scale_modifier, viewm
     if poison_outputs:
         grad.fill_(float("nan"))
     # scratch the API wants besides: accumulation records [P,16] (64-byte aligned), dL_dmeans2D [P,3], dL_dcov3D [P,6]
-    nrec = int(L.gcr_grad_record_floats())  # 16, or 32 under option "deterministic_backward"
+    opt = _current_options()
+    nrec = int(L.gcr_grad_record_floats_opt(C.byref(opt) if opt is not None else None))  # 16, or 32 in the deterministic mode
     flat = torch.empty((P * (nrec + 3 + 6) + 64,), dtype=torch.float32, device=device)
     if poison_outputs:
         flat.fill_(float("nan"))
@@ -301,8 +541,9 @@ def rasterize_points14_backward(points, radii, background, scale_modifier, viewm
     c3d = flat[P * (nrec + 3):P * (nrec + 9)]
     with _on_device(device):
         cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W,
-                              scale_modifier, 0, False, False, False, flip_x, flip_y, window)
+                              scale_modifier, 0, False, False, True, flip_x, flip_y, window)
         dpix, dpix_ptr = _dev_f32(dL_dout_color, "dL_dout_color", device)
+        R, binningBuffer = _state_for_backward(L, device, cam, g, geomBuffer, binningBuffer, imageBuffer, R, W, H)
         gb = grad.data_ptr()
         col = {k: gb + 4 * v for k, v in _POINT_COLUMNS.items()}
         grads = N.Grads(m2d.data_ptr(), rec.data_ptr(), col["opacities"], col["colors"], col["means3D"], c3d.data_ptr(),
@@ -325,7 +566,8 @@ def _gradient_buffers(P, M, device):
     of ONE uninitialised buffer: gcr_backward writes every element of every output itself (include/gcr.h).
     dL_dconic is the native side's accumulation scratch: one 64-byte record per Gaussian.
     Order: dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations."""
-    nrec = int(N.lib().gcr_grad_record_floats())  # 16, or 32 under option "deterministic_backward"
+    opt = _current_options()
+    nrec = int(N.lib().gcr_grad_record_floats_opt(C.byref(opt) if opt is not None else None))  # 16, or 32 (deterministic)
     shapes = ((P, 3), (P, 3), (P, NUM_CHANNELS), (P, nrec), (P, 1), (P, 6), (P, M, 3), (P, 3), (P, 4))
     sizes = [int(torch.Size(sh).numel()) for sh in shapes]
     starts, off = [], 0
@@ -358,7 +600,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if P != 0:
         with _on_device(device):
             cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
-                                  tan_fovy, H, W, scale_modifier, degree, False, debug)  # (flips: see rasterize_points14)
+                                  tan_fovy, H, W, scale_modifier, degree, False, debug, True)  # (flips: see rasterize_points14)
             # opacity is not an input of the backward (it is read from the geometry state)
             g, keep_g = _gaussians(device, P, means3D, None, sh, colors, scales, rotations,
                                    cov3D_precomp)
@@ -371,6 +613,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                             dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
                             dL_drotations.data_ptr())
             gb, bb, ib = geomBuffer.contiguous(), binningBuffer.contiguous(), imageBuffer.contiguous()
+            R, bb = _state_for_backward(L, device, cam, g, gb, bb, ib, R, W, H)
             N.check(L.gcr_backward(C.byref(cam), C.byref(g), radii_c.data_ptr(), gb.data_ptr(),
                                    gb.numel(), bb.data_ptr() if bb.numel() else None, bb.numel(),
                                    ib.data_ptr(), ib.numel(), int(R), dpix_ptr, C.byref(grads),

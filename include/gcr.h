@@ -14,6 +14,9 @@
  *                                  callbacks become C callbacks)
  * gcr_forward                      the same forward with every launch enqueued before the host
  *                                  learns num_rendered (no GPU idle gap at the sync)
+ * gcr_forward_async                the same forward WITHOUT the host wait: num_rendered arrives later in a
+ *                                  pinned word of the caller's (callers that never look at it -- the Python
+ *                                  API discards it, dgr/__init__.py:404-420 -- enqueue frame after frame)
  * gcr_forward_preprocess +         the same forward split at its one host sync
  *   gcr_forward_render             (cr/rasterizer_impl.cu:236-238) so the caller allocates
  *                                  the binning buffer itself (dgr/rasterize_points.cu:27-33)
@@ -42,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GCR_ABI_VERSION 5
+#define GCR_ABI_VERSION 6
 #define GCR_BLOCK_X 16 /* cr/config.h:16 */
 #define GCR_BLOCK_Y 16 /* cr/config.h:17 */
 #define GCR_NUM_CHANNELS 3 /* cr/config.h:15 */
@@ -56,13 +59,32 @@ typedef enum gcr_status {
   GCR_ERR_ALLOC = -5             /* a resize callback returned NULL */
 } gcr_status;
 
+/* Per-call options (ABI v6).  Every field: -1 = the process-wide default (gcr_set_option), >= 0 = this call's value.
+ * The reference's entry points are re-entrant and carry no global state (dgr/rasterize_points.cu:37-93); with this
+ * record two host threads can render with different options at the same time.  The forward and the backward of one
+ * frame must be given the same values (as with the process-wide knobs).  Meanings: see gcr_set_option below. */
+typedef struct gcr_options {
+  int32_t fast_exp;
+  int32_t lazy_sort;
+  int32_t sort_in_blend;
+  int32_t bwd_piece;
+  int32_t deterministic_backward;
+  int32_t split_preprocess;
+  int32_t force_radix;
+  int32_t force_global_cursor;
+} gcr_options;
+#define GCR_OPTIONS_DEFAULT {-1, -1, -1, -1, -1, -1, -1, -1}
+
 /* GaussianRasterizationSettings (dgr/__init__.py:203-215) */
 typedef struct gcr_camera {
   int32_t img_h, img_w;
   float tanfovx, tanfovy;
   float scale_modifier;
   int32_t sh_degree;   /* active degree D, 0..3 */
-  int32_t prefiltered; /* accepted for API parity; culled points are simply skipped */
+  int32_t prefiltered; /* accepted and IGNORED.  Upstream it only arms a diagnostic (cr/auxiliary.h:148-152: a device
+                          printf + trap when a point the caller declared pre-culled fails the near-plane test); the
+                          result of a frame never depends on it, and GaussianCity always passes False
+                          (dgr/__init__.py:399).  Here culled points are skipped silently either way */
   int32_t debug;       /* !=0: synchronise + check after every stage (cr/auxiliary.h:158) */
   const float *bg;          /* [3] */
   const float *view_matrix; /* [16] */
@@ -79,9 +101,15 @@ typedef struct gcr_camera {
                           blended nor walked by the backward (their pixels would be cropped away / have zero gradient:
                           GaussianCity renders 960x540 and keeps a 640x448 crop, utils/helpers.py:255-260).  radii,
                           num_rendered and the binning state are those of the full frame.  0: the whole image */
-  int32_t backward;    /* hint, never changes a result: !=0 = gcr_backward will be called on this frame's state (the
-                          forward blend then cuts its tile lists into the smaller pieces the backward balances best
-                          with, option "bwd_piece"); 0 = inference (256-entry pieces: gcr_backward still works) */
+  int32_t backward;    /* never changes the image.  Forward calls: 1 = gcr_backward WILL be called on this frame: the forward
+                          blend cuts its tile lists into the pieces the backward balances best with (option "bwd_piece")
+                          and leaves the backward's per-piece state (checkpoints, work items, block masks) in the binning
+                          buffer.  0 = inference: no such state is written (the headline workload does not pay for a
+                          backward it never runs) and the binning buffer may be the smaller gcr_binning_bytes_lean().
+                          gcr_backward needs a frame rendered with 1: on a frame rendered with 0 the gradients of every
+                          rendered Gaussian come out as NaN (never as plausible zeros) -- render its state first with
+                          gcr_forward_render(out_color = NULL, backward = 1) into a gcr_binning_bytes() buffer */
+  const gcr_options *options; /* HOST pointer or NULL (= all defaults); read during the call only */
 } gcr_camera;
 
 /* Per-Gaussian inputs (argument list of cr/rasterizer.h:25-37) */
@@ -170,6 +198,7 @@ typedef struct gcr_layout {
   size_t bin_ckpt;      /* 4096 B per slot: per-pixel (T, prefix colour) at the piece boundaries the forward
                            blend crossed -- what lets the backward blend start in the middle of a tile list */
   size_t bin_total;
+  size_t bin_lean_total; /* everything in front of bin_work: all a frame with gcr_camera.backward == 0 uses */
 } gcr_layout;
 
 /* Host-side summary of K1+K2, produced by gcr_forward_preprocess and consumed by
@@ -186,6 +215,9 @@ const char *gcr_last_error(void);
 size_t gcr_geometry_bytes(int32_t P);
 size_t gcr_image_bytes(int32_t W, int32_t H);
 size_t gcr_binning_bytes(int64_t R, int32_t W, int32_t H);
+/* binning buffer of a frame that will never see gcr_backward (gcr_camera.backward == 0): sorted list, keys and the
+ * radix fallback's scratch only -- 24 B per instance instead of ~90 */
+size_t gcr_binning_bytes_lean(int64_t R, int32_t W, int32_t H);
 int gcr_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout *out);
 
 /* K1 (project, cov2D, SH colour, tile rect, per-tile instance counts) + K2 (scan of the tile
@@ -220,17 +252,59 @@ int gcr_forward(const gcr_camera *cam, const gcr_gaussians *g, void *geom, size_
                 int64_t tile_list_capacity, void *img, size_t img_bytes, int32_t *radii,
                 float *out_color, gcr_frame_info *info_host, void *hip_stream);
 
+/* gcr_forward without the host wait (ABI v6).  The reference blocks its caller in every frame until it has read
+ * num_rendered back (cr/rasterizer_impl.cu:236-238), although its Python callers never look at the number
+ * (dgr/__init__.py:404-420 keeps it for the backward only).  Here the whole frame is enqueued and the call returns;
+ * the host thread goes on to enqueue the next frames while this one runs.
+ *   words_host  eight 64-bit words of pinned host memory from gcr_host_words_alloc(), owned by the caller and not
+ *               reused for another frame before this one's ticket is resolved (gcr_ticket_wait / _poll):
+ *                 [0] <- (seq << 32 | min(num_rendered, 2^32 - 1)), stored by the device as soon as K1 is done
+ *                 [1] <- the frame's longest tile list (a hint for the next frame's tile_list_capacity)
+ *                 [2..7] protocol words of the overflow rescue below
+ *   seq         a non-zero tag of the caller's choice that tells this frame's store from an earlier one's
+ *   binning_capacity  > 0: the caller's guess of num_rendered; `binning` holds gcr_binning_bytes(binning_capacity)
+ *               (gcr_binning_bytes_lean(binning_capacity) suffices when cam->backward == 0)
+ * When num_rendered turns out larger than binning_capacity the frame is still rendered correctly, IN STREAM ORDER:
+ * the frame ends with a one-wave gate kernel that returns at once for a frame that fitted and otherwise holds the
+ * stream until a rescue thread of the library (started by the first asynchronous call) has rendered the frame on a
+ * stream of its own with a temporary, exactly sized binning buffer (hipMalloc / hipFree, the one place the library
+ * allocates device memory) -- so whatever the caller enqueued behind the frame sees the right image.  The state of
+ * such a frame is NOT in the caller's `binning` buffer: before gcr_backward, call gcr_forward_render with
+ * out_color == NULL and a buffer of gcr_binning_bytes(num_rendered).  Until the ticket is resolved the caller keeps
+ * geom / img / radii / out_color and the Gaussians' arrays alive or releases them stream-ordered on `hip_stream`
+ * (torch's caching allocator does): the rescue reads them while the gate holds that stream.
+ * Returns 0, or < 0 on an argument / launch error (nothing useful was enqueued). */
+unsigned long long *gcr_host_words_alloc(size_t n_words); /* pinned, coherent, zero-filled; NULL on failure */
+void gcr_host_words_free(unsigned long long *words);
+int gcr_forward_async(const gcr_camera *cam, const gcr_gaussians *g, void *geom, size_t geom_bytes,
+                      void *binning, size_t binning_bytes, int64_t binning_capacity,
+                      int64_t tile_list_capacity, void *img, size_t img_bytes, int32_t *radii,
+                      float *out_color, unsigned long long *words_host, uint32_t seq, void *hip_stream);
+/* Resolve an asynchronous frame's ticket.  _poll never blocks: 0 = resolved (*info_host filled: num_rendered exact,
+ * max_tile_instances = the longest list seen so far or 0), 1 = not yet.  _wait blocks (spinning, with a liveness
+ * check of `hip_stream` when non-NULL) until the frame has published num_rendered and -- for a frame that needed the
+ * rescue -- until the rescue is complete.  Both return GCR_ERR_OVERFLOW / GCR_ERR_DEVICE when the frame failed. */
+int gcr_ticket_poll(const unsigned long long *words_host, uint32_t seq, int64_t binning_capacity,
+                    gcr_frame_info *info_host);
+int gcr_ticket_wait(const unsigned long long *words_host, uint32_t seq, int64_t binning_capacity,
+                    void *hip_stream, gcr_frame_info *info_host);
+long gcr_rescue_count(void); /* diagnostics: asynchronous frames of this process that needed the rescue so far */
+
 /* K3 (instance emit) + K4 (depth sort inside every tile, ties in ascending Gaussian index ==
  * the reference's stable radix sort by tile|depth) + K5 (tile ranges) + K6 (blend).
- * out_color is [3,H,W].  *info must be what gcr_forward_preprocess returned. */
+ * out_color is [3,H,W].  *info must be what gcr_forward_preprocess returned.
+ * out_color == NULL (ABI v6): state only -- binning, sort and the forward blend's walk with cam->backward == 1, no
+ * pixel is stored: what gcr_backward needs after an asynchronous frame overflowed its binning buffer. */
 int gcr_forward_render(const gcr_camera *cam, const gcr_gaussians *g, void *geom,
                        size_t geom_bytes, void *binning, size_t binning_bytes, void *img,
                        size_t img_bytes, const gcr_frame_info *info, float *out_color,
                        void *hip_stream);
 
 /* K7 (reverse-walk blend gradient) + K8 (preprocess gradient). dL_dpix is [3,H,W]. */
-/* floats per Gaussian of gcr_grads.dL_dconic: 16, or 32 under option "deterministic_backward" */
+/* floats per Gaussian of gcr_grads.dL_dconic: 16, or 32 under option "deterministic_backward" (the process-wide
+ * value; _opt: with a call's gcr_options applied, NULL = defaults) */
 int gcr_grad_record_floats(void);
+int gcr_grad_record_floats_opt(const gcr_options *options);
 
 int gcr_backward(const gcr_camera *cam, const gcr_gaussians *g, const int32_t *radii,
                  const void *geom, size_t geom_bytes, const void *binning,
@@ -251,7 +325,8 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
                               const gcr_camera *cam, const gcr_gaussians *g, float *out_color,
                               int32_t *radii, void *hip_stream);
 
-/* Process-wide knobs for A/B measurement (defaults are the shipping/parity configuration):
+/* Process-wide DEFAULTS of the per-call gcr_options (the shipping/parity configuration unless changed; a call that
+ * carries gcr_camera.options overrides them for itself only):
  *   "fast_exp"     1: v_exp_f32 in the blend kernels (NOT bit-reproducible)          default 0
  *   "force_radix"  1: always use the global LSD radix sort path for binning          default 0
  *   "force_global_cursor" 1: count/scatter with device-scope atomics instead of LDS  default 0

@@ -13,9 +13,10 @@ def to_dev(a, device):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
-def run_forward(rs, sc, device, *, use_sh=True, use_cov3d=False, cov3D=None, for_backward=False):
-    """Calls ext.rasterize_gaussians with the reference's positional signature (`for_backward`: the performance
-    hint RasterizeGaussiansFunction gives when an input requires a gradient)."""
+def run_forward(rs, sc, device, *, use_sh=True, use_cov3d=False, cov3D=None, for_backward=None):
+    """Calls ext.rasterize_gaussians with the reference's positional signature (`for_backward`: None = the function's
+    own default, i.e. the backward's state is written; False = an inference frame; True = what
+    RasterizeGaussiansFunction says when an input requires a gradient)."""
     colors = torch.Tensor([]) if use_sh else to_dev(sc["colors_precomp"], device)
     sh = to_dev(sc["shs"], device) if use_sh else torch.Tensor([])
     scales = torch.Tensor([]) if use_cov3d else to_dev(sc["scales"], device)

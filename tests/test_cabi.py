@@ -143,6 +143,72 @@ def test_abi_v5_argument_checks_without_a_gpu():
     assert lib.gcr_set_option(b"deterministic_backward", 0) == 1 and lib.gcr_grad_record_floats() == 16
 
 
+def test_abi_v6_per_call_options_async_arguments_and_ticket_protocol_without_a_gpu():
+    """ABI v6: per-call gcr_options override the process-wide defaults for one call only; the lean binning carve; the
+    argument checks of gcr_forward_async / gcr_backward / the state-only gcr_forward_render; and the ticket protocol of
+    an asynchronous frame, driven here by hand on ordinary host memory (no device is touched)."""
+    lib = N.lib()
+    # options: one call's view, the process-wide default untouched
+    opt = N.Options(deterministic_backward=1)
+    assert lib.gcr_grad_record_floats_opt(C.byref(opt)) == 32 and lib.gcr_grad_record_floats() == 16
+    assert lib.gcr_grad_record_floats_opt(None) == 16 and lib.gcr_grad_record_floats_opt(C.byref(N.Options())) == 16
+    with pytest.raises(TypeError):
+        N.Options(no_such_option=1)
+    # lean carve: everything in front of the backward's state
+    L = N.get_layout(1000, 640, 448, 200000)
+    assert L.bin_lean_total == lib.gcr_binning_bytes_lean(200000, 640, 448) == L.bin_work < L.bin_mask < L.bin_ckpt < L.bin_total
+    assert 24 * 200000 <= L.bin_lean_total <= 40 * 200000
+    buf = (C.c_float * 256)()
+    p = (C.addressof(buf) + 63) // 64 * 64
+    words = (C.c_uint64 * N.TICKET_WORDS)()
+    w = C.addressof(words)
+    cam = N.Camera(16, 16, 0.3, 0.3, 1.0, 0, 0, 0, p, p, p, p)
+    g = N.Gaussians(4, 0, p, p, None, p, p, p, None)
+    big = 1 << 30
+    call = lambda capacity, wp, seq: lib.gcr_forward_async(C.byref(cam), C.byref(g), p, big, p, big, capacity, 0, p, big, p, p,  # noqa: E731
+                                                           wp, seq, None)
+    assert call(100, None, 1) == -1 and b"words_host" in lib.gcr_last_error()
+    assert call(100, w, 0) == -1
+    assert call(0, w, 1) == -1 and b"capacity guess" in lib.gcr_last_error()
+    cam.debug = 1
+    assert call(100, w, 1) == -1 and b"debug" in lib.gcr_last_error()
+    cam.debug = 0
+    opt_r = N.Options(force_radix=1)
+    cam.options = C.pointer(opt_r)
+    assert call(100, w, 1) == -1          # the reference's global radix scheme has no speculative form
+    cam.options = None
+    assert lib.gcr_forward_async(C.byref(cam), C.byref(g), p, big, p, 64, 100, 0, p, big, p, p, w, 1, None) == -2  # binning too small
+    # P == 0: nothing to enqueue, the ticket resolves at once
+    g0 = N.Gaussians(0, 0, None, None, None, None, None, None, None)
+    info = N.FrameInfo(-1, -1)
+    assert lib.gcr_forward_async(C.byref(cam), C.byref(g0), None, 0, None, 0, 0, 0, None, 0, None, None, w, 7, None) == 0
+    assert lib.gcr_ticket_poll(w, 7, 0, C.byref(info)) == 0 and info.num_rendered == 0
+    # ticket protocol by hand: pending -> resolved; overflow -> pending until the rescue says done; failure words
+    assert lib.gcr_ticket_poll(w, 9, 1000, C.byref(info)) == 1                      # tag of another frame
+    words[0], words[1] = (9 << 32) | 700, 33
+    assert lib.gcr_ticket_poll(w, 9, 1000, C.byref(info)) == 0 and (info.num_rendered, info.max_tile_instances) == (700, 33)
+    assert lib.gcr_ticket_wait(w, 9, 1000, None, C.byref(info)) == 0
+    assert lib.gcr_ticket_poll(w, 9, 500, C.byref(info)) == 1                       # 700 > 500: the rescue is still to come
+    words[2] = 9
+    assert lib.gcr_ticket_poll(w, 9, 500, C.byref(info)) == 0 and info.num_rendered == 700
+    words[5] = 9
+    assert lib.gcr_ticket_poll(w, 9, 500, C.byref(info)) == -4 and b"rescue" in lib.gcr_last_error()
+    words[5], words[2], words[4] = 0, 0, 9
+    assert lib.gcr_ticket_poll(w, 9, 500, C.byref(info)) == -4 and b"not rescued in time" in lib.gcr_last_error()
+    words[0] = (9 << 32) | 0xFFFFFFFF
+    assert lib.gcr_ticket_poll(w, 9, 500, C.byref(info)) == -3                      # num_rendered beyond 2^31 - 1
+    assert lib.gcr_ticket_poll(None, 9, 500, C.byref(info)) == -1 and lib.gcr_ticket_poll(w, 0, 500, C.byref(info)) == -1
+    # the backward wants a frame that was rendered for it, and says so; a state-only render needs backward == 1
+    gb = N.Gaussians(1, 0, p, None, None, p, p, p, None)
+    gr = N.Grads(p, p, p, p, p, p, None, p, p)
+    rc = lib.gcr_backward(C.byref(cam), C.byref(gb), p, p, big, None, 0, p, big, 0, p, C.byref(gr), None)
+    assert rc == -1 and b"backward == 1" in lib.gcr_last_error()
+    fi = N.FrameInfo(10, 10)
+    assert lib.gcr_forward_render(C.byref(cam), C.byref(gb), p, big, p, big, p, big, C.byref(fi), None, None) == -1
+    assert b"state-only" in lib.gcr_last_error()
+    assert lib.gcr_rescue_count() == 0
+
+
 def _gcv_header_functions():
     src = open(os.path.join(ROOT, "include", "gcv.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)

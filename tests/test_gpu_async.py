@@ -1,0 +1,246 @@
+"""-m gpu: ABI v6 -- frames without the host wait (gcr_forward_async / FrameTicket), the overflow rescue behind the
+frame gate, frames rendered without the backward's state, per-call options from several host threads, and the global
+radix path on a scene with empty tiles.  Everything against the CPU oracle on identical seeded inputs, through the
+native-module surface (ext -> C ABI -> gfx950 kernels)."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import gpu_util as G
+import scenes
+from test_gpu_parity import GRAD_TOL, _check_forward, _check_grads, _frame
+
+pytestmark = pytest.mark.gpu
+
+ALL_GRADS = ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot", "dL_dsh"]
+
+
+def _args(rs, sc, device, sh=True):
+    e = torch.Tensor([])
+    return (rs.bg.to(device), G.to_dev(sc["means3D"], device), e if sh else G.to_dev(sc["colors_precomp"], device),
+            G.to_dev(sc["opacities"], device), G.to_dev(sc["scales"], device), G.to_dev(sc["rotations"], device),
+            rs.scale_modifier, e, rs.view_matrix.to(device), rs.proj_matrix.to(device), rs.tanfovx, rs.tanfovy,
+            rs.img_h, rs.img_w, G.to_dev(sc["shs"], device) if sh else e, rs.sh_degree, rs.campos.to(device), False, False)
+
+
+def test_frames_without_the_host_wait_match_the_oracle(oracle_mod, cuda_device):
+    """rasterize_gaussians_ticket: the call returns with the frame enqueued and num_rendered as a FrameTicket.  Twelve
+    frames of four poses back to back over three streams, nothing synchronised in between: every image bit-exact,
+    every ticket resolves to the oracle's num_rendered, the frames after the first of the key really were asynchronous,
+    and none of them needed the rescue."""
+    from gaussiancity_amd import _native as N, ext
+    P, W, H = 3500, 176, 128
+    sc = scenes.blob_scene(P, 71, 2)
+    cams = [scenes.camera(W, H, pose_index=i)._replace(sh_degree=2) for i in (1, 5, 9, 13)]
+    frames = [_frame(oracle_mod, rs, sc) for rs in cams]
+    ext._capacity_hint.pop((cuda_device.index, P, W, H), None)
+    rescued0 = N.lib().gcr_rescue_count()
+    streams = [torch.cuda.Stream(device=cuda_device) for _ in range(3)]
+    argsets = [_args(rs, sc, cuda_device) for rs in cams]
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(12):
+        with torch.cuda.stream(streams[i % 3]):
+            outs.append(ext.rasterize_gaussians_ticket(*argsets[i % 4]))
+    assert all(isinstance(o[0], ext.FrameTicket) for o in outs)
+    assert sum(1 for o in outs if o[0].seq != 0) >= 10, "the frames after the key's first must take the asynchronous path"
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        fr = frames[i % 4]
+        assert int(o[0]) == fr.R and o[0].done() and not o[0].rescued
+        assert np.array_equal(o[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32)), "frame %d" % i
+        np.testing.assert_array_equal(o[2].cpu().numpy(), fr.radii)
+    assert N.lib().gcr_rescue_count() == rescued0
+    # the whole state of an asynchronous inference frame, decoded (lean binning buffer: sorted list + keys only)
+    o = outs[-1]
+    _check_forward(frames[11 % 4], G.decode(P, W, H, (int(o[0]),) + tuple(o[1:])), P, True)
+    assert o[4].numel() == N.lib().gcr_binning_bytes_lean(o[0].capacity, W, H) < N.lib().gcr_binning_bytes(o[0].capacity, W, H)
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["inference_frame", "training_frame"])
+def test_a_frame_that_overflows_its_capacity_guess_is_rescued_in_stream_order(oracle_mod, cuda_device, train, monkeypatch):
+    """The capacity guess of an asynchronous frame can be short (the camera jumped).  The frame's gate kernel then
+    holds the stream while the library's rescue thread renders the frame with an exactly sized buffer: work enqueued
+    BEHIND the frame -- here a clone of the image, enqueued before anything is synchronised -- sees the right pixels.
+    A training frame's backward bins the frame again (its state was not in the caller's buffer) and still matches."""
+    from gaussiancity_amd import _native as N, ext
+    P, W, H = 3500, 176, 128
+    rs = scenes.camera(W, H)._replace(sh_degree=2)
+    sc = scenes.blob_scene(P, 71, 2)
+    fr = _frame(oracle_mod, rs, sc)
+    key = (cuda_device.index, P, W, H)
+    monkeypatch.setattr(ext, "_ASYNC_MARGIN", 16)
+    ext._capacity_hint[key] = (10, 64)     # "the last frame rendered ten instances": capacity guess 36
+    rescued0 = N.lib().gcr_rescue_count()
+    a = _args(rs, sc, cuda_device)
+    torch.cuda.synchronize()
+    out = ext.rasterize_gaussians_ticket(*a, _for_backward=train)
+    behind = out[1].clone()                # enqueued behind the gate, long before the rescue has run
+    t = out[0]
+    assert t.seq != 0 and t.capacity == 36
+    assert int(t) == fr.R and t.rescued
+    torch.cuda.synchronize()
+    assert N.lib().gcr_rescue_count() == rescued0 + 1
+    assert np.array_equal(behind.cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
+    assert np.array_equal(out[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
+    assert ext._capacity_hint[key][0] == fr.R   # the next guess starts from the truth
+    # the frame after it fits again
+    out2 = ext.rasterize_gaussians_ticket(*a, _for_backward=train)
+    assert int(out2[0]) == fr.R and not out2[0].rescued
+    assert np.array_equal(out2[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
+    if train:
+        dpix = np.random.default_rng(4).normal(size=(3, H, W)).astype(np.float32)
+        gref = fr.backward(dpix)
+        for o in (out, out2):   # the rescued frame (binned again by the backward) and the ordinary one
+            (bg, m3, col, opa, scl, rot, smod, cov, view, proj, tfx, tfy, h, w, sh, deg, campos, _, _) = a
+            g = ext.rasterize_gaussians_backward(bg, m3, o[2], col, scl, rot, smod, cov, view, proj, tfx, tfy,
+                                                 G.to_dev(dpix, cuda_device), sh, deg, campos, o[3], o[0], o[4], o[5], False)
+            names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
+            _check_grads(gref, {n: x.cpu().numpy() for n, x in zip(names, g)},
+                         ["dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"])
+
+
+def test_autograd_through_tickets_and_the_wrapper_under_no_grad(oracle_mod, cuda_device):
+    """GaussianRasterizer (autograd) keeps a ticket where the reference keeps num_rendered: forward + backward through
+    it match the oracle, several steps in a row without a synchronisation in between; under no_grad the same module
+    renders inference frames (no backward state) bit-exactly."""
+    from gaussiancity_amd import GaussianRasterizer
+    P, W, H = 2000, 112, 80
+    rs_cpu = scenes.camera(W, H)._replace(sh_degree=3)
+    sc = scenes.blob_scene(P, 41, 3)
+    fr = _frame(oracle_mod, rs_cpu, sc)
+    rs = rs_cpu._replace(bg=rs_cpu.bg.to(cuda_device), view_matrix=rs_cpu.view_matrix.to(cuda_device),
+                         proj_matrix=rs_cpu.proj_matrix.to(cuda_device), campos=rs_cpu.campos.to(cuda_device))
+    dpix = np.random.default_rng(1).normal(size=(3, H, W)).astype(np.float32)
+    gref = fr.backward(dpix)
+    dp = G.to_dev(dpix, cuda_device)
+    r = GaussianRasterizer(rs)
+    results = []
+    for _ in range(4):
+        t = {k: G.to_dev(sc[k], cuda_device).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        m2 = torch.zeros((P, 3), device=cuda_device, requires_grad=True)
+        img, radii = r(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                       rotations=t["rotations"])
+        (img * dp).sum().backward()
+        results.append((img.detach(), t, m2))
+    torch.cuda.synchronize()
+    for img, t, m2 in results:
+        assert np.array_equal(img.cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
+        for name, key in (("dL_dmean3D", "means3D"), ("dL_dopacity", "opacities"), ("dL_dsh", "shs"),
+                          ("dL_dscale", "scales"), ("dL_drot", "rotations")):
+            ref = gref[name]
+            got = t[key].grad.cpu().numpy().reshape(ref.shape)
+            assert np.abs(ref - got).max() <= GRAD_TOL * max(1.0, float(np.abs(ref).max())), name
+    with torch.no_grad():
+        t = {k: G.to_dev(sc[k], cuda_device) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        imgs = [r(means3D=t["means3D"], means2D=torch.zeros((P, 3), device=cuda_device), opacities=t["opacities"],
+                  shs=t["shs"], scales=t["scales"], rotations=t["rotations"])[0] for _ in range(5)]
+    for img in imgs:
+        assert np.array_equal(img.cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
+
+
+def test_backward_on_a_frame_without_state_is_binned_again_or_poisoned_never_silently_zero(oracle_mod, cuda_device):
+    """An inference frame (gcr_camera.backward == 0) carries no backward state.  rasterize_gaussians_backward knows such
+    a frame by its geometry buffer and bins it again, state only: the gradients match.  When it CANNOT know (the
+    bookkeeping entry is gone: here it is deleted), the C ABI's own guard speaks: every rendered Gaussian's gradient is
+    NaN -- never a plausible zero."""
+    from gaussiancity_amd import ext
+    P, W, H = 3000, 200, 150
+    rs = scenes.camera(W, H)._replace(sh_degree=1)
+    sc = scenes.blob_scene(P, 11, 1)
+    fr = _frame(oracle_mod, rs, sc)
+    dpix = np.random.default_rng(2).normal(size=(3, H, W)).astype(np.float32)
+    args, out = G.run_forward(rs, sc, cuda_device, for_backward=False)
+    _check_forward(fr, G.decode(P, W, H, out), P, True)
+    _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device), ALL_GRADS)
+    with ext._meta_lock:
+        ext._frame_meta.clear()
+    g = G.run_backward(args, out, dpix, cuda_device)
+    vis = fr.radii > 0
+    assert vis.sum() > 100
+    for n in ("dL_dmean3D", "dL_dopacity", "dL_dscale", "dL_drot", "dL_dmean2D"):
+        a = g[n].reshape(P, -1)
+        assert np.isnan(a[vis]).all(), n + ": a frame without backward state must poison its gradients"
+        assert (a[~vis] == 0).all(), n
+
+
+def test_three_host_threads_with_different_per_call_options(oracle_mod, cuda_device):
+    """gcr_options travel with the call (ABI v6): three host threads render and differentiate the same scene at the same
+    time, one with the defaults (bit-exact image), one with fast_exp + 64-entry pieces, one with the deterministic
+    backward (bit-identical gradients run to run) -- and the process-wide defaults are what they were."""
+    from gaussiancity_amd import _native as N, ext
+    P, W, H, seed = 9000, 96, 80, 41
+    rs = scenes.camera(W, H, pose_index=seed % 24)._replace(sh_degree=1, bg=torch.tensor((0.2, 0.0, 0.4)))
+    sc = scenes.blob_scene(P, seed, 1, smax=14.0)
+    fr = _frame(oracle_mod, rs, sc, True)
+    dpix = np.random.default_rng(seed).normal(size=(3, H, W)).astype(np.float32)
+    gref = fr.backward(dpix)
+    res, errs = {}, []
+
+    def worker(name, opts, rounds):
+        try:
+            torch.cuda.set_device(cuda_device)
+            with torch.cuda.stream(torch.cuda.Stream(device=cuda_device)):
+                with ext.options(**opts):
+                    got = []
+                    for _ in range(rounds):
+                        args, out = G.run_forward(rs, sc, cuda_device, for_backward=True)
+                        got.append((out[1].cpu().numpy(), G.run_backward(args, out, dpix, cuda_device)))
+                    res[name] = got
+        except Exception as e:  # noqa: BLE001
+            errs.append((name, repr(e)))
+
+    th = [threading.Thread(target=worker, args=a) for a in (("default", {}, 4), ("fast", dict(fast_exp=1, bwd_piece=64), 4),
+                                                            ("det", dict(deterministic_backward=1), 4))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for img, _ in res["default"]:
+        assert np.array_equal(img.view(np.uint32), fr.out_color.view(np.uint32))
+    tol = GRAD_TOL * max(1.0, float(np.abs(fr.out_color).max()))
+    for img, _ in res["fast"]:
+        off = np.abs(img - fr.out_color).max(axis=0) > tol
+        assert int(off.sum()) <= 2 and not np.array_equal(img.view(np.uint32), fr.out_color.view(np.uint32))
+    for name in res:
+        for _, g in res[name]:
+            _check_grads(gref, g, ALL_GRADS)
+    d0 = res["det"][0][1]
+    for _, g in res["det"][1:]:
+        for n in ALL_GRADS:
+            assert np.array_equal(g[n].view(np.uint32), d0[n].view(np.uint32)), n + " differs between deterministic runs"
+    assert N.lib().gcr_grad_record_floats() == 16 and N.get_option("fast_exp") == 0 and N.get_option("bwd_piece") == 128
+
+
+def test_global_radix_path_on_a_scene_with_empty_tiles(oracle_mod, cuda_device):
+    """the reference's own binning scheme (option force_radix) leaves an untouched tile's range at (0, 0);
+    the backward pieces address their slots by the range START, so empty tiles must sit where the previous list ends.
+    A sparse scene -- most tiles empty, a few long lists -- forward + backward on that path."""
+    from gaussiancity_amd import ext
+    P, W, H = 800, 208, 160
+    rs = scenes.camera(W, H)._replace(sh_degree=1)
+    sc = scenes.blob_scene(P, 52, 1, spread=6.0, smin=0.5, smax=2.5)   # 37 of 130 tiles empty, longest list 707
+    fr = _frame(oracle_mod, rs, sc)
+    lens = fr.ranges[:, 1].astype(np.int64) - fr.ranges[:, 0]
+    assert (lens == 0).sum() >= 20 and lens.max() > 128, (int((lens == 0).sum()), int(lens.max()))
+    dpix = np.random.default_rng(5).normal(size=(3, H, W)).astype(np.float32)
+    gref = fr.backward(dpix)
+    for piece in (64, 128):
+        with ext.options(force_radix=1, bwd_piece=piece):
+            args, out = G.run_forward(rs, sc, cuda_device, for_backward=True)
+            R, color, radii, geom, binning, img = out
+            assert R == fr.R
+            assert np.array_equal(color.cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
+            from gaussiancity_amd import _native as N
+            L = N.get_layout(P, W, H, R)
+            T = fr.ranges.shape[0]
+            got = img.cpu().numpy()[L.img_ranges:L.img_ranges + 8 * T].view(np.uint32).reshape(T, 2)
+            ne = lens > 0
+            np.testing.assert_array_equal(got[ne], fr.ranges[ne])
+            assert (got[~ne, 0] == got[~ne, 1]).all()
+            ends = np.maximum.accumulate(np.concatenate([[0], fr.ranges[:, 1]]))[:-1]  # end of the last list before each tile
+            np.testing.assert_array_equal(got[~ne, 0], ends[~ne])
+            _check_grads(gref, G.run_backward(args, out, dpix, cuda_device), ALL_GRADS)
