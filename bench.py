@@ -151,17 +151,44 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 and not share_gpu:
+    if not share_gpu:
         # every rank keeps to the CPUs of its GPU's NUMA node (counterpart of utils/distributed.py:19-62): the frame
-        # loop is host-enqueue-bound and ends every frame polling a pinned word the GPU writes
+        # loop is host-enqueue-bound and its pinned ticket words are first-touched after the binding.  Also at N = 1, so
+        # that the N = 1 line of a scaling run is the same program as the headline run.
         from gaussiancity_amd.affinity import bind_rank_to_gpu
+        args.full_cpu_mask = os.sched_getaffinity(0)  # the CPU baseline legs run on all host cores again
         args.affinity = bind_rank_to_gpu(local_rank)
+    args.rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
             dist.init_process_group(backend="gloo")
         else:
+            # RCCL's own account of the communicator (rings / trees / transports) goes to a FILE per rank -- stdout
+            # carries exactly one JSON line -- and is summarised into the report (affinity.summarize_rccl_log)
+            if "NCCL_DEBUG" not in os.environ:
+                os.environ["NCCL_DEBUG"] = "INFO"
+                os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING")
+                os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/gcr_rccl_%d_rank%d.log" % (os.getppid(), rank))
+            args.rccl_log = os.environ.get("NCCL_DEBUG_FILE")
             dist.init_process_group(backend="nccl", device_id=dev)
+
+    def collect_ranks():
+        """rank 0: [{rank, affinity, rccl}] of every rank (all_gather_object); other ranks: None."""
+        from gaussiancity_amd.affinity import summarize_rccl_log
+        mine = {"rank": rank, "affinity": getattr(args, "affinity", None), "rccl": None}
+        if args.rccl_log:
+            try:
+                mine["rccl"] = summarize_rccl_log(open(args.rccl_log.replace("%h", os.uname().nodename)
+                                                       .replace("%p", str(os.getpid()))).read())
+            except OSError as e:
+                mine["rccl"] = {"log": "unreadable: %s" % e}
+        if world == 1:
+            return [mine]
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+        return got if rank == 0 else None
+    args.collect_ranks = collect_ranks
     N.lib()
     N.set_option("fast_exp", 1 if args.fast_exp else 0)
     N.set_option("split_preprocess", 1 if args.split_preprocess else 0)
@@ -413,6 +440,7 @@ def main():
         other_blocks = timed_blocks(fwd.api if args.native_int_api else fwd, 0.15)
 
     out = None
+    ranks_info = args.collect_ranks()  # (a collective for N > 1: every rank calls it)
     if rank == 0:
         # ---- per-frame workload statistics over the same poses (untimed) --------------------
         R_mean, Rp_mean, Pv_mean = frame_statistics(
@@ -527,6 +555,7 @@ def main():
                             "ns_per_instance": round(1e9 * elapsed / args.steps / max(R_mean, 1.0), 4)},
             "stages_ms": stages,
             "roofline": roofline,
+            "ranks": ranks_info,
         }
         if other_blocks:
             oel = float(np.median(other_blocks))
@@ -538,6 +567,8 @@ def main():
                 "repeats": len(other_blocks)}
 
         # ---- CPU baseline: the oracle on a bounded sample of the same workload --------------
+        if world == 1 and getattr(args, "full_cpu_mask", None):
+            os.sched_setaffinity(0, args.full_cpu_mask)  # (the timed GPU region is over; the oracle wants every core)
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
             kw = oracle_kwargs(cams[0], sc, use_sh)
@@ -1097,6 +1128,7 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
         tt = torch.tensor([elapsed, ar_ms, leg_s], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, ar_ms, leg_s = float(tt[0].item()), float(tt[1].item()), float(tt[2].item())
+    ranks_info = args.collect_ranks()
     if rank == 0:
         nbytes = n_param * 4
         bus = (2.0 * (world - 1) / world) * nbytes / 1e9 / (ar_ms / 1e3) if world > 1 else None
@@ -1125,7 +1157,10 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
             "allreduce_ms": round(ar_ms, 4) if ar_ms else None, "allreduce_bytes": nbytes,
             "allreduce_messages": n_msg, "allreduce_bus_GBps": round(bus, 1) if bus else None,
             "rccl": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_DEBUG") if os.environ.get(k)} or None,
-            "affinity": getattr(args, "affinity", None)}), flush=True)
+            "expected_allreduce": {"bytes": nbytes, "ring_ms_estimate": 3.2, "direct_all_links_ms_estimate": 0.46,
+                                   "note": "SURVEY.md section 5: 279 MB fp32 over xGMI, 7 links x ~153 GB/s per GPU; a ring "
+                                           "is per-link bound"},
+            "ranks": ranks_info}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

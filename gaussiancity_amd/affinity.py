@@ -72,4 +72,49 @@ def bind_rank_to_gpu(device_index, sysfs="/sys/bus/pci/devices"):
         os.sched_setaffinity(0, allowed)
     except OSError as e:
         return {"bound": False, "cpus": 0, "numa_node": node, "why": "sched_setaffinity: %s" % e}
-    return {"bound": True, "cpus": len(allowed), "numa_node": node, "why": "ok"}
+    return {"bound": True, "cpus": len(allowed), "numa_node": node, "why": "ok", "cpulist": format_cpulist(allowed),
+            "pci": gpu_pci_address(device_index)}
+
+
+def format_cpulist(cpus):
+    """[0, 1, 2, 3, 8, 10, 11] -> '0-3,8,10-11' (inverse of parse_cpulist)."""
+    cpus = sorted(set(cpus))
+    parts, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        parts.append("%d-%d" % (cpus[i], cpus[j]) if j > i else "%d" % cpus[i])
+        i = j + 1
+    return ",".join(parts)
+
+
+def summarize_rccl_log(text):
+    """What an RCCL log written with NCCL_DEBUG=INFO (NCCL_DEBUG_FILE) says about the communicator this rank built:
+    channel count, ring / tree graphs, transports (xGMI peer-to-peer, shared memory, network) and the algorithm /
+    protocol lines RCCL prints when NCCL_DEBUG_SUBSYS includes TUNING.  Best effort -- the log format is RCCL's, not
+    an interface: fields that are not found are simply absent."""
+    import re
+    out = {}
+    m = re.findall(r"(\d+) coll channels", text)
+    if m:
+        out["coll_channels"] = int(m[-1])
+    out["ring_lines"] = len(re.findall(r"NCCL INFO (?:Channel \d+/\d+ :|Ring \d+ :)", text))
+    out["tree_lines"] = len(re.findall(r"NCCL INFO Trees? ", text))
+    tr = {}
+    for name, pat in (("p2p_xgmi_or_ipc", r"via P2P/"), ("shm", r"via SHM"), ("net", r"via NET/")):
+        n = len(re.findall(pat, text))
+        if n:
+            tr[name] = n
+    if tr:
+        out["transports"] = tr
+    algo = sorted(set(re.findall(r"\b(?:Algo|algorithm)[ =:]+(\w+)", text)))
+    if algo:
+        out["algorithms"] = algo
+    proto = sorted(set(re.findall(r"\b(?:Proto|protocol)[ =:]+(\w+)", text)))
+    if proto:
+        out["protocols"] = proto
+    ver = re.search(r"(?:RCCL|NCCL) version ([\w.+-]+)", text)
+    if ver:
+        out["version"] = ver.group(1)
+    return out

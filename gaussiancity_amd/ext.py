@@ -13,6 +13,7 @@ Differences, all on the safe side:
 """
 import collections
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -100,6 +101,7 @@ _RING = 32  # asynchronous frames a host thread may have outstanding (the ring's
 # capacity guess of an asynchronous frame from the newest num_rendered this thread has seen for the same (device, P, W,
 # H): the host runs ahead of the device, so that number may be a few frames old -- twice it, plus a constant
 _ASYNC_FACTOR, _ASYNC_MARGIN = 2, 65536
+_SYNC_ONLY = os.environ.get("GCR_EXT_SYNC") == "1"  # measurement aid: keep the reference's host wait in every frame
 
 
 class FrameTicket:
@@ -344,6 +346,8 @@ def _forward(L, device, cam, g, P, H, W, ticket=False):
     img = torch.empty((ibytes,), **byte)
     key = (device.index, P, W, H)
     ring = None
+    if ticket and _SYNC_ONLY:
+        ticket = None  # A/B switch: every frame through the synchronous entry point, tickets resolved on return
     if ticket:
         ring = _ring(L)
         ring.harvest()
@@ -384,7 +388,7 @@ def _forward(L, device, cam, g, P, H, W, ticket=False):
     longest = int(info.max_tile_instances)
     _hint_put(key, (R, longest))  # the library adds its own margin to the longest list
     _meta_put(geom, stateful, R, longest)
-    if ticket:
+    if ticket is not False:
         R = FrameTicket(L, None, None, 0, max(capacity, R), stream, None, stateful, R=R, longest=longest)
     return R, out_color, radii, geom, binning, img
 

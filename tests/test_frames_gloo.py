@@ -190,7 +190,14 @@ def test_rank_affinity_from_sysfs(tmp_path, monkeypatch):
     assert cpus == sorted({mine[0], 4000, 4001}) and node == 1 and why == "ok"
     try:
         r = A.bind_rank_to_gpu(0, sysfs=str(tmp_path))
-        assert r == {"bound": True, "cpus": 1, "numa_node": 1, "why": "ok"} and sorted(os.sched_getaffinity(0)) == [mine[0]]
+        assert r == {"bound": True, "cpus": 1, "numa_node": 1, "why": "ok", "cpulist": str(mine[0]),
+                     "pci": "0000:c1:00.0"} and sorted(os.sched_getaffinity(0)) == [mine[0]]
+        assert A.format_cpulist([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11" and A.format_cpulist([]) == ""
+        summary = A.summarize_rccl_log("NCCL INFO RCCL version 2.22.3+hip7.0\nNCCL INFO Channel 00/16 : 0 1 2 3\n"
+                                       "NCCL INFO Trees [0] 1/-1/-1->0->-1\nNCCL INFO Channel 00 : 0[0] -> 1[1] via P2P/IPC\n"
+                                       "NCCL INFO 16 coll channels, 16 p2p channels\n")
+        assert summary["coll_channels"] == 16 and summary["transports"] == {"p2p_xgmi_or_ipc": 1}
+        assert summary["ring_lines"] == 1 and summary["tree_lines"] == 1 and summary["version"].startswith("2.22")
     finally:
         os.sched_setaffinity(0, mine)
     monkeypatch.setenv("GCR_NO_AFFINITY", "1")

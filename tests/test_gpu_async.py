@@ -144,8 +144,10 @@ def test_autograd_through_tickets_and_the_wrapper_under_no_grad(oracle_mod, cuda
 def test_backward_on_a_frame_without_state_is_binned_again_or_poisoned_never_silently_zero(oracle_mod, cuda_device):
     """An inference frame (gcr_camera.backward == 0) carries no backward state.  rasterize_gaussians_backward knows such
     a frame by its geometry buffer and bins it again, state only: the gradients match.  When it CANNOT know (the
-    bookkeeping entry is gone: here it is deleted), the C ABI's own guard speaks: every rendered Gaussian's gradient is
-    NaN -- never a plausible zero."""
+    bookkeeping entry is gone: here it is deleted), the C ABI's own guards speak: the lean binning buffer of an
+    inference frame is refused as too small, and -- should the buffer be large enough all the same (here: the lean
+    buffer's contents copied into a full-size one) -- every rendered Gaussian's gradient is NaN, never a plausible zero."""
+    from gaussiancity_amd import _native as N
     from gaussiancity_amd import ext
     P, W, H = 3000, 200, 150
     rs = scenes.camera(W, H)._replace(sh_degree=1)
@@ -157,7 +159,12 @@ def test_backward_on_a_frame_without_state_is_binned_again_or_poisoned_never_sil
     _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device), ALL_GRADS)
     with ext._meta_lock:
         ext._frame_meta.clear()
-    g = G.run_backward(args, out, dpix, cuda_device)
+    with pytest.raises(RuntimeError, match="binning buffer too small"):
+        G.run_backward(args, out, dpix, cuda_device)
+    R, color, radii, geom, binning, img = out
+    big = torch.zeros((N.lib().gcr_binning_bytes(R, W, H),), dtype=torch.uint8, device=cuda_device)
+    big[:binning.numel()] = binning
+    g = G.run_backward(args, (R, color, radii, geom, big, img), dpix, cuda_device)
     vis = fr.radii > 0
     assert vis.sum() > 100
     for n in ("dL_dmean3D", "dL_dopacity", "dL_dscale", "dL_drot", "dL_dmean2D"):

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=$R/gpurun_out
 mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -x -q --timeout 180 > $O/${TAG}_pytest.txt 2>&1
+timeout 1200 python -m pytest tests -m gpu -q --timeout 180 > $O/${TAG}_pytest.txt 2>&1
 tail -5 $O/${TAG}_pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.txt 2>&1
 tail -3 $O/${TAG}_smoke.txt
