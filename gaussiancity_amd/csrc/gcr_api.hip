@@ -429,7 +429,8 @@ static void set_piece_args(const Opts& op, GcrBlendArgs& b, bool want_state, con
 static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_gaussians* g, void* geom, void* binning, void* img,
                               int64_t R_layout, int64_t list_length_hint, bool speculative,
                               unsigned long long cap_instances, unsigned long long cap_list, float* out_color,
-                              hipStream_t s, unsigned long long* host_longest = nullptr) {
+                              hipStream_t s, unsigned long long* host_longest = nullptr,
+                              unsigned long long* gate_words = nullptr, unsigned int gate_seq = 0) {
   gcr_layout L;
   compute_layout(g->P, cam->img_w, cam->img_h, R_layout, &L);
   char *gb = (char*)geom, *bb = (char*)binning, *ib = (char*)img;
@@ -498,6 +499,9 @@ static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_g
   b.list_out = list;
   b.lazy = lazy;
   set_piece_args(op, b, cam->backward == 1, L, R_layout > 0 ? binning : nullptr, geom);
+  b.gate_words = gate_words;  // asynchronous frames: the forward blend is the frame's last kernel and carries the gate
+  b.gate_seq = gate_seq;
+  b.gate_polls = 400000u;  // about two seconds before a gate gives up (~5 us per poll: a PCIe round trip + two s_sleep 127)
 #ifdef GCR_EXPERIMENTS
   b.debug_flags = g_k6_debug.load();
 #endif
@@ -774,12 +778,13 @@ class RescueService {
     // the caller reuses a word set only for a frame whose ticket it has resolved: an older entry on the same words is
     // finished (or abandoned)
     for (auto it = frames_.begin(); it != frames_.end();) it = it->words == f.words ? frames_.erase(it) : it + 1;
+    const bool was_empty = frames_.empty();
     frames_.push_back(f);
     if (!started_) {
       started_ = true;
       std::thread([this] { run(); }).detach();
     }
-    cv_.notify_one();
+    if (was_empty) cv_.notify_one();  // (with frames outstanding the thread is polling, not waiting)
   }
   long rescued() const { return rescued_.load(); }
 };
@@ -815,9 +820,6 @@ int gcr_forward_async(const gcr_camera* cam, const gcr_gaussians* g, void* geom,
   if (int rc = enqueue_preprocess(op, cam, g, geom, geom_bytes, img, img_bytes, radii, (unsigned long long)binning_capacity,
                                   ~0ull, &frame, s, words_host, seq))
     return rc;
-  if (int rc = enqueue_render_lds(op, cam, g, geom, binning, img, binning_capacity, list_hint, true,
-                                  (unsigned long long)binning_capacity, ~0ull, out_color, s, words_host + 1))
-    return rc;
   AsyncFrame f;
   memset((void*)&f, 0, sizeof(f));
   f.words = words_host;
@@ -841,10 +843,9 @@ int gcr_forward_async(const gcr_camera* cam, const gcr_gaussians* g, void* geom,
   f.out_color = out_color;
   f.capacity = binning_capacity;
   f.born = std::chrono::steady_clock::now();
-  rescue_service().add(f);
-  // about two seconds of polling before a gate gives up (~5 us per poll: a PCIe round trip + two s_sleep 127)
-  HIP_TRY(gcr_launch_frame_gate(frame, words_host, seq, 400000u, s), "frame gate");
-  return 0;
+  rescue_service().add(f);  // (before the kernel that may call for it is enqueued)
+  return enqueue_render_lds(op, cam, g, geom, binning, img, binning_capacity, list_hint, true,
+                            (unsigned long long)binning_capacity, ~0ull, out_color, s, words_host + 1, words_host, seq);
 }
 
 static int ticket_state(const unsigned long long* words_host, uint32_t seq, int64_t capacity, gcr_frame_info* info) {
@@ -1160,12 +1161,16 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void* geometry_user
   const size_t ibytes = gcr_image_bytes(cam->img_w, cam->img_h);
   void* img = image_buffer(image_user, ibytes);
   if (!img) return fail(GCR_ERR_ALLOC, "image resize callback returned null");
+  // the reference's forward always leaves what its backward needs (cr/rasterizer.h:25-48 has no inference mode): so
+  // does this entry point, whatever gcr_camera.backward says
+  gcr_camera cam1 = *cam;
+  cam1.backward = 1;
   gcr_frame_info info;
-  if (int rc = gcr_forward_preprocess(cam, g, geom, gbytes, img, ibytes, radii, &info, hip_stream)) return rc;
+  if (int rc = gcr_forward_preprocess(&cam1, g, geom, gbytes, img, ibytes, radii, &info, hip_stream)) return rc;
   const size_t bbytes = gcr_binning_bytes(info.num_rendered, cam->img_w, cam->img_h);
   void* bin = binning_buffer(binning_user, bbytes);
   if (!bin && info.num_rendered > 0) return fail(GCR_ERR_ALLOC, "binning resize callback returned null");
-  if (int rc = gcr_forward_render(cam, g, geom, gbytes, bin, bbytes, img, ibytes, &info, out_color, hip_stream))
+  if (int rc = gcr_forward_render(&cam1, g, geom, gbytes, bin, bbytes, img, ibytes, &info, out_color, hip_stream))
     return rc;
   return info.num_rendered;
 }

@@ -574,34 +574,7 @@ __global__ __launch_bounds__(256) void k_ranges_make_contiguous(uint32_t* __rest
   }
 }
 
-// Last kernel of an ASYNCHRONOUS frame (gcr_forward_async, include/gcr.h), one wave.  A frame that fitted its binning
-// buffer: the go flag is set, return -- the stream goes on.  A frame the scatter kernel vetoed (num_rendered larger
-// than the caller's capacity guess): nothing was rendered; tell the host (words[3] = seq) and hold the stream until the
-// library's rescue thread has rendered the frame with an exactly sized buffer on its own stream (words[2] = seq), so
-// that everything the caller enqueued behind this frame sees the finished image.  The wait is bounded (about two
-// seconds): a gate that gives up says so in words[4] and the ticket resolves to an error instead of a hung device.
-__global__ __launch_bounds__(64) void k_frame_gate(const unsigned long long* __restrict__ frame,
-                                                   unsigned long long* __restrict__ words, unsigned int seq,
-                                                   unsigned int max_polls) {
-  if (threadIdx.x != 0) return;
-  if (frame[2] != 0ull) return;
-  gcr_store_to_host(words + 3, (unsigned long long)seq);
-  for (unsigned int i = 0; i < max_polls; i++) {
-    const unsigned long long v = __hip_atomic_load(words + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if ((unsigned int)v == seq) return;
-    __builtin_amdgcn_s_sleep(127);
-    __builtin_amdgcn_s_sleep(127);
-  }
-  gcr_store_to_host(words + 4, (unsigned long long)seq);
-}
-
 }  // namespace
-
-hipError_t gcr_launch_frame_gate(const unsigned long long* frame, unsigned long long* words, unsigned int seq,
-                                 unsigned int max_polls, hipStream_t s) {
-  k_frame_gate<<<1, 64, 0, s>>>(frame, words, seq, max_polls);
-  return hipGetLastError();
-}
 
 hipError_t gcr_launch_emit(int P, const uint32_t* tiles_touched, const uint32_t* block_offsets,
                            const float4* rec, int gx, uint64_t* keys, uint32_t* vals,

@@ -158,6 +158,24 @@ __device__ __noinline__ uint32_t k6_lazy_extend(uint64_t* s, const uint64_t* key
   return ns;
 }
 
+// THE FRAME GATE of an asynchronous frame (gcr_forward_async, include/gcr.h).  A frame that fitted its binning buffer
+// never gets here.  A frame the scatter kernel vetoed (num_rendered larger than the caller's capacity guess) renders
+// nothing on the caller's stream: the first thread of the forward blend -- the frame's LAST kernel -- tells the host
+// (words[3] = seq) and keeps the kernel, and with it the stream, from finishing until the library's rescue thread has
+// rendered the frame with an exactly sized buffer on a stream of its own (words[2] = seq): everything the caller
+// enqueued behind the frame sees the finished image.  The wait is bounded (about two seconds): a gate that gives up
+// says so in words[4] and the ticket resolves to an error instead of a hung device.
+__device__ __noinline__ void k6_frame_gate(unsigned long long* words, unsigned int seq, unsigned int max_polls) {
+  gcr_store_to_host(words + 3, (unsigned long long)seq);
+  for (unsigned int i = 0; i < max_polls; i++) {
+    const unsigned long long v = __hip_atomic_load(words + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned int)v == seq) return;
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
+  }
+  gcr_store_to_host(words + 4, (unsigned long long)seq);
+}
+
 // amdgpu_waves_per_eu(7, 8): the call above constrains the register assignment (what lives across it must sit in
 // callee-saved registers) and the allocator, left alone, ends at 78 VGPRs = six waves per SIMD; told to fit seven, it
 // finds a 71-register assignment without a spill and with the blend steps unchanged instruction for instruction.
@@ -172,7 +190,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   __shared__ uint32_t sMask[CHUNK];
   __shared__ uint16_t sList[4][4][LIST_STRIDE];  // [wave][row]: byte offsets into sE, list order
 
-  if (a.frame != nullptr && a.frame[2] == 0ull) return;  // speculative launch vetoed
+  if (a.frame != nullptr && a.frame[2] == 0ull) {  // speculative launch vetoed
+    if (a.gate_words != nullptr && blockIdx.x == 0 && threadIdx.x == 0) k6_frame_gate(a.gate_words, a.gate_seq, a.gate_polls);
+    return;
+  }
   const int tile = blockIdx.x;
   const int tx = tile % a.gx, ty = tile / a.gx;
   const int tid = threadIdx.x;

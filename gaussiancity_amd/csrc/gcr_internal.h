@@ -179,6 +179,8 @@ struct GcrBlendArgs {
   unsigned long long* frame_out;   // fwd: device frame words; [3..7] published by the first tile
   unsigned long long ckpt_off, work_off;  // fwd: what it publishes (byte offsets in the binning buffer)
   unsigned long long carve_bytes;         // fwd: ... and the size of the carve they belong to
+  unsigned long long* gate_words;         // fwd, asynchronous frames: the ticket's host words (the FRAME GATE, gcr_blend.hip)
+  unsigned int gate_seq, gate_polls;
   unsigned long long binning_bytes;       // bwd: size of the buffer behind binning_base
   const char* binning_base;        // bwd: checkpoints / work list are found through the frame words
   const unsigned long long* frame_in;  // bwd
@@ -197,9 +199,6 @@ hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, bool split, hipStre
 hipError_t gcr_launch_zero_grad_records(int nblocks, int chunk, const uint32_t* vis_list, const uint32_t* vis_count,
                                         float4* grad_rec, int rec_quads, hipStream_t s);
 hipError_t gcr_launch_fill(const GcrFillArgs& f, hipStream_t s);
-// last kernel of an asynchronous frame (gcr_binning.hip k_frame_gate)
-hipError_t gcr_launch_frame_gate(const unsigned long long* frame, unsigned long long* words, unsigned int seq,
-                                 unsigned int max_polls, hipStream_t s);
 hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long long* total,
                                       hipStream_t s);
 // fallback binning: per-Gaussian tile counts from radii + record rect, then emit in index order

@@ -168,6 +168,7 @@ class _TicketRing:
             raise RuntimeError("gcr_host_words_alloc failed (pinned host memory for the frame tickets)")
         self.words = [(C.c_uint64 * N.TICKET_WORDS).from_address(self.base + 8 * N.TICKET_WORDS * i) for i in range(_RING)]
         self.tickets = [None] * _RING
+        self.pending = collections.deque()  # unresolved tickets, oldest first
         self.next = 0
         self.seq = 0
 
@@ -181,10 +182,10 @@ class _TicketRing:
         return i, self.words[i], self.base + 8 * N.TICKET_WORDS * i, self.seq
 
     def harvest(self):
-        """Resolve whatever has been published (never blocks): keeps the capacity hints fresh."""
-        for t in self.tickets:
-            if t is not None and t._R is None:
-                t.done()
+        """Resolve what has been published, oldest first, without blocking: keeps the capacity hints fresh."""
+        p = self.pending
+        while p and p[0].done():
+            p.popleft()
 
 
 def _ring(lib):
@@ -367,6 +368,7 @@ def _forward(L, device, cam, g, P, H, W, ticket=False):
                 "gcr_forward_async")
         t = FrameTicket(L, words, addr, seq, capacity, stream, key, stateful)
         ring.tickets[slot] = t
+        ring.pending.append(t)
         _meta_put(geom, stateful, t, list_cap)
         return t, out_color, radii, geom, binning, img
     info = N.FrameInfo()

@@ -165,7 +165,7 @@ def test_backward_on_a_frame_without_state_is_binned_again_or_poisoned_never_sil
     big = torch.zeros((N.lib().gcr_binning_bytes(R, W, H),), dtype=torch.uint8, device=cuda_device)
     big[:binning.numel()] = binning
     g = G.run_backward(args, (R, color, radii, geom, big, img), dpix, cuda_device)
-    vis = fr.radii > 0
+    vis = (fr.radii > 0) & (fr.tiles_touched[:P] > 0)   # K1's survivors: the Gaussians the backward visits
     assert vis.sum() > 100
     for n in ("dL_dmean3D", "dL_dopacity", "dL_dscale", "dL_drot", "dL_dmean2D"):
         a = g[n].reshape(P, -1)
