@@ -21,6 +21,7 @@ import torch
 from . import ext as _ext
 
 _EMPTY = None
+_CPU = torch.device("cpu")
 
 
 def _absent():
@@ -232,8 +233,8 @@ class GaussianRasterizerWrapper(torch.nn.Module):
         P[3, 2] = -1.0
         return torch.from_numpy(P).to(self.device)
 
-    def _get_w2c_matrix(self, cam_position, cam_quaternion):
-        # dgr/__init__.py:349-368
+    def _get_w2c_matrix(self, cam_position, cam_quaternion, device=None):
+        # dgr/__init__.py:349-368 (`device`: where the result lives; None = self.device, as upstream)
         if isinstance(cam_position, torch.Tensor):
             cam_position = cam_position.cpu().numpy()
         if isinstance(cam_quaternion, torch.Tensor):
@@ -245,7 +246,7 @@ class GaussianRasterizerWrapper(torch.nn.Module):
         w2c[:3, :3] = rot.transpose()
         w2c[:3, [3]] = -rot.transpose() @ cam_position[:, None]
         w2c[3, 3] = 1.0
-        return torch.from_numpy(w2c).to(self.device)
+        return torch.from_numpy(w2c).to(self.device if device is None else device)
 
     def _get_gaussian_rasterization_settings(self, cam_position, cam_quaternion):
         # dgr/__init__.py:382-402: row-vector (transposed) matrices, black background,
@@ -277,11 +278,8 @@ class GaussianRasterizerWrapper(torch.nn.Module):
 
     def _reference_recipe_on_host(self, cam_position, cam_quaternion):
         """dgr/__init__.py:349-402 operation by operation, on CPU tensors (host_camera="reference")."""
-        dev, self.device = self.device, torch.device("cpu")
-        try:
-            view = self._get_w2c_matrix(cam_position, cam_quaternion).transpose(0, 1)
-        finally:
-            self.device = dev
+        view = self._get_w2c_matrix(cam_position, cam_quaternion, device=_CPU).transpose(0, 1)  # (no shared state is
+        #                                  touched: two threads may share one wrapper, ADVICE r03)
         if getattr(self, "_P_cpu_t", None) is None:
             self._P_cpu_t = self.P.detach().cpu().transpose(0, 1)
             self._bg_host = torch.zeros(3, dtype=torch.float32)
@@ -359,5 +357,11 @@ class GaussianRasterizerWrapper(torch.nn.Module):
         _, n_channels = points.shape
         assert n_channels == 14, "The input tensor should have 14 channels."
         if gaussian_rasterizer is None:
-            gaussian_rasterizer = self.get_gaussian_rasterizer(cam_position, cam_quaternion)
+            rs = self._get_gaussian_rasterization_settings(cam_position, cam_quaternion)
+            if points.is_cuda and points.dtype == torch.float32:
+                # this build's own rasterizer on the [N,14] tensor in place (see _get_gaussian_rasterization): the
+                # GaussianRasterizer module the reference constructs per frame (dgr/__init__.py:376-380) would only be
+                # unpacked again -- ten microseconds of a host-bound loop
+                return _RasterizePoints14Function.apply(points, rs, bool(self.flip_lr), bool(self.flip_ud), crop)
+            gaussian_rasterizer = GaussianRasterizer(raster_settings=rs)
         return self._get_gaussian_rasterization(points, gaussian_rasterizer, crop)

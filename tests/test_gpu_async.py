@@ -157,6 +157,8 @@ def test_backward_on_a_frame_without_state_is_binned_again_or_poisoned_never_sil
     args, out = G.run_forward(rs, sc, cuda_device, for_backward=False)
     _check_forward(fr, G.decode(P, W, H, out), P, True)
     _check_grads(fr.backward(dpix), G.run_backward(args, out, dpix, cuda_device), ALL_GRADS)
+    # (that backward rendered the frame's state into a buffer of its own and stamped the frame with it: a fresh frame)
+    args, out = G.run_forward(rs, sc, cuda_device, for_backward=False)
     with ext._meta_lock:
         ext._frame_meta.clear()
     with pytest.raises(RuntimeError, match="binning buffer too small"):

@@ -1,6 +1,14 @@
 """A fixed slice of tools/fuzz_parity.py's randomised sweep (random sizes, counts, extents, opacities, SH degrees,
-poses, options) as a -m gpu test: every case must agree with the oracle -- forward bit for bit, gradients within
-1e-4 * max."""
+poses, options) as a -m gpu test: every case must agree with the oracle -- forward bit for bit, gradients within the
+THREE tolerance tiers of tools/fuzz_parity.py, which this test applies unchanged:
+
+    1e-4 * max(1, max|ref|)   the north-star bar: every case whose largest scale stays within 8 and that is not dense
+    3e-4 * max                dense frames (regimes "dense" / "*_pile": thousands of overlapping Gaussians per tile)
+    5e-3 * max                scenes with scales beyond 8 (smax > 8: near-degenerate 2D covariances, 1 / det^2 in the
+                              conic gradient; fp32 itself is the limit -- the float64 evidence is in the tool's docstring)
+
+The slice = the generator's first 40 cases (8 of them in the 1e-4 tier) plus the next cases of the 1e-4 tier until 20
+such cases have run, so that the looser tiers cannot swallow the bar."""
 import os
 import sys
 
@@ -20,11 +28,17 @@ def test_randomised_parity_sweep(oracle_mod, cuda_device):
     rng = np.random.default_rng(20240917)
     bad = []
     regimes = set()
-    for i in range(40):
+    strict = 0
+    for i in range(160):
         c = F.draw_case(rng)
+        is_strict = F.gradient_tolerance(c) == F.GRAD_TOL
+        if i >= 40 and (not is_strict or strict >= 20):
+            continue
         regimes.add(c["regime"])
+        strict += 1 if is_strict else 0
         fails = F.run_case(c, oracle_mod, G, scenes, N, cuda_device)
         if fails:
             bad.append((i, fails, c))
     assert len(regimes) >= 4
+    assert strict >= 20, "only %d cases were held to 1e-4 * max" % strict
     assert not bad, bad[:3]

@@ -40,6 +40,13 @@ GRAD_TOL_ILL_CONDITIONED = 5e-3   # scenes with scales beyond 8
 GRADS = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
 
 
+def gradient_tolerance(c):
+    """The tier a case's gradients are held to (see the module docstring): relative to max(1, max|ref|)."""
+    if c["smax"] > 8.0:
+        return GRAD_TOL_ILL_CONDITIONED
+    return GRAD_TOL_DENSE if c["regime"] in ("dense", "translucent_pile", "opaque_pile") else GRAD_TOL
+
+
 def draw_case(rng):
     """One random frame description (plain dict, JSON-able)."""
     W = int(rng.choice([16, 17, 31, 48, 64, 97, 160, 208, 333]))
@@ -110,9 +117,7 @@ def run_case(c, O, G, scenes, N, dev):
                 if n == "dL_dcolor" and c["use_sh"]:
                     continue
                 ref, got = gref[n], ggpu[n].reshape(gref[n].shape)
-                rel = GRAD_TOL_ILL_CONDITIONED if c["smax"] > 8.0 else (
-                    GRAD_TOL_DENSE if c["regime"] in ("dense", "translucent_pile", "opaque_pile") else GRAD_TOL)
-                tol = rel * max(1.0, float(np.abs(ref).max()))
+                tol = gradient_tolerance(c) * max(1.0, float(np.abs(ref).max()))
                 err = float(np.abs(ref - got).max()) if ref.size else 0.0
                 if not (err <= tol) or not np.isfinite(got).all():
                     fails.append("%s err %.3g > %.3g" % (n, err, tol))
