@@ -130,6 +130,21 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
 
+    # Rank -> CPU affinity (counterpart of utils/distributed.py:19-62) BEFORE anything initialises HIP: the runtime's
+    # helper threads and the first pinned allocations then come up on the GPU's NUMA node.  From sysfs alone
+    # (affinity.bind_rank_early); GCR_NO_AFFINITY=1 disables it, GCR_AFFINITY=late reproduces round 3's binding after
+    # torch.cuda.set_device for the A/B (profiles/r04_affinity_ab.json).
+    import importlib.util
+    _spec = importlib.util.spec_from_file_location("_gcr_affinity", os.path.join(ROOT, "gaussiancity_amd", "affinity.py"))
+    _aff = importlib.util.module_from_spec(_spec)
+    _spec.loader.exec_module(_aff)
+    args.full_cpu_mask = os.sched_getaffinity(0)  # the CPU baseline legs run on all host cores again
+    late_affinity = os.environ.get("GCR_AFFINITY") == "late"
+    share_gpu_early = os.environ.get("GCR_BENCH_SHARE_GPU") == "1"
+    args.affinity = None
+    if not late_affinity and not share_gpu_early:
+        args.affinity = _aff.bind_rank_early(int(os.environ.get("LOCAL_RANK", "0")))
+
     import torch
     import torch.distributed as dist
     from gaussiancity_amd import _native as N
@@ -151,13 +166,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if not share_gpu:
-        # every rank keeps to the CPUs of its GPU's NUMA node (counterpart of utils/distributed.py:19-62): the frame
-        # loop is host-enqueue-bound and its pinned ticket words are first-touched after the binding.  Also at N = 1, so
-        # that the N = 1 line of a scaling run is the same program as the headline run.
+    if late_affinity and not share_gpu:
         from gaussiancity_amd.affinity import bind_rank_to_gpu
-        args.full_cpu_mask = os.sched_getaffinity(0)  # the CPU baseline legs run on all host cores again
         args.affinity = bind_rank_to_gpu(local_rank)
+        args.affinity["when"] = "after torch.cuda.set_device (GCR_AFFINITY=late)"
     args.rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -39,9 +39,38 @@ def gpu_pci_address(device_index):
     return "%04x:%02x:%02x.0" % (dom, bus, dev)
 
 
-def gpu_local_cpus(device_index, sysfs="/sys/bus/pci/devices"):
+def kfd_gpu_pci_addresses(topology="/sys/class/kfd/kfd/topology/nodes"):
+    """PCI addresses of the GPU agents in KFD node order -- HIP's device order -- read from sysfs WITHOUT touching the
+    HIP runtime, so that a rank can bind itself before the runtime (and its helper threads, and the first pinned
+    allocations) exist.  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES lists of plain indices are honoured; anything else
+    (UUIDs) -> [] and the caller falls back to the runtime's answer."""
+    try:
+        nodes = sorted((int(n) for n in os.listdir(topology) if n.isdigit()))
+    except OSError:
+        return []
+    gpus = []
+    for n in nodes:
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(topology, str(n), "properties")) if " " in line)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue  # a CPU agent
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        except (OSError, ValueError, KeyError):
+            return []
+        gpus.append("%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            try:
+                gpus = [gpus[int(i)] for i in v.split(",") if i.strip() != ""]
+            except (ValueError, IndexError):
+                return []
+    return gpus
+
+
+def gpu_local_cpus(device_index, sysfs="/sys/bus/pci/devices", pci=None):
     """(cpus, numa_node, why): the CPUs local to the GPU according to sysfs; cpus == [] with a reason otherwise."""
-    addr = gpu_pci_address(device_index)
+    addr = pci if pci is not None else gpu_pci_address(device_index)
     if addr is None:
         return [], None, "no PCI address for device %s" % device_index
     base = os.path.join(sysfs, addr)
@@ -57,12 +86,27 @@ def gpu_local_cpus(device_index, sysfs="/sys/bus/pci/devices"):
     return cpus, node, "ok" if cpus else "empty local_cpulist for %s" % addr
 
 
-def bind_rank_to_gpu(device_index, sysfs="/sys/bus/pci/devices"):
+def bind_rank_early(device_index, sysfs="/sys/bus/pci/devices", topology="/sys/class/kfd/kfd/topology/nodes"):
+    """bind_rank_to_gpu() from sysfs alone, to be called BEFORE the process initialises HIP.  Measured (round 4,
+    profiles/r04_affinity_ab.json): binding AFTER torch.cuda.set_device -- what round 3 did -- made the host-bound C4
+    leg 70 % slower (0.199 -> 0.336 ms): the runtime's threads and the pinned memory allocated so far stay where they
+    were, and the rank's own threads now reach them across the socket."""
+    if os.environ.get("GCR_NO_AFFINITY") == "1":
+        return {"bound": False, "cpus": 0, "numa_node": None, "why": "GCR_NO_AFFINITY=1"}
+    gpus = kfd_gpu_pci_addresses(topology)
+    if device_index >= len(gpus):
+        return {"bound": False, "cpus": 0, "numa_node": None, "why": "no KFD topology entry for device %d" % device_index}
+    r = bind_rank_to_gpu(device_index, sysfs, pci=gpus[device_index])
+    r["when"] = "before HIP initialisation"
+    return r
+
+
+def bind_rank_to_gpu(device_index, sysfs="/sys/bus/pci/devices", pci=None):
     """os.sched_setaffinity(this process, CPUs local to the GPU).  Returns a dict for logs:
     {"bound": bool, "cpus": n, "numa_node": k, "why": str}."""
     if os.environ.get("GCR_NO_AFFINITY") == "1":
         return {"bound": False, "cpus": 0, "numa_node": None, "why": "GCR_NO_AFFINITY=1"}
-    cpus, node, why = gpu_local_cpus(device_index, sysfs)
+    cpus, node, why = gpu_local_cpus(device_index, sysfs, pci)
     if not cpus:
         return {"bound": False, "cpus": 0, "numa_node": node, "why": why}
     allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))  # never widen a mask the launcher / cgroup set
@@ -73,7 +117,7 @@ def bind_rank_to_gpu(device_index, sysfs="/sys/bus/pci/devices"):
     except OSError as e:
         return {"bound": False, "cpus": 0, "numa_node": node, "why": "sched_setaffinity: %s" % e}
     return {"bound": True, "cpus": len(allowed), "numa_node": node, "why": "ok", "cpulist": format_cpulist(allowed),
-            "pci": gpu_pci_address(device_index)}
+            "pci": pci if pci is not None else gpu_pci_address(device_index)}
 
 
 def format_cpulist(cpus):

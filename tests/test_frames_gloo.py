@@ -200,6 +200,26 @@ def test_rank_affinity_from_sysfs(tmp_path, monkeypatch):
         assert summary["ring_lines"] == 1 and summary["tree_lines"] == 1 and summary["version"].startswith("2.22")
     finally:
         os.sched_setaffinity(0, mine)
+    # binding before HIP exists: the GPU agents' PCI addresses from a (fake) KFD topology, CPU agents skipped,
+    # *_VISIBLE_DEVICES index lists honoured
+    topo = tmp_path / "kfd"
+    for n, (simd, loc) in enumerate([(0, 0), (0, 0), (1024, 0xc100), (1024, 0x8b00)]):
+        d = topo / str(n)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count 64\nsimd_count %d\nlocation_id %d\ndomain 0\n" % (simd, loc))
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert A.kfd_gpu_pci_addresses(str(topo)) == ["0000:c1:00.0", "0000:8b:00.0"]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert A.kfd_gpu_pci_addresses(str(topo)) == ["0000:8b:00.0"]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    try:
+        r = A.bind_rank_early(0, sysfs=str(tmp_path), topology=str(topo))
+        assert r["bound"] is True and r["pci"] == "0000:c1:00.0" and r["when"].startswith("before HIP")
+    finally:
+        os.sched_setaffinity(0, mine)
+    assert A.bind_rank_early(5, sysfs=str(tmp_path), topology=str(topo))["bound"] is False
+    assert A.kfd_gpu_pci_addresses(str(tmp_path / "nowhere")) == []
     monkeypatch.setenv("GCR_NO_AFFINITY", "1")
     assert A.bind_rank_to_gpu(0, sysfs=str(tmp_path))["bound"] is False
     monkeypatch.delenv("GCR_NO_AFFINITY")
