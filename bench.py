@@ -109,6 +109,10 @@ def main():
                     help="time the native module's positional rasterize_gaussians() (returns num_rendered as an int: one "
                          "host wait per frame, the reference's contract) instead of the Python API GaussianRasterizer "
                          "(returns image and radii; this build does not wait for num_rendered there)")
+    ap.add_argument("--chain-k1", type=int, default=None, choices=[0, 1],
+                    help="frames without the host wait: frame f+1's K1 waits for frame f's K1 (gcr_camera.after_event / "
+                         "k1_event): the HBM-bound K1 launches of frames on different streams never overlap each other; "
+                         "default = the package's (ext.chain_k1)")
     ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the frame loop alternates over (frames are independent; 1 = serial); "
                          "default 3 (measured optimum for both paths: C3 forward 4 520 / 4 700 / 4 690 frames/s "
@@ -139,11 +143,15 @@ def main():
     _aff = importlib.util.module_from_spec(_spec)
     _spec.loader.exec_module(_aff)
     args.full_cpu_mask = os.sched_getaffinity(0)  # the CPU baseline legs run on all host cores again
+    # N = 1 is not bound unless GCR_AFFINITY says so (one process has the whole host; round 4's A/B of none / early /
+    # late binding at N = 1 was inside the noise of the host-bound lines, profiles/r04_affinity_ab.jsonl)
+    want_affinity = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("GCR_AFFINITY") in ("early", "late", "1")
     late_affinity = os.environ.get("GCR_AFFINITY") == "late"
     share_gpu_early = os.environ.get("GCR_BENCH_SHARE_GPU") == "1"
     args.affinity = None
-    if not late_affinity and not share_gpu_early:
+    if want_affinity and not late_affinity and not share_gpu_early:
         args.affinity = _aff.bind_rank_early(int(os.environ.get("LOCAL_RANK", "0")))
+        late_affinity = not args.affinity.get("bound") and os.environ.get("GCR_NO_AFFINITY") != "1"  # no KFD sysfs: late
 
     import torch
     import torch.distributed as dist
@@ -166,10 +174,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if late_affinity and not share_gpu:
+    if want_affinity and late_affinity and not share_gpu:
         from gaussiancity_amd.affinity import bind_rank_to_gpu
+        early_why = (args.affinity or {}).get("why")
         args.affinity = bind_rank_to_gpu(local_rank)
-        args.affinity["when"] = "after torch.cuda.set_device (GCR_AFFINITY=late)"
+        args.affinity["when"] = "after torch.cuda.set_device" + (" (early binding: %s)" % early_why if early_why else "")
     args.rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -202,6 +211,8 @@ def main():
         return got if rank == 0 else None
     args.collect_ranks = collect_ranks
     N.lib()
+    if args.chain_k1 is not None:
+        ext.chain_k1 = bool(args.chain_k1)
     N.set_option("fast_exp", 1 if args.fast_exp else 0)
     N.set_option("split_preprocess", 1 if args.split_preprocess else 0)
     N.set_option("sort_in_blend", 1 if args.sort_in_blend else 0)
@@ -559,6 +570,7 @@ def main():
                        "parallelism": "frames sharded round-robin, one frame per GPU, no data-path collective; "
                                       "%d HIP streams per GPU alternate over consecutive frames (`value` is a throughput "
                                       "with that many frames in flight; `frame_latency_ms` is one frame alone)" % len(streams),
+                       "chain_k1": bool(ext.chain_k1),
                        "exp": "v_exp_f32 (non-parity)" if args.fast_exp else "%s (bit-exact vs oracle)" % NUMERICS,
                        "tile_sort": "every list sorted whole (--sort-whole)" if args.sort_whole else
                                     "lists beyond 1024 entries sorted lazily, as far as the blend walks (default)"},

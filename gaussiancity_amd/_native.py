@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = (
     "gcr_backward", "gcr_mark_visible", "gcr_rasterize_forward", "gcr_set_option",
     "gcr_get_stage_ms", "gcr_grad_record_floats", "gcr_grad_record_floats_opt", "gcr_binning_bytes_lean",
     "gcr_forward_async", "gcr_ticket_poll", "gcr_ticket_wait", "gcr_host_words_alloc", "gcr_host_words_free", "gcr_rescue_count",
+    "gcr_event_create", "gcr_event_destroy",
 )
 GRAD_REC_FLOATS = 16  # gcr_grad_record_floats() by default (32 under option "deterministic_backward": ext asks per call)
 
@@ -54,6 +55,7 @@ class Camera(C.Structure):
         ("win_x", C.c_int32), ("win_y", C.c_int32), ("win_w", C.c_int32), ("win_h", C.c_int32),  # output window
         ("backward", C.c_int32),  # 1: a backward call will follow (the forward blend leaves its per-piece state)
         ("options", C.POINTER(Options)),  # per-call options or NULL
+        ("after_event", C.c_void_p), ("k1_event", C.c_void_p),  # scheduling hints of a multi-stream frame loop
     ]
 
 
@@ -155,6 +157,9 @@ def lib():
     L.gcr_ticket_wait.restype = C.c_int
     L.gcr_ticket_wait.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_void_p, C.POINTER(FrameInfo)]
     L.gcr_rescue_count.restype = C.c_long
+    L.gcr_event_create.restype = C.c_void_p
+    L.gcr_event_destroy.restype = None
+    L.gcr_event_destroy.argtypes = [C.c_void_p]
     L.gcr_grad_record_floats_opt.restype = C.c_int
     L.gcr_grad_record_floats_opt.argtypes = [C.POINTER(Options)]
     L.gcr_forward_render.restype = C.c_int

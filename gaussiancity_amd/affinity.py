@@ -87,10 +87,10 @@ def gpu_local_cpus(device_index, sysfs="/sys/bus/pci/devices", pci=None):
 
 
 def bind_rank_early(device_index, sysfs="/sys/bus/pci/devices", topology="/sys/class/kfd/kfd/topology/nodes"):
-    """bind_rank_to_gpu() from sysfs alone, to be called BEFORE the process initialises HIP.  Measured (round 4,
-    profiles/r04_affinity_ab.json): binding AFTER torch.cuda.set_device -- what round 3 did -- made the host-bound C4
-    leg 70 % slower (0.199 -> 0.336 ms): the runtime's threads and the pinned memory allocated so far stay where they
-    were, and the rank's own threads now reach them across the socket."""
+    """bind_rank_to_gpu() from sysfs alone, to be called BEFORE the process initialises HIP, so that the runtime's
+    helper threads and the first pinned allocations come up on the GPU's NUMA node (a binding made after
+    torch.cuda.set_device leaves them where they were).  Where the KFD topology is not visible (the gpurun boxes of
+    this project: their containers do not mount it) the caller falls back to the late binding."""
     if os.environ.get("GCR_NO_AFFINITY") == "1":
         return {"bound": False, "cpus": 0, "numa_node": None, "why": "GCR_NO_AFFINITY=1"}
     gpus = kfd_gpu_pci_addresses(topology)

@@ -371,6 +371,7 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
   const int NG = op.force_global_cursor ? 0 : gcr_tile_table_groups(T, a.nblocks, &G);
   uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
   uint32_t* ranges = (uint32_t*)(ib + L.img_ranges);
+  if (cam->after_event) HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)cam->after_event, 0), "wait for the previous frame's K1");
   if (NG > 0) {
     // default: per-tile counts are built in LDS tables after K1 (no global atomics)
     a.tile_count = nullptr;
@@ -378,6 +379,7 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
       StageTimer t(s, ST_PRE);
       HIP_TRY(gcr_launch_preprocess(a, op.split_preprocess != 0, s), "preprocess");
     }
+    if (cam->k1_event) HIP_TRY(hipEventRecord((hipEvent_t)cam->k1_event, s), "record K1's event");
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
     // tile_total | tile_local | blk_total share the (T x 128 B) cursor region, unused on this path
@@ -391,6 +393,7 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
       HIP_TRY(hipMemsetAsync(a.tile_count, 0, sizeof(uint32_t) * GCR_CURSOR_STRIDE * (size_t)T, s), "tile count memset");
       HIP_TRY(gcr_launch_preprocess(a, op.split_preprocess != 0, s), "preprocess");
     }
+    if (cam->k1_event) HIP_TRY(hipEventRecord((hipEvent_t)cam->k1_event, s), "record K1's event");
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
     HIP_TRY(gcr_launch_scan_tiles(cursor, GCR_CURSOR_STRIDE, ranges, T, frame, cap_instances, cap_list, host_R, seq, s),
@@ -702,6 +705,8 @@ class RescueService {
       cam.backward = 0;  // the temporary buffer dies with the rescue: no backward state (gcr_forward_render with
       //                    out_color == NULL rebuilds it in a buffer of the caller's when a backward follows)
       cam.options = f.has_opt ? &f.opt : nullptr;
+      cam.after_event = nullptr;
+      cam.k1_event = nullptr;
       if (cam.host_camera) {
         cam.view_matrix = f.camvals;
         cam.proj_matrix = f.camvals + 16;
@@ -792,6 +797,14 @@ class RescueService {
 static RescueService& rescue_service() {
   static RescueService* r = new RescueService();
   return *r;
+}
+
+void* gcr_event_create(void) {
+  hipEvent_t e = nullptr;
+  return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? (void*)e : nullptr;
+}
+void gcr_event_destroy(void* event) {
+  if (event) (void)hipEventDestroy((hipEvent_t)event);
 }
 
 long gcr_rescue_count(void) { return rescue_service().rescued(); }  // diagnostics: frames that needed the rescue so far

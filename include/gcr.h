@@ -110,6 +110,14 @@ typedef struct gcr_camera {
                           rendered Gaussian come out as NaN (never as plausible zeros) -- render its state first with
                           gcr_forward_render(out_color = NULL, backward = 1) into a gcr_binning_bytes() buffer */
   const gcr_options *options; /* HOST pointer or NULL (= all defaults); read during the call only */
+  /* Scheduling hints of a frame LOOP that alternates frames over several streams (ABI v6; both NULL by default, never
+   * change a result).  Events from gcr_event_create().  The forward waits for `after_event` on its stream before its
+   * first kernel and records `k1_event` right after the preprocess kernel (K1).  A caller that hands frame f's
+   * k1_event to frame f+1 as after_event keeps the K1 launches of consecutive frames -- the HBM-bound kernel of a
+   * frame -- from running at the same time (where they would share the memory bandwidth three ways and then leave it
+   * idle together), so that every K1 streams at full bandwidth beside the VALU-bound blend of the frames before it. */
+  void *after_event;
+  void *k1_event;
 } gcr_camera;
 
 /* Per-Gaussian inputs (argument list of cr/rasterizer.h:25-37) */
@@ -289,6 +297,9 @@ int gcr_ticket_poll(const unsigned long long *words_host, uint32_t seq, int64_t 
 int gcr_ticket_wait(const unsigned long long *words_host, uint32_t seq, int64_t binning_capacity,
                     void *hip_stream, gcr_frame_info *info_host);
 long gcr_rescue_count(void); /* diagnostics: asynchronous frames of this process that needed the rescue so far */
+/* events for gcr_camera.after_event / k1_event (hipEvent_t without timing); NULL on failure */
+void *gcr_event_create(void);
+void gcr_event_destroy(void *event);
 
 /* K3 (instance emit) + K4 (depth sort inside every tile, ties in ascending Gaussian index ==
  * the reference's stable radix sort by tile|depth) + K5 (tile ranges) + K6 (blend).
