@@ -109,10 +109,8 @@ def main():
                     help="time the native module's positional rasterize_gaussians() (returns num_rendered as an int: one "
                          "host wait per frame, the reference's contract) instead of the Python API GaussianRasterizer "
                          "(returns image and radii; this build does not wait for num_rendered there)")
-    ap.add_argument("--chain-k1", type=int, default=None, choices=[0, 1],
-                    help="frames without the host wait: frame f+1's K1 waits for frame f's K1 (gcr_camera.after_event / "
-                         "k1_event): the HBM-bound K1 launches of frames on different streams never overlap each other; "
-                         "default = the package's (ext.chain_k1)")
+    ap.add_argument("--bucket-scatter", type=int, default=None, choices=[0, 1],
+                    help="A/B: option bucket_scatter (two-pass scatter through 64-tile blocks; default = the library's)")
     ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the frame loop alternates over (frames are independent; 1 = serial); "
                          "default 3 (measured optimum for both paths: C3 forward 4 520 / 4 700 / 4 690 frames/s "
@@ -211,8 +209,8 @@ def main():
         return got if rank == 0 else None
     args.collect_ranks = collect_ranks
     N.lib()
-    if args.chain_k1 is not None:
-        ext.chain_k1 = bool(args.chain_k1)
+    if args.bucket_scatter is not None:
+        N.set_option("bucket_scatter", args.bucket_scatter)
     N.set_option("fast_exp", 1 if args.fast_exp else 0)
     N.set_option("split_preprocess", 1 if args.split_preprocess else 0)
     N.set_option("sort_in_blend", 1 if args.sort_in_blend else 0)
@@ -570,7 +568,6 @@ def main():
                        "parallelism": "frames sharded round-robin, one frame per GPU, no data-path collective; "
                                       "%d HIP streams per GPU alternate over consecutive frames (`value` is a throughput "
                                       "with that many frames in flight; `frame_latency_ms` is one frame alone)" % len(streams),
-                       "chain_k1": bool(ext.chain_k1),
                        "exp": "v_exp_f32 (non-parity)" if args.fast_exp else "%s (bit-exact vs oracle)" % NUMERICS,
                        "tile_sort": "every list sorted whole (--sort-whole)" if args.sort_whole else
                                     "lists beyond 1024 entries sorted lazily, as far as the blend walks (default)"},

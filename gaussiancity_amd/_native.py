@@ -19,7 +19,6 @@ EXPORTED_SYMBOLS = (
     "gcr_backward", "gcr_mark_visible", "gcr_rasterize_forward", "gcr_set_option",
     "gcr_get_stage_ms", "gcr_grad_record_floats", "gcr_grad_record_floats_opt", "gcr_binning_bytes_lean",
     "gcr_forward_async", "gcr_ticket_poll", "gcr_ticket_wait", "gcr_host_words_alloc", "gcr_host_words_free", "gcr_rescue_count",
-    "gcr_event_create", "gcr_event_destroy",
 )
 GRAD_REC_FLOATS = 16  # gcr_grad_record_floats() by default (32 under option "deterministic_backward": ext asks per call)
 
@@ -31,10 +30,10 @@ class Options(C.Structure):
     """gcr_options: per-call overrides of the gcr_set_option() defaults (-1 = the default)."""
     _fields_ = [(n, C.c_int32) for n in (
         "fast_exp", "lazy_sort", "sort_in_blend", "bwd_piece", "deterministic_backward", "split_preprocess",
-        "force_radix", "force_global_cursor")]
+        "force_radix", "force_global_cursor", "bucket_scatter")]
 
     def __init__(self, **kw):
-        super().__init__(*([-1] * 8))
+        super().__init__(*([-1] * 9))
         for k, v in kw.items():
             if k not in dict(self._fields_):
                 raise TypeError("unknown rasterizer option %r" % k)
@@ -55,7 +54,6 @@ class Camera(C.Structure):
         ("win_x", C.c_int32), ("win_y", C.c_int32), ("win_w", C.c_int32), ("win_h", C.c_int32),  # output window
         ("backward", C.c_int32),  # 1: a backward call will follow (the forward blend leaves its per-piece state)
         ("options", C.POINTER(Options)),  # per-call options or NULL
-        ("after_event", C.c_void_p), ("k1_event", C.c_void_p),  # scheduling hints of a multi-stream frame loop
     ]
 
 
@@ -87,7 +85,7 @@ class Layout(C.Structure):
         ("geom_num_rendered", C.c_size_t), ("geom_block_tiles", C.c_size_t), ("geom_total", C.c_size_t),
         ("img_final_T", C.c_size_t), ("img_n_contrib", C.c_size_t), ("img_ranges", C.c_size_t),
         ("img_tile_cursor", C.c_size_t), ("img_tile_table", C.c_size_t), ("img_tile_lazy", C.c_size_t),
-        ("img_total", C.c_size_t),
+        ("img_bucket_base", C.c_size_t), ("img_total", C.c_size_t),
         ("bin_keys", C.c_size_t * 2), ("bin_vals", C.c_size_t * 2), ("bin_hist", C.c_size_t),
         ("bin_sorted", C.c_size_t), ("bin_work", C.c_size_t), ("bin_mask", C.c_size_t), ("bin_ckpt", C.c_size_t),
         ("bin_total", C.c_size_t), ("bin_lean_total", C.c_size_t),
@@ -157,9 +155,6 @@ def lib():
     L.gcr_ticket_wait.restype = C.c_int
     L.gcr_ticket_wait.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_void_p, C.POINTER(FrameInfo)]
     L.gcr_rescue_count.restype = C.c_long
-    L.gcr_event_create.restype = C.c_void_p
-    L.gcr_event_destroy.restype = None
-    L.gcr_event_destroy.argtypes = [C.c_void_p]
     L.gcr_grad_record_floats_opt.restype = C.c_int
     L.gcr_grad_record_floats_opt.argtypes = [C.POINTER(Options)]
     L.gcr_forward_render.restype = C.c_int

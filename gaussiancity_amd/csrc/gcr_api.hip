@@ -24,6 +24,7 @@ std::atomic<int> g_lazy_sort{1};         // 1: long tile lists are sorted segmen
 std::atomic<int> g_sort_in_blend{0};     // 1: the forward blend sorts short tile lists itself (lower frame latency, lower throughput)
 std::atomic<int> g_split_preprocess{0};  // 1: K1 as two kernels (streaming cull, then exact pass) instead of the fused one
 std::atomic<int> g_deterministic{0};  // 1: fixed-point gradient records (order-independent sums), gcr_internal.h
+std::atomic<int> g_bucket_scatter{1};    // 1: two-pass scatter through 64-tile blocks (gcr_binning.hip "bucketed")
 std::atomic<int> g_bwd_piece{128};  // entries per backward piece of frames rendered for a backward (gcr_camera.backward)
 #ifdef GCR_EXPERIMENTS  // make EXTRA=-DGCR_EXPERIMENTS: timing experiments, never in the shipping library
 std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results are wrong when set
@@ -35,6 +36,7 @@ std::atomic<unsigned long long*> g_clock_buf{nullptr};  // K7 per-wave phase clo
 // Resolved once at the top of every entry point and handed down by value -- nothing below reads the globals.
 struct Opts {
   int fast_exp, lazy_sort, sort_in_blend, bwd_piece, deterministic, split_preprocess, force_radix, force_global_cursor;
+  int bucket_scatter;
 };
 Opts resolve_options(const gcr_options* o) {
   Opts r;
@@ -46,7 +48,9 @@ Opts resolve_options(const gcr_options* o) {
   r.split_preprocess = g_split_preprocess.load();
   r.force_radix = g_force_radix.load();
   r.force_global_cursor = g_force_global_cursor.load();
+  r.bucket_scatter = g_bucket_scatter.load();
   if (o != nullptr) {
+    if (o->bucket_scatter >= 0) r.bucket_scatter = o->bucket_scatter != 0;
     if (o->fast_exp >= 0) r.fast_exp = o->fast_exp != 0;
     if (o->lazy_sort >= 0) r.lazy_sort = o->lazy_sort != 0;
     if (o->sort_in_blend >= 0) r.sort_in_blend = o->sort_in_blend != 0;
@@ -179,6 +183,11 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
     L->img_tile_table = o;   o = align_up(o + (size_t)ng * T * sizeof(uint32_t));
   }
   L->img_tile_lazy = o;    o = align_up(o + T * 4 * sizeof(uint32_t));
+  {
+    int G = 1;
+    const int ng = gcr_tile_table_groups((int)T, GCR_K1_MAX_BLOCKS, &G);
+    L->img_bucket_base = o;  o = align_up(o + (size_t)ng * ((T + 63) / 64) * sizeof(uint32_t));
+  }
   L->img_total = o;
 
   const size_t r = (size_t)(R > 0 ? R : 0);
@@ -288,6 +297,7 @@ int gcr_set_option(const char* name, int value) {
   if (!strcmp(name, "split_preprocess")) return g_split_preprocess.exchange(value);
   if (!strcmp(name, "sort_in_blend")) return g_sort_in_blend.exchange(value);
   if (!strcmp(name, "lazy_sort")) return g_lazy_sort.exchange(value != 0);
+  if (!strcmp(name, "bucket_scatter")) return g_bucket_scatter.exchange(value != 0);
   if (!strcmp(name, "deterministic_backward")) return g_deterministic.exchange(value != 0);
   if (!strcmp(name, "bwd_piece")) {
     const int v = value < GCR_PIECE_MIN ? GCR_PIECE_MIN : (value > GCR_PIECE_MAX ? GCR_PIECE_MAX : value);
@@ -371,7 +381,6 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
   const int NG = op.force_global_cursor ? 0 : gcr_tile_table_groups(T, a.nblocks, &G);
   uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
   uint32_t* ranges = (uint32_t*)(ib + L.img_ranges);
-  if (cam->after_event) HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)cam->after_event, 0), "wait for the previous frame's K1");
   if (NG > 0) {
     // default: per-tile counts are built in LDS tables after K1 (no global atomics)
     a.tile_count = nullptr;
@@ -379,13 +388,13 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
       StageTimer t(s, ST_PRE);
       HIP_TRY(gcr_launch_preprocess(a, op.split_preprocess != 0, s), "preprocess");
     }
-    if (cam->k1_event) HIP_TRY(hipEventRecord((hipEvent_t)cam->k1_event, s), "record K1's event");
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
     // tile_total | tile_local | blk_total share the (T x 128 B) cursor region, unused on this path
     HIP_TRY(gcr_launch_tile_count(T, a.gx, NG, G, a.nblocks, a.chunk, a.vis_list, a.vis_count, a.rec,
                                   (uint32_t*)(ib + L.img_tile_table), cursor, cursor + (size_t)T,
-                                  cursor + 2 * (size_t)T, frame, a.block_tiles, host_R, seq, s),
+                                  cursor + 2 * (size_t)T, frame, a.block_tiles, host_R, seq,
+                                  op.bucket_scatter ? (uint32_t*)(ib + L.img_bucket_base) : nullptr, s),
             "tile count");
   } else {
     {
@@ -393,7 +402,6 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
       HIP_TRY(hipMemsetAsync(a.tile_count, 0, sizeof(uint32_t) * GCR_CURSOR_STRIDE * (size_t)T, s), "tile count memset");
       HIP_TRY(gcr_launch_preprocess(a, op.split_preprocess != 0, s), "preprocess");
     }
-    if (cam->k1_event) HIP_TRY(hipEventRecord((hipEvent_t)cam->k1_event, s), "record K1's event");
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
     HIP_TRY(gcr_launch_scan_tiles(cursor, GCR_CURSOR_STRIDE, ranges, T, frame, cap_instances, cap_list, host_R, seq, s),
@@ -454,7 +462,16 @@ static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_g
   const int NG = op.force_global_cursor ? 0 : gcr_tile_table_groups(T, nblocks, &G);
   {
     StageTimer t(s, ST_EMIT);
-    if (NG > 0) {
+    if (NG > 0 && op.bucket_scatter && R_layout > 0) {
+      // two passes through 64-tile blocks (gcr_binning.hip); the intermediate (key, tile & 63) pairs live in the spare
+      // key / value halves of the binning buffer, which nothing else uses before the per-tile sort
+      uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
+      HIP_TRY(gcr_launch_bucket_scatter(T, gx, NG, G, nblocks, chunk, vis_list, vis_count, rec, cursor, cursor + (size_t)T,
+                                        cursor + 2 * (size_t)T, (const uint32_t*)(ib + L.img_bucket_base), ranges,
+                                        (uint64_t*)(bb + L.bin_keys[1]), (uint8_t*)(bb + L.bin_vals[1 - L.bin_sorted]), pairs,
+                                        frame_dev, cap_instances, cap_list, host_longest, s),
+              "bucket scatter");
+    } else if (NG > 0) {
       // also rebuilds `ranges` from the block totals, so it runs even when nothing is rendered
       uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
       HIP_TRY(gcr_launch_tile_scatter(T, gx, NG, G, nblocks, chunk, vis_list, vis_count, rec,
@@ -705,8 +722,6 @@ class RescueService {
       cam.backward = 0;  // the temporary buffer dies with the rescue: no backward state (gcr_forward_render with
       //                    out_color == NULL rebuilds it in a buffer of the caller's when a backward follows)
       cam.options = f.has_opt ? &f.opt : nullptr;
-      cam.after_event = nullptr;
-      cam.k1_event = nullptr;
       if (cam.host_camera) {
         cam.view_matrix = f.camvals;
         cam.proj_matrix = f.camvals + 16;
@@ -797,14 +812,6 @@ class RescueService {
 static RescueService& rescue_service() {
   static RescueService* r = new RescueService();
   return *r;
-}
-
-void* gcr_event_create(void) {
-  hipEvent_t e = nullptr;
-  return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? (void*)e : nullptr;
-}
-void gcr_event_destroy(void* event) {
-  if (event) (void)hipEventDestroy((hipEvent_t)event);
 }
 
 long gcr_rescue_count(void) { return rescue_service().rescued(); }  // diagnostics: frames that needed the rescue so far

@@ -102,7 +102,6 @@ _RING = 32  # asynchronous frames a host thread may have outstanding (the ring's
 # H): the host runs ahead of the device, so that number may be a few frames old -- twice it, plus a constant
 _ASYNC_FACTOR, _ASYNC_MARGIN = 2, 65536
 _SYNC_ONLY = os.environ.get("GCR_EXT_SYNC") == "1"  # measurement aid: keep the reference's host wait in every frame
-chain_k1 = os.environ.get("GCR_CHAIN_K1", "0") == "1"  # asynchronous frames: chain the K1 launches of consecutive frames
 
 
 class FrameTicket:
@@ -169,8 +168,6 @@ class _TicketRing:
             raise RuntimeError("gcr_host_words_alloc failed (pinned host memory for the frame tickets)")
         self.words = [(C.c_uint64 * N.TICKET_WORDS).from_address(self.base + 8 * N.TICKET_WORDS * i) for i in range(_RING)]
         self.tickets = [None] * _RING
-        self.events = [None] * _RING        # K1 events of the frames (gcr_camera.k1_event), created on first use
-        self.last_event = None              # ... and the newest one recorded: the next frame's after_event
         self.pending = collections.deque()  # unresolved tickets, oldest first
         self.next = 0
         self.seq = 0
@@ -365,14 +362,6 @@ def _forward(L, device, cam, g, P, H, W, ticket=False):
         capacity = _ASYNC_FACTOR * R_seen + _ASYNC_MARGIN
         binning = torch.empty((nbytes(capacity, W, H),), **byte)
         slot, words, addr, seq = ring.take()
-        if chain_k1:
-            # consecutive frames of this thread's loop: frame f+1's K1 starts when frame f's K1 is done (gcr.h,
-            # gcr_camera.after_event): the HBM-bound K1 launches of frames on different streams never overlap each other
-            ev = ring.events[slot]
-            if ev is None:
-                ev = ring.events[slot] = L.gcr_event_create()
-            cam.after_event, cam.k1_event = ring.last_event, ev
-            ring.last_event = ev
         N.check(L.gcr_forward_async(C.byref(cam), C.byref(g), geom.data_ptr(), gbytes, binning.data_ptr(), binning.numel(),
                                     capacity, list_cap, img.data_ptr(), ibytes, radii.data_ptr(), out_color.data_ptr(),
                                     addr, seq, stream),

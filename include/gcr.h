@@ -72,8 +72,9 @@ typedef struct gcr_options {
   int32_t split_preprocess;
   int32_t force_radix;
   int32_t force_global_cursor;
+  int32_t bucket_scatter;
 } gcr_options;
-#define GCR_OPTIONS_DEFAULT {-1, -1, -1, -1, -1, -1, -1, -1}
+#define GCR_OPTIONS_DEFAULT {-1, -1, -1, -1, -1, -1, -1, -1, -1}
 
 /* GaussianRasterizationSettings (dgr/__init__.py:203-215) */
 typedef struct gcr_camera {
@@ -110,14 +111,6 @@ typedef struct gcr_camera {
                           rendered Gaussian come out as NaN (never as plausible zeros) -- render its state first with
                           gcr_forward_render(out_color = NULL, backward = 1) into a gcr_binning_bytes() buffer */
   const gcr_options *options; /* HOST pointer or NULL (= all defaults); read during the call only */
-  /* Scheduling hints of a frame LOOP that alternates frames over several streams (ABI v6; both NULL by default, never
-   * change a result).  Events from gcr_event_create().  The forward waits for `after_event` on its stream before its
-   * first kernel and records `k1_event` right after the preprocess kernel (K1).  A caller that hands frame f's
-   * k1_event to frame f+1 as after_event keeps the K1 launches of consecutive frames -- the HBM-bound kernel of a
-   * frame -- from running at the same time (where they would share the memory bandwidth three ways and then leave it
-   * idle together), so that every K1 streams at full bandwidth beside the VALU-bound blend of the frames before it. */
-  void *after_event;
-  void *k1_event;
 } gcr_camera;
 
 /* Per-Gaussian inputs (argument list of cr/rasterizer.h:25-37) */
@@ -193,6 +186,8 @@ typedef struct gcr_layout {
   size_t img_tile_table;  /* uint32 [groups][T]: per-group tile counts, then exclusive prefixes */
   size_t img_tile_lazy;   /* uint32[4] per tile {n_sorted, 0, L lo, L hi}: the first n_sorted entries of the tile's
                              list are in final order, every key >= L is not among them (option "lazy_sort") */
+  size_t img_bucket_base; /* uint32 [T / 64][groups]: where a group's run starts inside a 64-tile block's segment of the
+                             two-pass scatter's intermediate buffer (option "bucket_scatter") */
   size_t img_total;
   /* binning buffer (per instance) */
   size_t bin_keys[2]; /* uint64 per instance, ping/pong */
@@ -297,9 +292,6 @@ int gcr_ticket_poll(const unsigned long long *words_host, uint32_t seq, int64_t 
 int gcr_ticket_wait(const unsigned long long *words_host, uint32_t seq, int64_t binning_capacity,
                     void *hip_stream, gcr_frame_info *info_host);
 long gcr_rescue_count(void); /* diagnostics: asynchronous frames of this process that needed the rescue so far */
-/* events for gcr_camera.after_event / k1_event (hipEvent_t without timing); NULL on failure */
-void *gcr_event_create(void);
-void gcr_event_destroy(void *event);
 
 /* K3 (instance emit) + K4 (depth sort inside every tile, ties in ascending Gaussian index ==
  * the reference's stable radix sort by tile|depth) + K5 (tile ranges) + K6 (blend).
@@ -357,6 +349,9 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *                     as the forward blend walks them (saturating scenes never read most of a long list); the entries
  *                     behind the last one consumed stay unsorted (gcr_layout.img_tile_lazy says how far the order is
  *                     final).  0: every list is sorted whole, as the reference does.
+ *   "bucket_scatter" 1: the instance keys reach their tile segments in two passes through 64-tile blocks (full      default 1
+ *                     cache lines to HBM) instead of one scattered 8-byte store each (a read-modify-write of a 32-byte
+ *                     sector per key); the lists and everything downstream are the same bits
  *   "timing"       1: record per-stage HIP events (see gcr_get_stage_ms)             default 0
  * Returns the previous value or <0 if the name is unknown. */
 int gcr_set_option(const char *name, int value);
