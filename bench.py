@@ -109,8 +109,6 @@ def main():
                     help="time the native module's positional rasterize_gaussians() (returns num_rendered as an int: one "
                          "host wait per frame, the reference's contract) instead of the Python API GaussianRasterizer "
                          "(returns image and radii; this build does not wait for num_rendered there)")
-    ap.add_argument("--bucket-scatter", type=int, default=None, choices=[0, 1],
-                    help="A/B: option bucket_scatter (two-pass scatter through 64-tile blocks; default = the library's)")
     ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the frame loop alternates over (frames are independent; 1 = serial); "
                          "default 3 (measured optimum for both paths: C3 forward 4 520 / 4 700 / 4 690 frames/s "
@@ -209,8 +207,6 @@ def main():
         return got if rank == 0 else None
     args.collect_ranks = collect_ranks
     N.lib()
-    if args.bucket_scatter is not None:
-        N.set_option("bucket_scatter", args.bucket_scatter)
     N.set_option("fast_exp", 1 if args.fast_exp else 0)
     N.set_option("split_preprocess", 1 if args.split_preprocess else 0)
     N.set_option("sort_in_blend", 1 if args.sort_in_blend else 0)

@@ -30,10 +30,10 @@ class Options(C.Structure):
     """gcr_options: per-call overrides of the gcr_set_option() defaults (-1 = the default)."""
     _fields_ = [(n, C.c_int32) for n in (
         "fast_exp", "lazy_sort", "sort_in_blend", "bwd_piece", "deterministic_backward", "split_preprocess",
-        "force_radix", "force_global_cursor", "bucket_scatter")]
+        "force_radix", "force_global_cursor")]
 
     def __init__(self, **kw):
-        super().__init__(*([-1] * 9))
+        super().__init__(*([-1] * 8))
         for k, v in kw.items():
             if k not in dict(self._fields_):
                 raise TypeError("unknown rasterizer option %r" % k)
@@ -85,7 +85,7 @@ class Layout(C.Structure):
         ("geom_num_rendered", C.c_size_t), ("geom_block_tiles", C.c_size_t), ("geom_total", C.c_size_t),
         ("img_final_T", C.c_size_t), ("img_n_contrib", C.c_size_t), ("img_ranges", C.c_size_t),
         ("img_tile_cursor", C.c_size_t), ("img_tile_table", C.c_size_t), ("img_tile_lazy", C.c_size_t),
-        ("img_bucket_base", C.c_size_t), ("img_total", C.c_size_t),
+        ("img_total", C.c_size_t),
         ("bin_keys", C.c_size_t * 2), ("bin_vals", C.c_size_t * 2), ("bin_hist", C.c_size_t),
         ("bin_sorted", C.c_size_t), ("bin_work", C.c_size_t), ("bin_mask", C.c_size_t), ("bin_ckpt", C.c_size_t),
         ("bin_total", C.c_size_t), ("bin_lean_total", C.c_size_t),

@@ -24,7 +24,6 @@ std::atomic<int> g_lazy_sort{1};         // 1: long tile lists are sorted segmen
 std::atomic<int> g_sort_in_blend{0};     // 1: the forward blend sorts short tile lists itself (lower frame latency, lower throughput)
 std::atomic<int> g_split_preprocess{0};  // 1: K1 as two kernels (streaming cull, then exact pass) instead of the fused one
 std::atomic<int> g_deterministic{0};  // 1: fixed-point gradient records (order-independent sums), gcr_internal.h
-std::atomic<int> g_bucket_scatter{1};    // 1: two-pass scatter through 64-tile blocks (gcr_binning.hip "bucketed")
 std::atomic<int> g_bwd_piece{128};  // entries per backward piece of frames rendered for a backward (gcr_camera.backward)
 #ifdef GCR_EXPERIMENTS  // make EXTRA=-DGCR_EXPERIMENTS: timing experiments, never in the shipping library
 std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results are wrong when set
@@ -36,7 +35,6 @@ std::atomic<unsigned long long*> g_clock_buf{nullptr};  // K7 per-wave phase clo
 // Resolved once at the top of every entry point and handed down by value -- nothing below reads the globals.
 struct Opts {
   int fast_exp, lazy_sort, sort_in_blend, bwd_piece, deterministic, split_preprocess, force_radix, force_global_cursor;
-  int bucket_scatter;
 };
 Opts resolve_options(const gcr_options* o) {
   Opts r;
@@ -48,9 +46,7 @@ Opts resolve_options(const gcr_options* o) {
   r.split_preprocess = g_split_preprocess.load();
   r.force_radix = g_force_radix.load();
   r.force_global_cursor = g_force_global_cursor.load();
-  r.bucket_scatter = g_bucket_scatter.load();
   if (o != nullptr) {
-    if (o->bucket_scatter >= 0) r.bucket_scatter = o->bucket_scatter != 0;
     if (o->fast_exp >= 0) r.fast_exp = o->fast_exp != 0;
     if (o->lazy_sort >= 0) r.lazy_sort = o->lazy_sort != 0;
     if (o->sort_in_blend >= 0) r.sort_in_blend = o->sort_in_blend != 0;
@@ -183,11 +179,6 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
     L->img_tile_table = o;   o = align_up(o + (size_t)ng * T * sizeof(uint32_t));
   }
   L->img_tile_lazy = o;    o = align_up(o + T * 4 * sizeof(uint32_t));
-  {
-    int G = 1;
-    const int ng = gcr_tile_table_groups((int)T, GCR_K1_MAX_BLOCKS, &G);
-    L->img_bucket_base = o;  o = align_up(o + (size_t)ng * ((T + 63) / 64) * sizeof(uint32_t));
-  }
   L->img_total = o;
 
   const size_t r = (size_t)(R > 0 ? R : 0);
@@ -297,7 +288,6 @@ int gcr_set_option(const char* name, int value) {
   if (!strcmp(name, "split_preprocess")) return g_split_preprocess.exchange(value);
   if (!strcmp(name, "sort_in_blend")) return g_sort_in_blend.exchange(value);
   if (!strcmp(name, "lazy_sort")) return g_lazy_sort.exchange(value != 0);
-  if (!strcmp(name, "bucket_scatter")) return g_bucket_scatter.exchange(value != 0);
   if (!strcmp(name, "deterministic_backward")) return g_deterministic.exchange(value != 0);
   if (!strcmp(name, "bwd_piece")) {
     const int v = value < GCR_PIECE_MIN ? GCR_PIECE_MIN : (value > GCR_PIECE_MAX ? GCR_PIECE_MAX : value);
@@ -393,8 +383,7 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
     // tile_total | tile_local | blk_total share the (T x 128 B) cursor region, unused on this path
     HIP_TRY(gcr_launch_tile_count(T, a.gx, NG, G, a.nblocks, a.chunk, a.vis_list, a.vis_count, a.rec,
                                   (uint32_t*)(ib + L.img_tile_table), cursor, cursor + (size_t)T,
-                                  cursor + 2 * (size_t)T, frame, a.block_tiles, host_R, seq,
-                                  op.bucket_scatter ? (uint32_t*)(ib + L.img_bucket_base) : nullptr, s),
+                                  cursor + 2 * (size_t)T, frame, a.block_tiles, host_R, seq, s),
             "tile count");
   } else {
     {
@@ -462,16 +451,7 @@ static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_g
   const int NG = op.force_global_cursor ? 0 : gcr_tile_table_groups(T, nblocks, &G);
   {
     StageTimer t(s, ST_EMIT);
-    if (NG > 0 && op.bucket_scatter && R_layout > 0) {
-      // two passes through 64-tile blocks (gcr_binning.hip); the intermediate (key, tile & 63) pairs live in the spare
-      // key / value halves of the binning buffer, which nothing else uses before the per-tile sort
-      uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
-      HIP_TRY(gcr_launch_bucket_scatter(T, gx, NG, G, nblocks, chunk, vis_list, vis_count, rec, cursor, cursor + (size_t)T,
-                                        cursor + 2 * (size_t)T, (const uint32_t*)(ib + L.img_bucket_base), ranges,
-                                        (uint64_t*)(bb + L.bin_keys[1]), (uint8_t*)(bb + L.bin_vals[1 - L.bin_sorted]), pairs,
-                                        frame_dev, cap_instances, cap_list, host_longest, s),
-              "bucket scatter");
-    } else if (NG > 0) {
+    if (NG > 0) {
       // also rebuilds `ranges` from the block totals, so it runs even when nothing is rendered
       uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
       HIP_TRY(gcr_launch_tile_scatter(T, gx, NG, G, nblocks, chunk, vis_list, vis_count, rec,

@@ -209,18 +209,12 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
 // totals (tile_local = exclusive prefix inside the 64-tile block, blk_total = their sum) and folds
 // the block's longest list into the frame summary with one device-scope atomicMax per 64 tiles
 // (fire-and-forget; R itself was accumulated by K1b so that the host can read it earlier).
-//
-// `blk_grp` (optional, the two-pass scatter below): blk_grp[b][g] = instances of 64-tile block b owned by groups < g --
-// where group g's run starts inside block b's segment of the intermediate buffer.
 __global__ __launch_bounds__(1024) void k_table_colscan(uint32_t* __restrict__ table, int NG, int T,
                                                         uint32_t* __restrict__ tile_total,
                                                         uint32_t* __restrict__ tile_local,
                                                         uint32_t* __restrict__ blk_total,
-                                                        unsigned long long* __restrict__ frame,
-                                                        uint32_t* __restrict__ blk_grp) {
+                                                        unsigned long long* __restrict__ frame) {
   __shared__ uint32_t part[16][64];
-  __shared__ uint32_t rowsum[512];
-  __shared__ uint32_t rw[8];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + lane;
   const int rpg = (NG + 15) / 16;  // rows per row-group, <= 32
@@ -235,28 +229,7 @@ __global__ __launch_bounds__(1024) void k_table_colscan(uint32_t* __restrict__ t
 #pragma unroll
   for (int r = 0; r < 32; r++) sum += v[r];
   part[grp][lane] = sum;
-  if (blk_grp != nullptr) {  // row sums over this block's 64 tiles (wave-uniform branch and trip counts)
-#pragma unroll
-    for (int r = 0; r < 32; r++) {
-      if (r < rpg && r0 + r < NG) {
-        const uint32_t s = gcr_wave_sum_u32(v[r]);
-        if (lane == 0) rowsum[r0 + r] = s;
-      }
-    }
-  }
   __syncthreads();
-  if (blk_grp != nullptr) {  // exclusive prefix over the NG <= 512 groups
-    const int i = threadIdx.x;
-    const uint32_t x = (i < NG) ? rowsum[i] : 0u;
-    const uint32_t incl = gcr_wave_incl_scan_u32(x, lane);
-    if (i < 512 && lane == 63) rw[i >> 6] = incl;
-    __syncthreads();
-    if (i < NG) {
-      uint32_t before_g = 0;
-      for (int k = 0; k < (i >> 6); k++) before_g += rw[k];
-      blk_grp[(size_t)blockIdx.x * NG + i] = before_g + incl - x;
-    }
-  }
   uint32_t before = 0, all = 0;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
@@ -287,130 +260,6 @@ __global__ __launch_bounds__(1024) void k_table_colscan(uint32_t* __restrict__ t
       blk_total[blockIdx.x] = incl;
       if (mx) atomicMax(&frame[1], (unsigned long long)mx);
     }
-  }
-}
-
-// ------------------------------------------------------------------------------- two-pass ("bucketed") scatter
-// The one-pass scatter above stores every 8-byte key straight into its tile segment.  Consecutive instances of a
-// workgroup go to different tiles, so each store is the only write its 32-byte sector sees before the line leaves the
-// L2: HBM (ECC) turns it into a read-modify-write -- profiles/r03_traffic.json: 32 B fetched + 34 B written per 8-byte
-// key, and 194 us of a 20 M-Gaussian 4K frame.  Two passes whose open lines fit the L2 instead:
-//   pass 1  k_bucket_scatter: group g appends (key, tile & 63) to ITS run inside the segment of the key's 64-TILE BLOCK
-//           (blk_grp[b][g] from the column scan says where the run starts): a workgroup has one open line per block
-//           (128 at 1080p, 506 at 4K) instead of one per tile, and a run is tens of entries long -- lines fill up
-//           while they are still in the L2;
-//   pass 2  k_bucket_to_tiles: one workgroup per block streams the block's segment (coalesced) and drops every key into
-//           its tile's segment with 64 LDS cursors -- 64 open lines per workgroup.
-// The order inside a tile segment is arbitrary in both schemes (the per-tile sort follows; keys are unique).
-template <int TT_THREADS>
-__global__ __launch_bounds__(TT_THREADS) void k_bucket_scatter(
-    int T, int gx, int G, int NG, int nblocks_k1, int chunk, const uint32_t* __restrict__ vis_list,
-    const uint32_t* __restrict__ vis_count, const float4* __restrict__ rec, const uint32_t* __restrict__ tile_total,
-    const uint32_t* __restrict__ tile_local, const uint32_t* __restrict__ blk_total, const uint32_t* __restrict__ blk_grp,
-    uint32_t* __restrict__ ranges, uint64_t* __restrict__ tmp_key, uint8_t* __restrict__ tmp_tile,
-    unsigned long long* __restrict__ frame, unsigned long long cap_instances, unsigned long long cap_list,
-    unsigned long long* __restrict__ host_word) {
-  __shared__ uint32_t pre[TT_MAX_GROUP + 1];
-  __shared__ uint32_t blk_base[TT_MAX_TBLOCKS];
-  __shared__ uint32_t cur[TT_MAX_TBLOCKS];
-  __shared__ uint32_t wtot[TT_THREADS / 64];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const bool go = frame[0] <= cap_instances && frame[1] <= cap_list;  // (see k_tile_table<true>)
-  if (blockIdx.x == 0 && tid == 0) {
-    frame[2] = go ? 1ull : 0ull;
-    if (host_word != nullptr) gcr_store_to_host(host_word, frame[1]);
-  }
-  if (!go) return;
-  const int ntb = (T + 63) / 64;
-  uint32_t running = 0;
-  for (int b0 = 0; b0 < ntb; b0 += TT_THREADS) {
-    const int bi = b0 + tid;
-    const uint32_t v = bi < ntb ? blk_total[bi] : 0u;
-    const uint32_t incl = gcr_wave_incl_scan_u32(v, lane);
-    if (lane == 63) wtot[w] = incl;
-    __syncthreads();
-    uint32_t before = 0, all = 0;
-#pragma unroll
-    for (int k = 0; k < TT_THREADS / 64; k++) {
-      const uint32_t x = wtot[k];
-      if (k < w) before += x;
-      all += x;
-    }
-    if (bi < ntb) {
-      const uint32_t base = running + before + incl - v;
-      blk_base[bi] = base;
-      cur[bi] = base + blk_grp[(size_t)bi * NG + blockIdx.x];
-    }
-    running += all;
-    __syncthreads();
-  }
-  const int slice = (T + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int t_lo = blockIdx.x * slice, t_hi = min(T, t_lo + slice);
-  for (int t = t_lo + tid; t < t_hi; t += TT_THREADS) {
-    const uint32_t start = blk_base[t >> 6] + tile_local[t];
-    ranges[2 * t] = start;
-    ranges[2 * t + 1] = start + tile_total[t];
-  }
-  const int kb0 = blockIdx.x * G;
-  const int kbn = min(G, nblocks_k1 - kb0);
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (int k = 0; k < kbn; k++) {
-      pre[k] = run;
-      run += vis_count[kb0 + k];
-    }
-    pre[kbn] = run;
-  }
-  __syncthreads();
-  const uint32_t total = pre[kbn];
-  for (uint32_t f = tid; f < total; f += TT_THREADS) {
-    int k = 0;
-    while (k + 1 < kbn && pre[k + 1] <= f) k++;
-    const uint32_t idx = vis_list[(size_t)(kb0 + k) * chunk + (f - pre[k])];
-    const float4 q2 = rec[(size_t)idx * GCR_REC_QUADS + 2];
-    const uint32_t rx = __float_as_uint(q2.z), ry = __float_as_uint(q2.w);
-    const uint32_t minx = rx & 0xffffu, maxx = rx >> 16, miny = ry & 0xffffu, maxy = ry >> 16;
-    const uint64_t key = ((uint64_t)__float_as_uint(q2.y) << 32) | idx;
-    for (uint32_t y = miny; y < maxy; y++)
-      for (uint32_t x = minx; x < maxx; x++) {
-        const uint32_t t = y * (uint32_t)gx + x;
-        const uint32_t pos = atomicAdd(&cur[t >> 6], 1u);  // ds_add_rtn_u32
-        tmp_key[pos] = key;
-        tmp_tile[pos] = (uint8_t)(t & 63u);
-      }
-  }
-}
-
-__global__ __launch_bounds__(512) void k_bucket_to_tiles(int T, const uint32_t* __restrict__ tile_local,
-                                                         const uint32_t* __restrict__ blk_total,
-                                                         const uint64_t* __restrict__ tmp_key,
-                                                         const uint8_t* __restrict__ tmp_tile, uint64_t* __restrict__ pairs,
-                                                         const unsigned long long* __restrict__ frame) {
-  __shared__ uint32_t cur[64];
-  __shared__ uint32_t wsum[8];
-  if (frame[2] == 0ull) return;  // vetoed frame (capacity guess too short): nothing was binned
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int b = blockIdx.x;
-  // first instance of this block = sum of the block totals before it (<= TT_MAX_TBLOCKS values)
-  uint32_t part = 0;
-  for (int i = tid; i < b; i += 512) part += blk_total[i];
-  part = gcr_wave_sum_u32(part);
-  if (lane == 0) wsum[w] = part;
-  __syncthreads();
-  uint32_t base = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) base += wsum[k];
-  if (tid < 64) {
-    const int t = b * 64 + tid;
-    cur[tid] = base + (t < T ? tile_local[t] : 0u);
-  }
-  __syncthreads();
-  const uint32_t n = blk_total[b];
-  for (uint32_t i = tid; i < n; i += 512u) {
-    const uint64_t key = tmp_key[base + i];
-    const uint32_t tl = tmp_tile[base + i];
-    const uint32_t pos = atomicAdd(&cur[tl], 1u);
-    pairs[pos] = key;
   }
 }
 
@@ -773,7 +622,7 @@ hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, i
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,
                                  uint32_t* tile_total, uint32_t* tile_local, uint32_t* blk_total,
                                  unsigned long long* frame, const unsigned long long* block_tiles,
-                                 unsigned long long* host_R, unsigned int seq, uint32_t* blk_grp, hipStream_t s) {
+                                 unsigned long long* host_R, unsigned int seq, hipStream_t s) {
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
   if (tile_table_wide(T))
@@ -784,20 +633,7 @@ hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, i
     k_tile_table<false, 512><<<NG, 512, (size_t)T * sizeof(uint32_t), s>>>(
         T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, nullptr, nullptr, nullptr, nullptr, nullptr,
         frame, 0ull, 0ull, host_R, seq, block_tiles);
-  k_table_colscan<<<(T + 63) / 64, 1024, 0, s>>>(table, NG, T, tile_total, tile_local, blk_total, frame, blk_grp);
-  return hipGetLastError();
-}
-
-hipError_t gcr_launch_bucket_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
-                                     const uint32_t* vis_count, const float4* rec, const uint32_t* tile_total,
-                                     const uint32_t* tile_local, const uint32_t* blk_total, const uint32_t* blk_grp,
-                                     uint32_t* ranges, uint64_t* tmp_key, uint8_t* tmp_tile, uint64_t* pairs,
-                                     unsigned long long* frame, unsigned long long cap_instances,
-                                     unsigned long long cap_list, unsigned long long* host_longest, hipStream_t s) {
-  k_bucket_scatter<1024><<<NG, 1024, 0, s>>>(T, gx, G, NG, nblocks_k1, chunk, vis_list, vis_count, rec, tile_total,
-                                            tile_local, blk_total, blk_grp, ranges, tmp_key, tmp_tile, frame,
-                                            cap_instances, cap_list, host_longest);
-  k_bucket_to_tiles<<<(T + 63) / 64, 512, 0, s>>>(T, tile_local, blk_total, tmp_key, tmp_tile, pairs, frame);
+  k_table_colscan<<<(T + 63) / 64, 1024, 0, s>>>(table, NG, T, tile_total, tile_local, blk_total, frame);
   return hipGetLastError();
 }
 

@@ -218,14 +218,7 @@ hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, i
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,
                                  uint32_t* tile_total, uint32_t* tile_local, uint32_t* blk_total,
                                  unsigned long long* frame, const unsigned long long* block_tiles,
-                                 unsigned long long* host_R, unsigned int seq, uint32_t* blk_grp, hipStream_t s);
-// two-pass scatter (gcr_binning.hip "bucketed"): needs the blk_grp table of gcr_launch_tile_count
-hipError_t gcr_launch_bucket_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
-                                     const uint32_t* vis_count, const float4* rec, const uint32_t* tile_total,
-                                     const uint32_t* tile_local, const uint32_t* blk_total, const uint32_t* blk_grp,
-                                     uint32_t* ranges, uint64_t* tmp_key, uint8_t* tmp_tile, uint64_t* pairs,
-                                     unsigned long long* frame, unsigned long long cap_instances,
-                                     unsigned long long cap_list, unsigned long long* host_longest, hipStream_t s);
+                                 unsigned long long* host_R, unsigned int seq, hipStream_t s);
 hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                    const uint32_t* vis_count, const float4* rec, uint32_t* table,
                                    const uint32_t* tile_total, const uint32_t* tile_local,

@@ -72,9 +72,8 @@ typedef struct gcr_options {
   int32_t split_preprocess;
   int32_t force_radix;
   int32_t force_global_cursor;
-  int32_t bucket_scatter;
 } gcr_options;
-#define GCR_OPTIONS_DEFAULT {-1, -1, -1, -1, -1, -1, -1, -1, -1}
+#define GCR_OPTIONS_DEFAULT {-1, -1, -1, -1, -1, -1, -1, -1}
 
 /* GaussianRasterizationSettings (dgr/__init__.py:203-215) */
 typedef struct gcr_camera {
@@ -186,8 +185,6 @@ typedef struct gcr_layout {
   size_t img_tile_table;  /* uint32 [groups][T]: per-group tile counts, then exclusive prefixes */
   size_t img_tile_lazy;   /* uint32[4] per tile {n_sorted, 0, L lo, L hi}: the first n_sorted entries of the tile's
                              list are in final order, every key >= L is not among them (option "lazy_sort") */
-  size_t img_bucket_base; /* uint32 [T / 64][groups]: where a group's run starts inside a 64-tile block's segment of the
-                             two-pass scatter's intermediate buffer (option "bucket_scatter") */
   size_t img_total;
   /* binning buffer (per instance) */
   size_t bin_keys[2]; /* uint64 per instance, ping/pong */
@@ -349,9 +346,6 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *                     as the forward blend walks them (saturating scenes never read most of a long list); the entries
  *                     behind the last one consumed stay unsorted (gcr_layout.img_tile_lazy says how far the order is
  *                     final).  0: every list is sorted whole, as the reference does.
- *   "bucket_scatter" 1: the instance keys reach their tile segments in two passes through 64-tile blocks (full      default 1
- *                     cache lines to HBM) instead of one scattered 8-byte store each (a read-modify-write of a 32-byte
- *                     sector per key); the lists and everything downstream are the same bits
  *   "timing"       1: record per-stage HIP events (see gcr_get_stage_ms)             default 0
  * Returns the previous value or <0 if the name is unknown. */
 int gcr_set_option(const char *name, int value);
