@@ -109,6 +109,9 @@ def main():
                     help="time the native module's positional rasterize_gaussians() (returns num_rendered as an int: one "
                          "host wait per frame, the reference's contract) instead of the Python API GaussianRasterizer "
                          "(returns image and radii; this build does not wait for num_rendered there)")
+    ap.add_argument("--float-frames", action="store_true",
+                    help="--inference-loop: render float images and convert them to uint8 frames with torch kernels, as "
+                         "scripts/inference.py does (default: the blend kernel stores the uint8 frame, same bytes)")
     ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the frame loop alternates over (frames are independent; 1 = serial); "
                          "default 3 (measured optimum for both paths: C3 forward 4 520 / 4 700 / 4 690 frames/s "
@@ -502,6 +505,9 @@ def main():
             g = valu_instr / 1e9 / (dom_ms / 1e3)
             valu = {"achieved": round(g, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
                     "frac": round(g / VALU_PEAK_GINSTR, 4), "instr_per_launch": int(valu_instr),
+                    # a VALU-issue fraction rises when a kernel executes MORE instructions in the same time: the count
+                    # per unit of useful work beside it (consumed list entries R_p) says which way it moved
+                    "valu_instr_per_consumed_entry": round(valu_instr / max(Rp_mean, 1.0), 2),
                     "frac_in_flight": round(valu_instr / 1e9 / (dom_flight_ms / 1e3) / VALU_PEAK_GINSTR, 4),
                     "source": "profiles/" + tfile,
                     "source_matches_this_tree": traffic_is_current(tdoc, ("gcr_blend.hip", "gcr_device.h", "gcr_cull.h"))}
@@ -1015,7 +1021,10 @@ def inference_loop_bench(args, torch, dist, synth, Wrapper, dev, world, rank, ba
     pts_np = np.concatenate([sc["means3D"], np.ones((n_pts, 1), np.float32), sc["scales"], rot, sc["colors_precomp"]], axis=1)
     points = torch.from_numpy(pts_np.astype(np.float32)).to(dev)
     orbit = synth.orbit_poses()
-    loop = InferenceLoop(lambda p, cp, cq: wr(p, cp, cq), device=dev, n_streams=args.streams)
+    # --float-frames: the reference's route (float image, then tensor_to_image * 255 -> uint8 with torch kernels);
+    # default: the blend kernel stores the uint8 frame itself (GaussianRasterizerWrapper(as_uint8=True): the same bytes)
+    loop = InferenceLoop(lambda p, cp, cq: wr(p, cp, cq), device=dev, n_streams=args.streams,
+                         render_uint8_fn=None if args.float_frames else (lambda p, cp, cq: wr(p, cp, cq, as_uint8=True)))
     sink = [0]
 
     def consume(i, frame):  # what a video writer would do with the frame: touch it
@@ -1053,7 +1062,9 @@ def inference_loop_bench(args, torch, dist, synth, Wrapper, dev, world, rank, ba
             "config": {"workload": "%d points [N,14] with precomputed colours, %dx%d, 24-pose orbit, uint8 HWC frames "
                                    "copied to pinned host memory (scripts/inference.py:655-667)" % (n_pts, W, H),
                        "parallelism": "frames round-robin over ranks; %d HIP streams per GPU" % loop.n,
-                       "camera": args.host_camera},
+                       "camera": args.host_camera,
+                       "frames": "float image + torch conversion kernels" if args.float_frames else
+                                 "uint8 frame stored by the blend kernel"},
             "frame_bytes_to_host": 3 * W * H}), flush=True)
     if world > 1:
         dist.barrier()

@@ -54,6 +54,7 @@ class Camera(C.Structure):
         ("win_x", C.c_int32), ("win_y", C.c_int32), ("win_w", C.c_int32), ("win_h", C.c_int32),  # output window
         ("backward", C.c_int32),  # 1: a backward call will follow (the forward blend leaves its per-piece state)
         ("options", C.POINTER(Options)),  # per-call options or NULL
+        ("out_u8", C.c_int32),  # out_color is a uint8 [H,W,3] video frame (inference frames)
     ]
 
 

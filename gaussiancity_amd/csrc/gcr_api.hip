@@ -211,6 +211,8 @@ int check_inputs(const gcr_camera* cam, const gcr_gaussians* g, bool need_opacit
     return fail(GCR_ERR_INVALID_ARGUMENT, "image too large for 16-bit tile coordinates");
   if (!cam->bg || !cam->view_matrix || !cam->proj_matrix || !cam->campos)
     return fail(GCR_ERR_INVALID_ARGUMENT, "bg/view_matrix/proj_matrix/campos must be non-null");
+  if (cam->out_u8 != 0 && cam->backward == 1)
+    return fail(GCR_ERR_INVALID_ARGUMENT, "out_u8 (uint8 video frames) is for inference frames: gcr_camera.backward must be 0");
   if (cam->win_w != 0 || cam->win_h != 0) {
     if (cam->win_w <= 0 || cam->win_h <= 0 || cam->win_x < 0 || cam->win_y < 0 || cam->win_x + cam->win_w > cam->img_w ||
         cam->win_y + cam->win_h > cam->img_h)
@@ -490,6 +492,7 @@ static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_g
   b.bg = cam->bg;
   b.flip_x = cam->flip_x != 0; b.flip_y = cam->flip_y != 0;
   b.win_x = cam->win_x; b.win_y = cam->win_y; b.win_w = cam->win_w; b.win_h = cam->win_h;
+  b.out_u8 = cam->out_u8 != 0 && cam->backward != 1;
   fill_cam(b.cam, cam);
   b.final_T = (float*)(ib + L.img_final_T);
   b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
@@ -971,6 +974,7 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   b.final_T = (float*)(ib + L.img_final_T);
   b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
   b.out_color = out_color;
+  b.out_u8 = cam->out_u8 != 0 && cam->backward != 1;
   set_piece_args(op, b, cam->backward == 1, L, binning, geom);
   {
     StageTimer t(s, ST_BLEND_FWD);

@@ -98,6 +98,16 @@ GCR_DEV bool gcr_tile_in_window(const GcrBlendArgs& a, int tx, int ty) {
   return x1 >= a.win_x && x0 < a.win_x + a.win_w && y1 >= a.win_y && y0 < a.win_y + a.win_h;
 }
 
+// scripts/inference.py:655-667 / utils/helpers.tensor_to_image: ((clamp(c, -1, 1) / 2 + 0.5) * 255).to(uint8), each step a
+// float32 operation of its own (torch runs them as separate kernels; the library is built without contraction)
+GCR_DEV uint8_t gcr_video_byte(float c) {
+  float t = c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c);  // torch.clamp: a NaN stays a NaN (and converts to 0 below)
+  t = t / 2.0f;
+  t = t + 0.5f;
+  t = t * 255.0f;
+  return (uint8_t)(t == t ? (int)t : 0);
+}
+
 // byte offset -> chunk slot (offsets are multiples of 48 below 2^14: 1366/65536 is 1/48 rounded up,
 // exact for slots < 2048)
 GCR_DEV uint32_t slot_of_offset(uint32_t off) { return (off * 1366u) >> 16; }
@@ -421,9 +431,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     asm volatile("" : "+v"(px_op), "+v"(py_op));
     const long long out_id = gcr_out_index(a, px_op, py_op, &oplane);
     if (out_id >= 0) {
-      a.out_color[out_id] = C0 + Tout * GCR_CAM(a, bg, a.bg, 0);
-      a.out_color[oplane + out_id] = C1 + Tout * GCR_CAM(a, bg, a.bg, 1);
-      a.out_color[2 * oplane + out_id] = C2 + Tout * GCR_CAM(a, bg, a.bg, 2);
+      const float c0 = C0 + Tout * GCR_CAM(a, bg, a.bg, 0);
+      const float c1 = C1 + Tout * GCR_CAM(a, bg, a.bg, 1);
+      const float c2 = C2 + Tout * GCR_CAM(a, bg, a.bg, 2);
+      if (!STATE && a.out_u8) {  // the video frame directly (gcr_camera.out_u8): uint8 [H,W,3]
+        uint8_t* o = reinterpret_cast<uint8_t*>(a.out_color) + 3 * (size_t)out_id;
+        o[0] = gcr_video_byte(c0);
+        o[1] = gcr_video_byte(c1);
+        o[2] = gcr_video_byte(c2);
+      } else {
+        a.out_color[out_id] = c0;
+        a.out_color[oplane + out_id] = c1;
+        a.out_color[2 * oplane + out_id] = c2;
+      }
     }
   }
   if (STATE && a.work != nullptr) {

@@ -168,6 +168,7 @@ struct GcrBlendArgs {
   int deterministic;        // bwd: fixed-point gradient records (option "deterministic_backward")
   int win_x, win_y, win_w, win_h;  // output window in image coordinates AFTER mirroring (win_w == 0: whole image)
   int flip_x, flip_y;       // fwd: out_color stored mirrored; bwd: dL_dpix loaded mirrored (gcr_camera.flip_x / flip_y)
+  int out_u8;               // fwd: out_color is uint8 [H,W,3] video frames (gcr_camera.out_u8)
   GcrCamVals cam;           // bg by value when cam.by_value
   int debug_flags;  // experiment builds only (GCR_EXPERIMENTS, "k7_skip_flush"): bit 0 = K7 drops its global atomics
   // pieces / checkpoints (above)

@@ -209,7 +209,7 @@ def _dev_f32(t, name, device):
 
 
 def _camera(device, bg, view, proj, campos, tan_fovx, tan_fovy, H, W, scale_modifier, degree,
-            prefiltered, debug, for_backward=False, flip_x=False, flip_y=False, window=None):
+            prefiltered, debug, for_backward=False, flip_x=False, flip_y=False, window=None, out_u8=False):
     """gcr_camera.  The four camera tensors are device tensors as in the reference -- or ALL four CPU tensors
     (GaussianRasterizerWrapper(host_camera=True)): then the library copies the 38 floats into its kernels' arguments
     (gcr_camera.host_camera) and no device copy of the camera exists at all."""
@@ -235,6 +235,7 @@ def _camera(device, bg, view, proj, campos, tan_fovx, tan_fovy, H, W, scale_modi
     cam.flip_x = int(bool(flip_x))
     cam.flip_y = int(bool(flip_y))
     cam.backward = int(bool(for_backward))
+    cam.out_u8 = int(bool(out_u8))
     opt = _current_options()
     if opt is not None:
         cam.options = C.pointer(opt)
@@ -331,8 +332,11 @@ def _forward(L, device, cam, g, P, H, W, ticket=False):
     byte = dict(dtype=torch.uint8, device=device)
     stateful = cam.backward == 1
     # every pixel / every radius is written by the kernels, so no zero-fill launches are needed
-    out_color = torch.empty((NUM_CHANNELS, cam.win_h, cam.win_w) if cam.win_w else (NUM_CHANNELS, H, W),
-                            dtype=torch.float32, device=device)
+    oh, ow = (cam.win_h, cam.win_w) if cam.win_w else (H, W)
+    if cam.out_u8:  # the video frame itself (gcr_camera.out_u8)
+        out_color = torch.empty((oh, ow, NUM_CHANNELS), dtype=torch.uint8, device=device)
+    else:
+        out_color = torch.empty((NUM_CHANNELS, oh, ow), dtype=torch.float32, device=device)
     radii = torch.empty((P,), dtype=torch.int32, device=device)
     stream = _stream(device)
     gbytes = _size_cache.get(P)
@@ -499,10 +503,15 @@ def _points14_gaussians(points):
 
 
 def rasterize_points14(points, background, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
-                       image_width, campos, flip_x=False, flip_y=False, for_backward=False, window=None, ticket=False):
+                       image_width, campos, flip_x=False, flip_y=False, for_backward=False, window=None, ticket=False,
+                       out_uint8=False):
     """Forward of GaussianRasterizerWrapper's call shape on the [N,14] tensor in place (precomputed colours, SH degree
     0).  Same six-tuple as rasterize_gaussians; the image comes out already mirrored if flip_x / flip_y ask for it, and
-    as the `window` = (x, y, w, h) of that mirrored image if one is given (tiles outside it are not blended)."""
+    as the `window` = (x, y, w, h) of that mirrored image if one is given (tiles outside it are not blended).
+    out_uint8 (inference frames): the second element is the uint8 [h,w,3] video frame of scripts/inference.py:655-667
+    instead of the float [3,h,w] image -- the same bytes its five elementwise kernels produce, stored by the blend."""
+    if out_uint8 and for_backward:
+        raise RuntimeError("out_uint8 renders video frames: there is no backward through them")
     L = N.lib()
     g, pts = _points14_gaussians(points)
     device = pts.device
@@ -512,7 +521,7 @@ def rasterize_points14(points, background, scale_modifier, viewmatrix, projmatri
         return ((FrameTicket(L, None, None, 0, 0, None, None, False, R=0),) + e[1:]) if ticket else e
     with _on_device(device):
         cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W,
-                              scale_modifier, 0, False, False, for_backward, flip_x, flip_y, window)
+                              scale_modifier, 0, False, False, for_backward, flip_x, flip_y, window, out_uint8)
         out = _forward(L, device, cam, g, P, H, W, ticket)
         del keep_c, pts
     return out

@@ -230,8 +230,12 @@ class InferenceLoop:
     frames' renders.  `render_fn(points, cam_pos, cam_quat) -> [3,H,W]`
     is the rasterizer wrapper (or any stand-in on CPU, which degrades to a plain loop)."""
 
-    def __init__(self, render_fn, device=None, n_streams=3):
+    def __init__(self, render_fn, device=None, n_streams=3, render_uint8_fn=None):
+        """`render_uint8_fn(points, cam_pos, cam_quat) -> uint8 [H,W,3]` (optional): a renderer that produces the video
+        frame itself (GaussianRasterizerWrapper(..., as_uint8=True): the blend kernel stores the bytes to_uint8_hwc would
+        compute); used instead of render_fn + to_uint8_hwc when given."""
         self.render_fn = render_fn
+        self.render_uint8_fn = render_uint8_fn
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.cuda = self.device.type == "cuda"
         self.n = max(1, int(n_streams))
@@ -275,7 +279,8 @@ class InferenceLoop:
                 if isinstance(points, torch.Tensor) and points.is_cuda:
                     points.record_stream(self.streams[slot])
                 with torch.cuda.stream(self.streams[slot]):
-                    frame = self.to_uint8_hwc(self.render_fn(points, cam_pos, cam_quat))
+                    frame = (self.render_uint8_fn(points, cam_pos, cam_quat) if self.render_uint8_fn is not None else
+                             self.to_uint8_hwc(self.render_fn(points, cam_pos, cam_quat)))
                     if self._pinned[slot] is None or self._pinned[slot].shape != frame.shape:
                         self._pinned[slot] = torch.empty(frame.shape, dtype=torch.uint8, pin_memory=True)
                     self._pinned[slot].copy_(frame, non_blocking=True)

@@ -30,6 +30,70 @@ def _absent():
     return torch.Tensor([])
 
 
+# ---- the reference's world-to-camera recipe without the scipy object --------------------------------------------------------
+# dgr/__init__.py:349-368 builds the rotation with scipy.spatial.transform.Rotation.from_quat(q).as_matrix(): ~25 us
+# of object construction and validation for thirty floating-point operations, in a frame loop that is host-bound.
+# _w2c_fast() performs the SAME IEEE binary64 operations in the same order with Python floats and then follows the
+# reference's numpy lines verbatim (the 3x3 @ 3x1 product is numpy's: its summation order is not ours to guess).  That
+# this gives scipy's bits is checked, not assumed: the first use compares the two routes on 64 fixed poses -- random ones
+# and orbit poses looking at a target, where the translation cancels -- and the fast route is only kept if every one
+# agrees bit for bit (tests/test_golden_api.py repeats the comparison on thousands).
+_fast_w2c_ok = None
+
+
+def _w2c_reference_ops(cam_position, cam_quaternion):
+    """dgr/__init__.py:349-368, operation by operation (numpy / scipy)."""
+    cam_position = np.asarray(cam_position)
+    rot = scipy.spatial.transform.Rotation.from_quat(cam_quaternion).as_matrix()
+    rot = rot[:, [1, 2, 0]]  # [F|R|U] -> [R|U|F]
+    w2c = np.zeros((4, 4), dtype=np.float32)
+    w2c[:3, :3] = rot.transpose()
+    w2c[:3, [3]] = -rot.transpose() @ cam_position[:, None]
+    w2c[3, 3] = 1.0
+    return w2c
+
+
+def _w2c_fast(cam_position, cam_quaternion):
+    x, y, z, w = (float(v) for v in cam_quaternion)
+    p0, p1, p2 = (float(v) for v in cam_position)
+    n = math.sqrt(x * x + y * y + z * z + w * w)
+    x, y, z, w = x / n, y / n, z / n, w / n
+    x2, y2, z2, w2 = x * x, y * y, z * z, w * w
+    xy, zw, xz, yw, yz, xw = x * y, z * w, x * z, y * w, y * z, x * w
+    # scipy's as_matrix(), rows of R = [F|R|U]
+    m = ((x2 - y2 - z2 + w2, 2 * (xy - zw), 2 * (xz + yw)),
+         (2 * (xy + zw), -x2 + y2 - z2 + w2, 2 * (yz - xw)),
+         (2 * (xz - yw), 2 * (yz + xw), -x2 - y2 + z2 + w2))
+    rot = np.array(m)[:, [1, 2, 0]]  # [F|R|U] -> [R|U|F]; from here on: the reference's own lines
+    cam_position = np.array((p0, p1, p2))
+    w2c = np.zeros((4, 4), dtype=np.float32)
+    w2c[:3, :3] = rot.transpose()
+    w2c[:3, [3]] = -rot.transpose() @ cam_position[:, None]
+    w2c[3, 3] = 1.0
+    return w2c
+
+
+def _fast_w2c_available():
+    global _fast_w2c_ok
+    if _fast_w2c_ok is None:
+        rng = np.random.default_rng(20240927)
+        ok = True
+        from . import synth
+        orbit = synth.orbit_poses()
+        for i in range(64):
+            q = rng.normal(size=4)
+            p = rng.normal(size=3) * (1000.0 if i % 2 else 1.0)
+            if i % 3 == 0:
+                q, p = q.astype(np.float32).astype(np.float64), p.astype(np.float32).astype(np.float64)
+            if i >= 40:
+                p, q = orbit[i - 40]
+            if not np.array_equal(_w2c_fast(p, q).view(np.uint32), _w2c_reference_ops(p, q).view(np.uint32)):
+                ok = False
+                break
+        _fast_w2c_ok = ok
+    return _fast_w2c_ok
+
+
 class GaussianRasterizationSettings(typing.NamedTuple):
     img_h: int
     img_w: int
@@ -239,13 +303,10 @@ class GaussianRasterizerWrapper(torch.nn.Module):
             cam_position = cam_position.cpu().numpy()
         if isinstance(cam_quaternion, torch.Tensor):
             cam_quaternion = cam_quaternion.cpu().numpy()
-        cam_position = np.asarray(cam_position)
-        rot = scipy.spatial.transform.Rotation.from_quat(cam_quaternion).as_matrix()
-        rot = rot[:, [1, 2, 0]]  # [F|R|U] -> [R|U|F]
-        w2c = np.zeros((4, 4), dtype=np.float32)
-        w2c[:3, :3] = rot.transpose()
-        w2c[:3, [3]] = -rot.transpose() @ cam_position[:, None]
-        w2c[3, 3] = 1.0
+        if _fast_w2c_available() and len(cam_quaternion) == 4 and len(cam_position) == 3:
+            w2c = _w2c_fast(cam_position, cam_quaternion)  # the same bits, without the library dispatch (see above)
+        else:
+            w2c = _w2c_reference_ops(cam_position, cam_quaternion)
         return torch.from_numpy(w2c).to(self.device if device is None else device)
 
     def _get_gaussian_rasterization_settings(self, cam_position, cam_quaternion):
@@ -276,8 +337,12 @@ class GaussianRasterizerWrapper(torch.nn.Module):
             debug=False,
         )
 
-    def _reference_recipe_on_host(self, cam_position, cam_quaternion):
-        """dgr/__init__.py:349-402 operation by operation, on CPU tensors (host_camera="reference")."""
+    def _reference_recipe_on_host(self, cam_position, cam_quaternion, need_campos=True):
+        """dgr/__init__.py:349-402 operation by operation, on CPU tensors (host_camera="reference").
+        need_campos=False (the wrapper's own render path): `campos` -- the one product of `view.inverse()`, 40 us of
+        LAPACK dispatch -- is only read by the SH evaluation, and this wrapper always renders precomputed colours
+        (sh_degree 0, dgr/__init__.py:404-420): the inverse is skipped and a zero vector stands in, in settings that
+        never leave the wrapper.  get_gaussian_rasterizer() hands out complete settings."""
         view = self._get_w2c_matrix(cam_position, cam_quaternion, device=_CPU).transpose(0, 1)  # (no shared state is
         #                                  touched: two threads may share one wrapper, ADVICE r03)
         if getattr(self, "_P_cpu_t", None) is None:
@@ -288,7 +353,7 @@ class GaussianRasterizerWrapper(torch.nn.Module):
             tanfovx=math.tan(self.fov_x * 0.5), tanfovy=math.tan(self.fov_y * 0.5),
             bg=self._bg_host, scale_modifier=1.0, view_matrix=view.contiguous(),
             proj_matrix=(view @ self._P_cpu_t).contiguous(), sh_degree=0,
-            campos=view.inverse()[3, :3].contiguous(), prefiltered=False, debug=False)
+            campos=view.inverse()[3, :3].contiguous() if need_campos else self._bg_host, prefiltered=False, debug=False)
 
     def _host_camera_settings(self, cam_position, cam_quaternion):
         """The same settings from host arithmetic only (opt-in, see __init__).  Rotation from the quaternion
@@ -350,14 +415,32 @@ class GaussianRasterizerWrapper(torch.nn.Module):
             image = image[:, y:y + h, x:x + w]
         return image
 
-    def forward(self, points, cam_position=None, cam_quaternion=None, gaussian_rasterizer=None, crop=None):
+    def forward(self, points, cam_position=None, cam_quaternion=None, gaussian_rasterizer=None, crop=None,
+                as_uint8=False):
         """`crop` = (x, y, w, h) (not in the reference, used by helpers.get_gaussian_rasterization): return only that
         window of the image -- the same values as image[:, y:y+h, x:x+w], but the native side stores just the window,
-        skips the tiles outside it in both directions, and the crop's slice-backward kernels disappear."""
+        skips the tiles outside it in both directions, and the crop's slice-backward kernels disappear.
+        `as_uint8` (not in the reference; inference only): return the uint8 [H,W,3] video frame that
+        scripts/inference.py:655-667 derives from the image -- (tensor_to_image(img) * 255).to(uint8) -- stored by the
+        blend kernel itself: the same bytes, without the float image's round trip and five elementwise kernels."""
         _, n_channels = points.shape
         assert n_channels == 14, "The input tensor should have 14 channels."
+        if as_uint8:
+            if gaussian_rasterizer is not None or not points.is_cuda or points.dtype != torch.float32:
+                raise RuntimeError("as_uint8 needs float32 GPU points and the wrapper's own rasterizer")
+            if torch.is_grad_enabled() and points.requires_grad:
+                raise RuntimeError("as_uint8 renders video frames: there is no backward through them (use no_grad)")
+            rs = (self._reference_recipe_on_host(cam_position, cam_quaternion, need_campos=False)
+                  if self.host_camera == "reference" else
+                  self._get_gaussian_rasterization_settings(cam_position, cam_quaternion))
+            return _ext.rasterize_points14(points, rs.bg, rs.scale_modifier, rs.view_matrix, rs.proj_matrix, rs.tanfovx,
+                                           rs.tanfovy, rs.img_h, rs.img_w, rs.campos, bool(self.flip_lr), bool(self.flip_ud),
+                                           window=crop, ticket=True, out_uint8=True)[1]
         if gaussian_rasterizer is None:
-            rs = self._get_gaussian_rasterization_settings(cam_position, cam_quaternion)
+            if points.is_cuda and points.dtype == torch.float32 and self.host_camera == "reference":
+                rs = self._reference_recipe_on_host(cam_position, cam_quaternion, need_campos=False)
+            else:
+                rs = self._get_gaussian_rasterization_settings(cam_position, cam_quaternion)
             if points.is_cuda and points.dtype == torch.float32:
                 # this build's own rasterizer on the [N,14] tensor in place (see _get_gaussian_rasterization): the
                 # GaussianRasterizer module the reference constructs per frame (dgr/__init__.py:376-380) would only be

@@ -110,6 +110,11 @@ typedef struct gcr_camera {
                           rendered Gaussian come out as NaN (never as plausible zeros) -- render its state first with
                           gcr_forward_render(out_color = NULL, backward = 1) into a gcr_binning_bytes() buffer */
   const gcr_options *options; /* HOST pointer or NULL (= all defaults); read during the call only */
+  int32_t out_u8;      /* !=0 (forward of an inference frame only, backward == 0): out_color is NOT float [3,H,W] but the
+                          video frame the reference's render loop makes of it with five elementwise kernels
+                          (scripts/inference.py:655-667: utils/helpers.tensor_to_image(img) * 255 -> uint8):
+                          uint8 [H,W,3] (or [win_h,win_w,3]), value = (uint8)(((clamp(c, -1, 1) / 2 + 0.5) * 255)) in
+                          float32 arithmetic, the same roundings in the same order -- the same bytes */
 } gcr_camera;
 
 /* Per-Gaussian inputs (argument list of cr/rasterizer.h:25-37) */

@@ -63,6 +63,27 @@ def test_reference_recipe_on_host_is_bit_equal_to_the_golden_camera():
         assert np.abs(rf.campos.numpy() - g["campos_%d" % i]).max() <= 1e-6 * max(1.0, float(np.abs(g["campos_%d" % i]).max()))
 
 
+def test_fast_w2c_route_gives_the_library_route_bits():
+    """rasterizer._w2c_fast replaces the scipy Rotation object of dgr/__init__.py:349-368 by the same IEEE operations on
+    Python floats (the numpy lines behind it are the reference's): bit-equal to the library route on thousands of poses,
+    random and orbit-like (where the translation cancels); and the wrapper's own render path skips `view.inverse()` --
+    campos is only read by the SH evaluation, which that path never runs -- without touching view / proj."""
+    from gaussiancity_amd import synth
+    assert rz._fast_w2c_available()
+    rng = np.random.default_rng(7)
+    cases = [(rng.normal(size=3) * 10.0 ** rng.integers(0, 4), rng.normal(size=4)) for _ in range(4000)]
+    cases += synth.orbit_poses() + synth.orbit_poses(24, 60.0, 50.0)
+    for p, q in cases:
+        assert np.array_equal(rz._w2c_fast(p, q).view(np.uint32), rz._w2c_reference_ops(p, q).view(np.uint32)), (p, q)
+    g = np.load(os.path.join(GOLD, "camera.npz"))
+    for i in range(int(g["n_tuples"])):
+        ss = tuple(int(v) for v in g["sensor_%d" % i])
+        wr = ga.GaussianRasterizerWrapper(g["K_%d" % i], ss, device=CPU, host_camera="reference")
+        rs = wr._reference_recipe_on_host(g["pos_%d" % i], g["quat_%d" % i], need_campos=False)
+        assert np.array_equal(rs.view_matrix.numpy(), g["view_%d" % i]) and np.array_equal(rs.proj_matrix.numpy(), g["proj_%d" % i])
+        assert float(rs.campos.abs().sum()) == 0.0   # the stand-in: never handed out, never read (precomputed colours)
+
+
 def test_camera_math_matches_reference():
     g = np.load(os.path.join(GOLD, "camera.npz"))
     for i in range(int(g["n_tuples"])):

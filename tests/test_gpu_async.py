@@ -254,3 +254,33 @@ def test_global_radix_path_on_a_scene_with_empty_tiles(oracle_mod, cuda_device):
             ends = np.maximum.accumulate(np.concatenate([[0], fr.ranges[:, 1]]))[:-1]  # end of the last list before each tile
             np.testing.assert_array_equal(got[~ne, 0], ends[~ne])
             _check_grads(gref, G.run_backward(args, out, dpix, cuda_device), ALL_GRADS)
+
+
+@pytest.mark.parametrize("flip_lr,flip_ud,crop", [(True, False, None), (False, True, (100, 37, 301, 200)), (True, True, (0, 0, 17, 9))])
+def test_video_frames_stored_by_the_blend_equal_the_torch_conversion(cuda_device, flip_lr, flip_ud, crop):
+    """GaussianRasterizerWrapper(as_uint8=True): the forward blend stores the uint8 [H,W,3] video frame that
+    scripts/inference.py:655-667 derives from the float image (tensor_to_image * 255 -> uint8, five torch kernels).
+    Same bytes -- values beyond [-1, 1] included (the colours are scaled so that the clamp matters) -- for mirrored and
+    windowed frames, and through frames.InferenceLoop."""
+    from gaussiancity_amd import GaussianRasterizerWrapper, synth
+    from gaussiancity_amd.frames import InferenceLoop
+    W, H, n = 480, 270, 40000
+    cfg, sc = synth.make_scene("C4", n)
+    rot = np.zeros((n, 4), np.float32)
+    rot[:, 0] = 1.0
+    pts = np.concatenate([sc["means3D"], np.full((n, 1), 0.7, np.float32), sc["scales"] * 3.0, rot, sc["colors_precomp"] * 1.7], axis=1)
+    points = torch.from_numpy(pts.astype(np.float32)).to(cuda_device)
+    wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), flip_lr=flip_lr, flip_ud=flip_ud, device=cuda_device)
+    poses = synth.orbit_poses()[:6]
+    with torch.no_grad():
+        for pos, quat in poses:
+            ref = InferenceLoop.to_uint8_hwc(wr(points, pos, quat, crop=crop))
+            got = wr(points, pos, quat, crop=crop, as_uint8=True)
+            assert got.dtype == torch.uint8 and got.shape == ref.shape
+            assert torch.equal(got, ref)
+            assert int(ref.max()) == 255 and int(ref.min()) == 0 and 20 < float(ref.float().mean()) < 235
+        a = InferenceLoop(lambda p, cp, cq: wr(p, cp, cq, crop=crop), device=cuda_device).run(points, poses)
+        b = InferenceLoop(None, device=cuda_device, render_uint8_fn=lambda p, cp, cq: wr(p, cp, cq, crop=crop, as_uint8=True)).run(points, poses)
+    assert len(a) == len(b) == 6 and all(np.array_equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(RuntimeError, match="no backward"):
+        wr(points.clone().requires_grad_(True), *poses[0], as_uint8=True)
