@@ -278,7 +278,8 @@ def test_video_frames_stored_by_the_blend_equal_the_torch_conversion(cuda_device
             got = wr(points, pos, quat, crop=crop, as_uint8=True)
             assert got.dtype == torch.uint8 and got.shape == ref.shape
             assert torch.equal(got, ref)
-            assert int(ref.max()) == 255 and int(ref.min()) == 0 and 20 < float(ref.float().mean()) < 235
+            if crop is None or crop[2] * crop[3] > 10000:   # (the frame exercises the whole range, both clamps included)
+                assert int(ref.max()) == 255 and int(ref.min()) == 0 and 20 < float(ref.float().mean()) < 235
         a = InferenceLoop(lambda p, cp, cq: wr(p, cp, cq, crop=crop), device=cuda_device).run(points, poses)
         b = InferenceLoop(None, device=cuda_device, render_uint8_fn=lambda p, cp, cq: wr(p, cp, cq, crop=crop, as_uint8=True)).run(points, poses)
     assert len(a) == len(b) == 6 and all(np.array_equal(x, y) for x, y in zip(a, b))

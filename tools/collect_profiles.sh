@@ -6,7 +6,7 @@
 # Afterwards copy gpurun_out/<tag>_* into profiles/ and commit.
 #   usage: gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out
@@ -16,6 +16,13 @@ mkdir -p $O
 B="python $R/bench.py --no-cpu-baseline --no-secondary"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_kt -o k -- $B > /dev/null 2>&1 < /dev/null
 python $R/tools/rocpd_stats.py /tmp/${TAG}_kt/k_results.db $O/${TAG}_kernel_trace_stats.txt > /dev/null
+# the frame period, K1-end -> next-K1-start gaps, queue busy fractions: the default command (frames
+# without the host wait), the positional int API (one host wait per frame), and a host API timeline of the default command
+python $R/tools/timeline.py /tmp/${TAG}_kt/k_results.db 600 48 > $O/${TAG}_timeline_c3.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace -d /tmp/${TAG}_kti -o k -- $B --native-int-api > /dev/null 2>&1 < /dev/null
+python $R/tools/timeline.py /tmp/${TAG}_kti/k_results.db 600 48 > $O/${TAG}_timeline_c3_native_int_api.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --hip-trace -d /tmp/${TAG}_ht -o k -- $B --steps 100 > /dev/null 2>&1 < /dev/null
+python $R/tools/timeline.py /tmp/${TAG}_ht/k_results.db 600 18 2>&1 | head -260 > $O/${TAG}_timeline_c3_hip_trace.txt
 # the same command on ONE stream: every kernel alone on the GPU -- the durations bench.py's `roofline.launch_ms` and
 # `stages_ms[*].ms_single_stream` report (the default command's trace above shows them stretched by the frames in flight)
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_kt1 -o k -- $B --streams 1 > /dev/null 2>&1 < /dev/null
@@ -42,13 +49,14 @@ python $R/tools/rocpd_pmc.py /tmp/${TAG}_c2_w/p_results.db $O/${TAG}_c2_bwd_pmc_
 python $R/tools/rocpd_pmc.py /tmp/${TAG}_c2_sq/p_results.db $O/${TAG}_c2_bwd_pmc_sq.txt > /dev/null
 python $R/tools/make_traffic.py /tmp/${TAG}_c2_f/p_results.db /tmp/${TAG}_c2_w/p_results.db $O/${TAG}_traffic_c2.json \
   /tmp/${TAG}_c2_sq/p_results.db "C2 (500k S-rand, 640x448, SH3, forward + backward)" > /dev/null
-# ---- backward blend: SQ counters (VALU / LDS activity), per-wave phase clocks and knock-outs (experiment build) --------
-bash $R/tools/k7_pmc.sh ${TAG} 128 > /dev/null 2>&1
-if [ -f $R/tools/_build/libgcr_hip_exp.so ]; then
-  (cd $R && timeout 200 python tools/k7_clocks.py --piece 128 > $O/${TAG}_k7_clocks.json 2>/dev/null)
-  (cd $R && timeout 200 python tools/k7_knockout.py 128 > $O/${TAG}_k7_knockouts.jsonl 2>/dev/null)
-fi
-(cd $R && timeout 300 python tools/piece_probe.py --pieces 256,128,64 > $O/${TAG}_piece_probe.jsonl 2>/dev/null)
+# ---- C5 (20 M Gaussians, 4K): counters for its roofline.traffic -------------------------------------------
+B="python $R/bench.py --config C5 --no-cpu-baseline --no-secondary"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_c5_f -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_c5_w -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
+  --kernel-trace -d /tmp/${TAG}_c5_sq -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
+python $R/tools/make_traffic.py /tmp/${TAG}_c5_f/p_results.db /tmp/${TAG}_c5_w/p_results.db $O/${TAG}_traffic_c5.json \
+  /tmp/${TAG}_c5_sq/p_results.db "C5 (20M S-city, 3840x2160, SH3, forward)" > /dev/null
 
 # ---- C4: the wrapper / helpers path at the product's own shape (host-bound): kernel trace + host profile ---------------
 B="python $R/bench.py --train-step --steps 200 --host-camera closed-form"
@@ -76,12 +84,13 @@ done
 
 # ---- bench lines ---------------------------------------------------------------------------------------------------
 python $R/bench.py > $O/${TAG}_bench_c3.json 2>/dev/null
+python $R/bench.py --native-int-api --no-cpu-baseline --no-secondary > $O/${TAG}_bench_c3_native_int_api.json 2>/dev/null
 python $R/bench.py --config C5 --steps 48 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_c5.json 2>/dev/null
 python $R/bench.py --config D1 --steps 48 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_d1.json 2>/dev/null   # dense stress scene (lazy tile sort)
 python $R/bench.py --config D1 --steps 48 --no-secondary --no-cpu-baseline --sort-whole > $O/${TAG}_bench_d1_sorted_whole.json 2>/dev/null
 python $R/bench.py --path visibility > $O/${TAG}_bench_visibility.json 2>/dev/null
 python $R/bench.py --path grid-encoder > $O/${TAG}_bench_grid_encoder.json 2>/dev/null
-for hc in "--host-camera device" "--host-camera reference" "--host-camera closed-form"; do   # the product's inference loop through the wrapper
+for hc in "--host-camera device" "--host-camera reference" "--host-camera closed-form" "--host-camera reference --float-frames" "--host-camera closed-form --float-frames"; do   # the product's inference loop through the wrapper
   python $R/bench.py --inference-loop --steps 240 $hc 2>/dev/null
 done > $O/${TAG}_bench_inference_loop.jsonl
 python $R/bench.py --config C2 --backward --no-secondary --steps 200 > $O/${TAG}_bench_c2_fwd_bwd.json 2>/dev/null

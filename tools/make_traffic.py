@@ -26,8 +26,8 @@ def kernel_source_hashes():
 # bench.py stage -> substrings of the kernel names launched inside that stage timer (gcr_api.hip)
 STAGES = {
     "preprocess": ("k_preprocess_fused", "k_preprocess_cull", "k_preprocess_project"),
-    "scan": ("k_tile_table<false>", "k_tile_table<0>", "k_tile_tableILb0", "k_table_colscan"),
-    "emit": ("k_tile_table<true>", "k_tile_table<1>", "k_tile_tableILb1"),
+    "scan": ("k_tile_table<false", "k_tile_table<0", "k_tile_tableILb0", "k_table_colscan"),   # (<false, 1024>: no ">")
+    "emit": ("k_tile_table<true", "k_tile_table<1", "k_tile_tableILb1"),
     "sort": ("k_tile_sort",),
     "blend_fwd": ("k_blend_fwd",),
     "blend_bwd": ("k_blend_bwd", "k_zero_grad_records"),
@@ -54,7 +54,7 @@ def main(fetch_db, write_db, out, sq_db=None, workload="C3 (5M S-city, 1920x1080
     for stage, pats in STAGES.items():
         fs = sum(v for k, (v, _) in f.items() if any(p in k for p in pats))
         ws = sum(v for k, (v, _) in w.items() if any(p in k for p in pats))
-        names = sorted(set(re.search(r"k_\w+(<\w+>)?", k).group(0) for k in f if any(p in k for p in pats)))
+        names = sorted(set(re.search(r"k_\w+(<[\w, ]+>)?", k).group(0) for k in f if any(p in k for p in pats)))
         if not names:
             continue
         kernels[stage] = {"FETCH_SIZE_KB": round(fs, 1), "WRITE_SIZE_KB": round(ws, 1), "kernels": names}
