@@ -285,3 +285,42 @@ def test_video_frames_stored_by_the_blend_equal_the_torch_conversion(cuda_device
     assert len(a) == len(b) == 6 and all(np.array_equal(x, y) for x, y in zip(a, b))
     with pytest.raises(RuntimeError, match="no backward"):
         wr(points.clone().requires_grad_(True), *poses[0], as_uint8=True)
+
+
+def test_long_lazily_sorted_lists_in_asynchronous_frames(oracle_mod, cuda_device, monkeypatch):
+    """Tile lists beyond 4096 entries of nearly transparent Gaussians: the forward blend sorts them on, segment by
+    segment, as far as it walks -- here inside ASYNCHRONOUS frames: inference frames on the lean binning carve (the
+    unsorted keys the extension reads sit at the capacity-carved offset), a training frame whose backward follows, and a
+    training frame that overflows its capacity guess (rescued, then binned again by the backward)."""
+    from gaussiancity_amd import ext
+    P, W, H = 9000, 48, 48
+    rs = scenes.camera(W, H)
+    sc = scenes.blob_scene(P, 61, 0, spread=2.0, smin=0.5, smax=2.0, omin=0.01, omax=0.05)
+    fr = _frame(oracle_mod, rs, sc, use_sh=False)
+    lens = fr.ranges[:, 1].astype(np.int64) - fr.ranges[:, 0]
+    assert lens.max() > 4096
+    key = (cuda_device.index, P, W, H)
+    ext._capacity_hint.pop(key, None)
+    a = _args(rs, sc, cuda_device, sh=False)
+    outs = [ext.rasterize_gaussians_ticket(*a) for _ in range(4)]                      # 1 synchronous + 3 asynchronous
+    outs.append(ext.rasterize_gaussians_ticket(*a, _for_backward=True))                 # training frame
+    monkeypatch.setattr(ext, "_ASYNC_MARGIN", 16)
+    ext._capacity_hint[key] = (100, 64)
+    outs.append(ext.rasterize_gaussians_ticket(*a, _for_backward=True))                 # overflows: rescued
+    torch.cuda.synchronize()
+    assert [o[0].seq != 0 for o in outs] == [False, True, True, True, True, True] and outs[-1][0].rescued
+    for o in outs:
+        assert int(o[0]) == fr.R
+        assert np.array_equal(o[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
+    d = G.decode(P, W, H, (fr.R,) + tuple(outs[2][1:]))
+    _check_forward(fr, d, P, False)
+    assert (d["tile_sorted"] > 1024).any()
+    dpix = np.random.default_rng(8).normal(size=(3, H, W)).astype(np.float32)
+    gref = fr.backward(dpix)
+    (bg, m3, col, opa, scl, rot, smod, cov, view, proj, tfx, tfy, h, w, sh, deg, campos, _, _) = a
+    names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
+    for o in outs[-2:]:
+        g = ext.rasterize_gaussians_backward(bg, m3, o[2], col, scl, rot, smod, cov, view, proj, tfx, tfy,
+                                             G.to_dev(dpix, cuda_device), sh, deg, campos, o[3], o[0], o[4], o[5], False)
+        _check_grads(gref, {n: x.cpu().numpy() for n, x in zip(names, g)},
+                     ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dscale", "dL_drot"])
