@@ -86,6 +86,13 @@ def test_a_frame_that_overflows_its_capacity_guess_is_rescued_in_stream_order(or
     assert np.array_equal(behind.cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
     assert np.array_equal(out[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
     assert ext._capacity_hint[key][0] == fr.R   # the next guess starts from the truth
+    # the same with the host thread blocked in a device-wide synchronisation instead of the ticket's wait: only the
+    # rescue thread can release the gate then
+    ext._capacity_hint[key] = (10, 64)
+    out_s = ext.rasterize_gaussians_ticket(*a, _for_backward=train)
+    torch.cuda.synchronize()
+    assert out_s[0].done() and out_s[0].rescued and N.lib().gcr_rescue_count() == rescued0 + 2
+    assert np.array_equal(out_s[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
     # the frame after it fits again
     out2 = ext.rasterize_gaussians_ticket(*a, _for_backward=train)
     assert int(out2[0]) == fr.R and not out2[0].rescued
