@@ -112,9 +112,6 @@ def main():
     ap.add_argument("--float-frames", action="store_true",
                     help="--inference-loop: render float images and convert them to uint8 frames with torch kernels, as "
                          "scripts/inference.py does (default: the blend kernel stores the uint8 frame, same bytes)")
-    ap.add_argument("--max-unresolved", type=int, default=None,
-                    help="frames without the host wait: asynchronous frames whose num_rendered the host has not seen yet "
-                         "before it enqueues another one (ext.max_unresolved; 0 = unbounded up to the ticket ring)")
     ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the frame loop alternates over (frames are independent; 1 = serial); "
                          "default 3 (measured optimum for both paths: C3 forward 4 520 / 4 700 / 4 690 frames/s "
@@ -213,8 +210,6 @@ def main():
         return got if rank == 0 else None
     args.collect_ranks = collect_ranks
     N.lib()
-    if args.max_unresolved is not None:
-        ext.max_unresolved = args.max_unresolved
     N.set_option("fast_exp", 1 if args.fast_exp else 0)
     N.set_option("split_preprocess", 1 if args.split_preprocess else 0)
     N.set_option("sort_in_blend", 1 if args.sort_in_blend else 0)

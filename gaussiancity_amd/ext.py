@@ -102,11 +102,6 @@ _RING = 32  # asynchronous frames a host thread may have outstanding (the ring's
 # H): the host runs ahead of the device, so that number may be a few frames old -- twice it, plus a constant
 _ASYNC_FACTOR, _ASYNC_MARGIN = 2, 65536
 _SYNC_ONLY = os.environ.get("GCR_EXT_SYNC") == "1"  # measurement aid: keep the reference's host wait in every frame
-# Asynchronous frames whose num_rendered this host thread has not seen yet (= whose K1 has not finished) before it
-# enqueues another one.  0 = only the ring bounds it.  A small number paces a BURST of frames: without it the host
-# enqueues a whole burst at once, the frames of the streams start in lock-step (all K1 launches together, then all
-# blends together) and the HBM-bound K1 never runs beside the VALU-bound blend until the streams have drifted apart.
-max_unresolved = int(os.environ.get("GCR_MAX_UNRESOLVED", "0"))
 
 
 class FrameTicket:
@@ -370,10 +365,6 @@ def _forward(L, device, cam, g, P, H, W, ticket=False):
         # num_rendered.  A frame that still does not fit is rendered correctly by the library's rescue (include/gcr.h).
         capacity = _ASYNC_FACTOR * R_seen + _ASYNC_MARGIN
         binning = torch.empty((nbytes(capacity, W, H),), **byte)
-        if max_unresolved > 0:
-            while len(ring.pending) >= max_unresolved:
-                ring.pending[0].wait()
-                ring.harvest()
         slot, words, addr, seq = ring.take()
         N.check(L.gcr_forward_async(C.byref(cam), C.byref(g), geom.data_ptr(), gbytes, binning.data_ptr(), binning.numel(),
                                     capacity, list_cap, img.data_ptr(), ibytes, radii.data_ptr(), out_color.data_ptr(),
