@@ -653,7 +653,10 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
   // the grid covers the units the host expects; should the forward have used a smaller piece, the waves stride on
   for (unsigned long long unit = (unsigned long long)blockIdx.x - (unsigned long long)a.fill.blocks; unit < nunits;
        unit += (unsigned long long)gridDim.x - (unsigned long long)a.fill.blocks) {
-    const uint4 d = work[unit >> 2];
+    uint4 d = work[unit >> 2];
+    // (one 16-byte load: left alone the compiler fetches d.x, tests it, and only then fetches the rest -- a second
+    // dependent round trip at the head of every unit's chain)
+    asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
     if (d.x == GCR_NO_TILE) continue;  // wave-uniform
     const int q = (int)(unit & 3ull);  // quadrant of the tile: the `wave` of K6's lane geometry
     const int tile = (int)d.x;
@@ -721,18 +724,53 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
     const float neg_T_final = -T_final;
     float last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;
 
-    // ---- passes of 64 list entries, back to front: pass slot `lane` holds list entry pos - 1 - lane
-    for (int pos = top; pos > (int)lo; pos -= WPASS) {
-      const int e_l = pos - 1 - lane;
-      const bool have = e_l >= (int)lo;
-      const uint32_t m16 = have ? (uint32_t)masks[r0 + (uint32_t)e_l] : 0u;
-      const bool any_rel = (m16 & quad_bits) != 0u;  // reaches one of this quadrant's 4x4 blocks (e_l < wave_max holds)
+    // ---- passes of 64 list entries, back to front: pass slot `lane` of pass k holds list entry top - 1 - 64 k - lane.
+    // A unit's life is a chain of dependent memory round trips, and round 3's knock-outs showed that they ADD (a wave per
+    // unit, 16 waves per CU: nothing covers another wave's wait).  Per pass the chain was masks -> list entry -> records;
+    // here (round 4) the block masks and list entries of ALL the unit's passes are requested at once (a piece is <= 256
+    // entries = <= 4 passes) and the records of pass k + 1 are gathered while pass k is walked: work item -> pixel state ->
+    // masks + list -> records of the FIRST pass is the whole chain, whatever the number of passes.  (+20 VGPRs, still
+    // within the 128 of four waves per SIMD.)
+    const int npass = (top - (int)lo + WPASS - 1) / WPASS;
+    uint32_t wm0, wm1, wm2, wm3, wi0, wi1, wi2, wi3;
+#define GCR_K7_WINDOW(K, M, I)                                         \
+  {                                                                    \
+    const int e = top - 1 - (K) * WPASS - lane;                        \
+    const bool hv = (K) < npass && e >= (int)lo;                       \
+    M = hv ? (uint32_t)masks[r0 + (uint32_t)(hv ? e : 0)] : 0u;        \
+    I = hv ? a.list[r0 + (uint32_t)(hv ? e : 0)] : 0u;                 \
+  }
+    GCR_K7_WINDOW(0, wm0, wi0)
+    GCR_K7_WINDOW(1, wm1, wi1)
+    GCR_K7_WINDOW(2, wm2, wi2)
+    GCR_K7_WINDOW(3, wm3, wi3)
+#undef GCR_K7_WINDOW
+    bool rel_n = (wm0 & quad_bits) != 0u;  // reaches one of this quadrant's 4x4 blocks (entries below wave_max only)
+    float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0, n2 = n0;
+    if (rel_n) {
+      const float4* __restrict__ rec = a.rec + (size_t)wi0 * GCR_REC_QUADS;
+      n0 = rec[0];
+      n1 = rec[1];
+      n2 = rec[2];
+    }
+    for (int k = 0; k < npass; k++) {
+      const int e_l = top - 1 - k * WPASS - lane;
+      const uint32_t m16 = wm0, id = wi0;
+      const bool any_rel = rel_n;
+      const float4 q0 = n0, q1 = n1, q2 = n2;
+      // the next pass's records: in flight while this pass is staged, walked and flushed
+      wm0 = wm1; wm1 = wm2; wm2 = wm3; wm3 = 0u;
+      wi0 = wi1; wi1 = wi2; wi2 = wi3; wi3 = 0u;
+      rel_n = k + 1 < npass && (wm0 & quad_bits) != 0u;
+      if (rel_n) {
+        const float4* __restrict__ rec = a.rec + (size_t)wi0 * GCR_REC_QUADS;
+        n0 = rec[0];
+        n1 = rec[1];
+        n2 = rec[2];
+      }
       const uint64_t rel_bal = __ballot(any_rel);
       if (rel_bal == 0ull) continue;  // wave-uniform: nothing of these 64 entries concerns the quadrant
       if (any_rel) {
-        const uint32_t id = a.list[r0 + (uint32_t)e_l];
-        const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         sE[lane].a = q0;
         sE[lane].b = q1;
         sE[lane].c = make_float4(q2.x, gcr_alpha_skip_bound(q1.y), __uint_as_float((uint32_t)e_l),
