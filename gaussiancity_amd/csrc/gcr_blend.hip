@@ -542,7 +542,7 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
     const float power_raw = gcr_power(QA.z, QA.w, QB.x, dx, dy);                               \
     const bool in_range = __float_as_uint(QC.z) < last_contributor && !(power_raw > 0.0f) &&   \
                           !(power_raw < QC.y);                                                 \
-    if (__ballot(in_range) != 0ull && GCR_STEP_ON) { /* else the whole wave skips this step */ \
+    if (GCR_K7_WAVE_SKIP(in_range) && GCR_STEP_ON) { /* else the whole wave skips this step */   \
       const float power = in_range ? power_raw : 0.0f;                                         \
       const float G = blend_exp<FAST_EXP>(power);                                              \
       const float alpha = __builtin_fminf(0.99f, QB.y * G);                                    \
@@ -589,6 +589,18 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
       if (acc_slot >= 0 && GCR_LDS_ADD_ON) atomicAdd(reinterpret_cast<float*>(acc_base + __float_as_uint(QC.w)), rsum); \
     }                                                                                          \
   }
+// The wave-uniform skip of a step no lane is in range of: K6 keeps it; here a step of a row list almost always has a lane
+// in range (the list holds the entries whose block mask reaches the row's block, below the row's max n_contrib), the body
+// is correct for a wave without one (alpha_eff = 0 everywhere), and without the branch the two steps of a trip are ONE basic
+// block the scheduler can interleave -- the walk is a ~50-deep dependent chain per step with four waves per SIMD to hide it.
+#ifndef GCR_K7_SKIP_BRANCH
+#define GCR_K7_SKIP_BRANCH 0
+#endif
+#if GCR_K7_SKIP_BRANCH
+#define GCR_K7_WAVE_SKIP(x) (__ballot(x) != 0ull)
+#else
+#define GCR_K7_WAVE_SKIP(x) true
+#endif
 #ifdef GCR_EXPERIMENTS  /* knock-out bit 3: one LDS read per step instead of three (results wrong) */
 #define GCR_BWD_LOAD(QA, QB, QC, OFF)                              \
   QA = *reinterpret_cast<const float4*>(sEb + (OFF));             \
