@@ -38,9 +38,9 @@ _hint_lock = threading.Lock()
 poison_outputs = False
 
 
-# "A backward call will follow this forward": set by RasterizeGaussiansFunction around its native call (per host
-# thread), read by rasterize_gaussians.  A pure performance hint (gcr_camera.backward): the forward blend leaves its
-# checkpoints in the smaller pieces the backward balances best with; results do not depend on it.
+# Per host thread: "a backward call will follow the next rasterize_gaussians()" for callers that cannot pass the keyword
+# (set_backward_hint; None / never set = True, the reference's contract), the per-call options, the ticket ring.
+# gcr_camera.backward never changes an image: it says whether the forward blend leaves the backward's per-piece state.
 _tls = threading.local()
 
 
@@ -359,8 +359,8 @@ def _forward(L, device, cam, g, P, H, W, ticket=False):
     R_seen, list_cap = _hint_get(key)
     nbytes = L.gcr_binning_bytes if stateful else L.gcr_binning_bytes_lean
     opt = _current_options()
-    if ticket and R_seen > 0 and not cam.debug and not (opt.force_radix > 0 if opt is not None
-                                                         else N.get_option("force_radix")):
+    radix = opt.force_radix if (opt is not None and opt.force_radix >= 0) else N.get_option("force_radix")
+    if ticket and R_seen > 0 and not cam.debug and not radix:
         # The guess is made from a frame that may be several frames old (the host runs ahead of the device): twice its
         # num_rendered.  A frame that still does not fit is rendered correctly by the library's rescue (include/gcr.h).
         capacity = _ASYNC_FACTOR * R_seen + _ASYNC_MARGIN
