@@ -141,6 +141,26 @@ GCR_DEV uint32_t slot_of_offset(uint32_t off) { return (off * 1366u) >> 16; }
 //     reads; unique keys => rank = position); a longer list -- only possible when the caller's length hint was
 //     stale, the host then switches to the K4 path -- is ranked the same way through global loads: slow, correct.
 //     The sorted indices are also written to `list_out` for the backward.
+// The step's wave-uniform skip ("no lane of the wave is in range of its row's entry").  With four rows on four different
+// entries it almost never fires, the body is exact for a wave without a lane in range (every use is behind a select), and
+// without the branch the two steps of a trip are one basic block: round 4 A/B at C3, same box, blend alone 106.4 -> 104.0 us,
+// 5 125-5 134 -> 5 161-5 192 frames/s (profiles/r04_micro_ab.jsonl).  1 = the branch (A/B builds).
+#ifndef GCR_K6_SKIP_BRANCH
+#define GCR_K6_SKIP_BRANCH 0
+#endif
+#if GCR_K6_SKIP_BRANCH
+#define GCR_K6_WAVE_SKIP(x) (__ballot(x) != 0ull)
+#else
+#define GCR_K6_WAVE_SKIP(x) true
+#endif
+// K7: a row standing on the sentinel entry (its list is shorter than the wave's longest) has nothing to add: without its
+// nine lanes in the ds_add_f32 the launch is 89.2 instead of 94.0 us at C2 (same A/B file).  1 = add anyway (A/B builds).
+#ifndef GCR_K7_ADD_SENTINEL
+#define GCR_K7_ADD_SENTINEL 0
+#endif
+#ifndef GCR_K7_ADD_ZERO  /* A/B builds: 0 = lanes whose row sum is exactly zero issue no LDS add either */
+#define GCR_K7_ADD_ZERO 1
+#endif
 #ifdef GCR_EXPERIMENTS  /* knock-outs for timing: bit 0 = no step arithmetic, bit 1 = no chunk loop at all */
 #define GCR_K6_STEP_ON !(a.debug_flags & 1)
 #define GCR_K6_LOOP_ON !(a.debug_flags & 2)
@@ -291,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const float dx = QA.x - pixx, dy = QA.y - pixy;                                          \
     const float power = __builtin_fmaf(QA.w * dx, dy, __builtin_fmaf(QB.x * dy, dy, (QA.z * dx) * dx)); \
     const bool in_range = !(power > 0.0f) && !(power < QC.y);                                \
-    if (__ballot(in_range) != 0ull && GCR_K6_STEP_ON) { /* wave-uniform */                   \
+    if (GCR_K6_WAVE_SKIP(in_range) && GCR_K6_STEP_ON) { /* wave-uniform */                    \
       /* lanes outside [pmin, 0] may produce garbage; every use below is behind a select */  \
       const float araw = __builtin_fminf(0.99f, QB.y * blend_exp<FAST_EXP>(power));          \
       const bool valid = in_range && !(araw < 1.0f / 255.0f);                                \
@@ -586,7 +606,9 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
       /* reduce-scatter over each 16-lane row, then ONE ds_add_f32: lanes 0..8 of every row */ \
       /* add their row's sum of term (lane & 15) into the column of the row's entry */         \
       const float rsum = gcr_row_reduce_scatter9(v, lane);                                     \
-      if (acc_slot >= 0 && GCR_LDS_ADD_ON) atomicAdd(reinterpret_cast<float*>(acc_base + __float_as_uint(QC.w)), rsum); \
+      if (acc_slot >= 0 && GCR_LDS_ADD_ON && (GCR_K7_ADD_SENTINEL || __float_as_uint(QC.z) != NO_ENTRY) &&               \
+          (GCR_K7_ADD_ZERO || rsum != 0.0f))                                                                              \
+        atomicAdd(reinterpret_cast<float*>(acc_base + __float_as_uint(QC.w)), rsum);                                      \
     }                                                                                          \
   }
 // The wave-uniform skip of a step no lane is in range of: K6 keeps it; here a step of a row list almost always has a lane
