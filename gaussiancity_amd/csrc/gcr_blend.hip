@@ -131,8 +131,8 @@ GCR_DEV uint32_t slot_of_offset(uint32_t off) { return (off * 1366u) >> 16; }
 //         A pixel that skips the entry has a_eff = 0 -> test_T = Tw (>= 1e-4 while live) -> keep, w = 0;
 //         a finished pixel has Tw < 0 -> !keep -> Tw unchanged.  (colour*0)*Tw adds an exact zero.
 //         Two corner cases are knowingly different from upstream, both on garbage input only: a
-//         NON-FINITE colour poisons every pixel of the 4x4 blocks that evaluate the Gaussian
-//         (upstream: only pixels it contributes to), and an accumulator that is exactly -0.0 (needs a
+//         NON-FINITE colour poisons every pixel of the 4x4 blocks whose list holds the Gaussian (the conservative
+//         block mask; upstream: only pixels it contributes to), and an accumulator that is exactly -0.0 (needs a
 //         colour below 1e-40) may become +0.0.
 //   * SORT (template): the workgroup sorts its own tile first.  GaussianCity's scenes have ~150 entries per tile, and
 //     sorting 150 keys is a microsecond of work for the workgroup that is about to gather them anyway -- as a
@@ -158,9 +158,7 @@ GCR_DEV uint32_t slot_of_offset(uint32_t off) { return (off * 1366u) >> 16; }
 #ifndef GCR_K7_ADD_SENTINEL
 #define GCR_K7_ADD_SENTINEL 0
 #endif
-#ifndef GCR_K7_ADD_ZERO  /* A/B builds: 0 = lanes whose row sum is exactly zero issue no LDS add either */
-#define GCR_K7_ADD_ZERO 1
-#endif
+// (lanes whose row sum is exactly zero left out of the add as well: 90.3 vs 89.4 us, no gain, not kept)
 #ifdef GCR_EXPERIMENTS  /* knock-outs for timing: bit 0 = no step arithmetic, bit 1 = no chunk loop at all */
 #define GCR_K6_STEP_ON !(a.debug_flags & 1)
 #define GCR_K6_LOOP_ON !(a.debug_flags & 2)
@@ -606,8 +604,7 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
       /* reduce-scatter over each 16-lane row, then ONE ds_add_f32: lanes 0..8 of every row */ \
       /* add their row's sum of term (lane & 15) into the column of the row's entry */         \
       const float rsum = gcr_row_reduce_scatter9(v, lane);                                     \
-      if (acc_slot >= 0 && GCR_LDS_ADD_ON && (GCR_K7_ADD_SENTINEL || __float_as_uint(QC.z) != NO_ENTRY) &&               \
-          (GCR_K7_ADD_ZERO || rsum != 0.0f))                                                                              \
+      if (acc_slot >= 0 && GCR_LDS_ADD_ON && (GCR_K7_ADD_SENTINEL || __float_as_uint(QC.z) != NO_ENTRY))                 \
         atomicAdd(reinterpret_cast<float*>(acc_base + __float_as_uint(QC.w)), rsum);                                      \
     }                                                                                          \
   }
