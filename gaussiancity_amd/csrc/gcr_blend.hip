@@ -554,6 +554,20 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
 // The two quotients share the divisor 1 - alpha: one v_rcp_f32 + one Newton step (<= 1 ulp) instead of two IEEE
 // division expansions -- the only place the HIP path leaves gcr-fp32-v2; K7's sums are order-dependent (atomics)
 // and tolerance-checked anyway.
+// GCR_K7_RS_ASM=0 builds the compiler-scheduled reduce-scatter (35 VALU instructions) for A/B runs
+#ifndef GCR_K7_RS_ASM
+#define GCR_K7_RS_ASM 1
+#endif
+#if GCR_K7_RS_ASM
+#define GCR_K7_ROW_SLOT gcr_row_reduce_scatter9_b_slot(lane)
+#define GCR_K7_ROW_SUMS                                                                                        \
+  float rs_r;                                                                                                  \
+  const float rs_8 = gcr_row_reduce_scatter9_b(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], rs_r);    \
+  const float rsum = acc_slot == 8 ? rs_8 : rs_r;
+#else
+#define GCR_K7_ROW_SLOT ((lane & 15) <= 8 ? (lane & 15) : -1)
+#define GCR_K7_ROW_SUMS const float rsum = gcr_row_reduce_scatter9(v, lane);
+#endif
 #define GCR_BWD_STEP(QA, QB, QC)                                                               \
   {                                                                                            \
     const float dx = QA.x - pixx, dy = QA.y - pixy;                                            \
@@ -601,9 +615,9 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
       v[6] = gdx * dy * hG;                                                                    \
       v[7] = gdy * dy * hG;                                                                    \
       v[8] = G * dL_dalpha;                                                                    \
-      /* reduce-scatter over each 16-lane row, then ONE ds_add_f32: lanes 0..8 of every row */ \
-      /* add their row's sum of term (lane & 15) into the column of the row's entry */         \
-      const float rsum = gcr_row_reduce_scatter9(v, lane);                                     \
+      /* reduce-scatter over each 16-lane row, then ONE ds_add_f32: nine lanes of every row    */ \
+      /* add their row's sum of one term each into the column of the row's entry               */ \
+      GCR_K7_ROW_SUMS                                                                          \
       if (acc_slot >= 0 && GCR_LDS_ADD_ON && (GCR_K7_ADD_SENTINEL || __float_as_uint(QC.z) != NO_ENTRY))                 \
         atomicAdd(reinterpret_cast<float*>(acc_base + __float_as_uint(QC.w)), rsum);                                      \
     }                                                                                          \
@@ -668,7 +682,7 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
   const uint4* __restrict__ work = reinterpret_cast<const uint4*>(a.binning_base + a.frame_in[GCR_FRAME_WORK_OFF]);
   const uint16_t* __restrict__ masks = reinterpret_cast<const uint16_t*>(a.binning_base + a.frame_in[GCR_FRAME_MASK_OFF]);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  const int acc_slot = (lane & 15) <= 8 ? (lane & 15) : -1;  // which of the 9 terms this lane adds / flushes
+  const int acc_slot = GCR_K7_ROW_SLOT;  // which of the nine terms this lane adds to the accumulators
   const float bg0 = GCR_CAM(a, bg, a.bg, 0), bg1 = GCR_CAM(a, bg, a.bg, 1), bg2 = GCR_CAM(a, bg, a.bg, 2);
   const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
   const char* const sEb = reinterpret_cast<const char*>(sE);

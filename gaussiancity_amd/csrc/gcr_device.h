@@ -163,6 +163,61 @@ GCR_DEV float gcr_row_reduce_scatter9(const float (&v)[9], int lane) {
   return GCR_RS_MERGE(m07, s8, b3, gcr_lane_xor8);
 }
 
+// The same reduce-scatter in 20 VALU instructions (round 4; the version above compiles to 35: 16 selects, 13 DPP
+// operations, 4 moves / adds and two s_nop).  The lane bits are consumed in the order 3, 2, 1, 0 instead of 0, 1, 2, 3:
+// on bits 3 and 2 a DPP row rotate / row shift with a BANK MASK adds and selects in one instruction (a bank is four
+// lanes: bits 3 and 2 of the lane number), so only bit 1 needs selects.  Written as one asm block because the
+// bank-masked form needs the destination as the "old" value of the lanes it leaves alone, and because a DPP
+// instruction must not read a VGPR a VALU instruction wrote in the two slots before it (the hardware does not
+// interlock: the independent chains are interleaved by hand, s_nop where nothing is left to interleave).
+// Out: every lane of a 16-lane row holds in `r` the row sum of term t = bit3 + 2 bit2 + 4 bit1 of its lane number
+// (both values of bit 0), and in the return value the row sum of v[8].
+GCR_DEV float gcr_row_reduce_scatter9_b(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                                        float v8, float& r) {
+  float keep, send;
+  const unsigned long long m_bit1 = 0xCCCCCCCCCCCCCCCCull;
+  asm volatile(
+      "s_nop 1\n\t"
+      // bit 3: lanes 0-7 <- (v_even[i] + v_even[i^8]), lanes 8-15 <- (v_odd[i] + v_odd[i^8])
+      "v_add_f32_dpp %[a0], %[a0], %[a0] row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[a2], %[a2], %[a2] row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[a4], %[a4], %[a4] row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[a6], %[a6], %[a6] row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[a0], %[b1], %[b1] row_ror:8 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[a2], %[b3], %[b3] row_ror:8 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[a4], %[b5], %[b5] row_ror:8 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[a6], %[b7], %[b7] row_ror:8 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[s8], %[s8], %[s8] row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      // bit 2: lanes with bit 2 clear (banks 0, 2) keep the first register's terms, the others take the second's
+      "v_add_f32_dpp %[a0], %[a0], %[a0] row_shl:4 row_mask:0xf bank_mask:0x5 bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[a0], %[a2], %[a2] row_shr:4 row_mask:0xf bank_mask:0xa bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[a4], %[a4], %[a4] row_shl:4 row_mask:0xf bank_mask:0x5 bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[a4], %[a6], %[a6] row_shr:4 row_mask:0xf bank_mask:0xa bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[s8], %[s8], %[s8] row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      // bit 1 (inside a bank: selects)
+      "v_cndmask_b32_e64 %[keep], %[a0], %[a4], %[m1]\n\t"
+      "v_cndmask_b32_e64 %[send], %[a4], %[a0], %[m1]\n\t"
+      "v_add_f32_dpp %[s8], %[s8], %[s8] row_ror:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %[keep], %[send], %[keep] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %[s8], %[s8], %[s8] row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 0\n\t"
+      // bit 0: both lanes of a pair end up with the complete sum of their term
+      "v_add_f32_dpp %[keep], %[keep], %[keep] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      : [a0] "+v"(v0), [a2] "+v"(v2), [a4] "+v"(v4), [a6] "+v"(v6), [s8] "+v"(v8), [keep] "=&v"(keep), [send] "=&v"(send)
+      : [b1] "v"(v1), [b3] "v"(v3), [b5] "v"(v5), [b7] "v"(v7), [m1] "s"(m_bit1));
+  r = keep;
+  return v8;
+}
+// which of the nine terms lane (lane & 15) of a row holds after gcr_row_reduce_scatter9_b, or -1: the even lanes hold
+// term bit3 + 2 bit2 + 4 bit1, lane 1 speaks for term 8
+GCR_DEV int gcr_row_reduce_scatter9_b_slot(int lane) {
+  const int l = lane & 15;
+  if (l == 1) return 8;
+  if (l & 1) return -1;
+  return ((l >> 3) & 1) + 2 * ((l >> 2) & 1) + 4 * ((l >> 1) & 1);
+}
+
 GCR_DEV uint32_t gcr_wave_sum_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

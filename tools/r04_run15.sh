@@ -1,0 +1,17 @@
+#!/bin/bash
+set -u
+TAG=${1:-r04q}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+O=$R/gpurun_out
+timeout 1200 python -m pytest tests -m gpu -q --timeout 180 > $O/${TAG}_pytest.txt 2>&1
+tail -3 $O/${TAG}_pytest.txt
+: > $O/${TAG}_micro_ab.jsonl
+for rep in 1 2 3; do
+  for v in ship rsold; do
+    echo "{\"variant\": \"K7 $v\"}" >> $O/${TAG}_micro_ab.jsonl
+    if [ $v = ship ]; then timeout 300 python tools/piece_probe.py --pieces 128 --no-c3 2>/dev/null >> $O/${TAG}_micro_ab.jsonl
+    else GCR_LIB_PATH=$R/tools/_build/libgcr_hip_$v.so timeout 300 python tools/piece_probe.py --pieces 128 --no-c3 2>/dev/null >> $O/${TAG}_micro_ab.jsonl; fi
+  done
+done
+echo done
