@@ -507,6 +507,7 @@ static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_g
   b.gate_polls = 400000u;  // about two seconds before a gate gives up (~5 us per poll: a PCIe round trip + two s_sleep 127)
 #ifdef GCR_EXPERIMENTS
   b.debug_flags = g_k6_debug.load();
+  b.clock_buf = g_clock_buf.load();  // K6: [tile][8] = {hw id | xcc id << 32, clock at entry, at exit, list length, staged, lists built, walk done, steps}
 #endif
   {
     StageTimer t(s, ST_BLEND_FWD);

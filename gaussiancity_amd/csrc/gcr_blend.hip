@@ -31,9 +31,12 @@
 namespace {
 
 constexpr int CHUNK = 256;
-constexpr int LIST_STRIDE = CHUNK + 8;       // u16 slots per row list: entries + pipeline pads
 constexpr uint32_t ENTRY_BYTES = 48;
-constexpr uint32_t SENT_OFF = CHUNK * ENTRY_BYTES;  // byte offset of the sentinel entry sE[CHUNK]
+// K6 (round 4): eight sub-row lists of BYTES per wave -- a list element is the slot of a staged entry, 0..254, and
+// slot 255 is the sentinel, so a chunk holds at most 255 entries (GCR_PIECE_MAX)
+constexpr int K6_SENT_SLOT = 255;
+constexpr int K6_LIST_STRIDE = 264;          // bytes per sub-row list: 255 entries + 3 pipeline pads, 8-aligned
+static_assert(GCR_PIECE_MAX <= K6_SENT_SLOT, "a K6 chunk must leave slot 255 to the sentinel");
 constexpr uint32_t NO_ENTRY = 0xFFFFFFFFu;
 
 // One staged list entry: 48 bytes, read by the blend loops as three 16-byte quads at one address.
@@ -75,6 +78,32 @@ GCR_DEV LaneGeom lane_geom(int tid, int tx, int ty) {
 #pragma unroll
   for (int rr = 0; rr < 4; rr++) g.bit[rr] = ((g.w >> 1) * 2 + (rr >> 1)) * 4 + (g.w & 1) * 2 + (rr & 1);
   return g;
+}
+
+// K6's lanes (round 4).  Wave w owns quadrant w like K7's, but cut into EIGHT sub-rows of 8 lanes, each a block of 2
+// (wide) x 4 (high) pixels: sub-row s = columns 2(s&3), 2(s&3)+1 and rows 4(s>>2) .. 4(s>>2)+3 of the quadrant, and its
+// bit in gcr_block_mask_2x4 is (2(w>>1) + (s>>2))*8 + 4(w&1) + (s&3).  A sub-row walks the entries that reach ITS block:
+// with eight lists instead of four the wave's longest list is 7 % (C3) to 12 % (C2) shorter
+// (profiles/r04_row_balance_sim.jsonl: the same lists dealt to the waves by length instead gain 0.2 %).
+struct LaneGeom6 {
+  int lane, w, sub, pxi, pyi;
+};
+GCR_DEV LaneGeom6 lane_geom6(int tid, int tx, int ty) {
+  LaneGeom6 g;
+  g.lane = tid & 63;
+  g.w = tid >> 6;
+  g.sub = g.lane >> 3;
+  const int li = g.lane & 7;
+  g.pxi = tx * GCR_TILE_X + (g.w & 1) * 8 + (g.sub & 3) * 2 + (li & 1);
+  g.pyi = ty * GCR_TILE_Y + (g.w >> 1) * 8 + (g.sub >> 2) * 4 + (li >> 1);
+  return g;
+}
+// the thread of K7's geometry (lane_geom) that owns the same pixel: the checkpoints are stored for the backward
+GCR_DEV uint32_t lane6_to_k7_thread(uint32_t tid) {
+  const uint32_t lane = tid & 63u, sub = lane >> 3, li = lane & 7u;
+  const uint32_t row4 = (sub >> 2) * 2u + ((sub & 3u) >> 1);
+  const uint32_t li4 = (li >> 1) * 4u + (sub & 1u) * 2u + (li & 1u);
+  return (tid & ~63u) + row4 * 16u + li4;
 }
 
 // Output window (gcr_camera.win_*): where pixel (px, py) of the frame lands in out_color / dL_dpix, or -1.  The
@@ -214,9 +243,9 @@ __device__ __noinline__ void k6_frame_gate(unsigned long long* words, unsigned i
 // frame regenerates the state with one more pass of this kernel (a.out_color == nullptr: no pixel is stored).
 template <bool FAST_EXP, bool SORT, bool STATE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_blend_fwd(const GcrBlendArgs a) {
-  __shared__ StagedEntry sE[CHUNK + 1];
+  __shared__ StagedEntry sE[K6_SENT_SLOT + 1];
   __shared__ uint32_t sMask[CHUNK];
-  __shared__ uint16_t sList[4][4][LIST_STRIDE];  // [wave][row]: byte offsets into sE, list order
+  __shared__ __attribute__((aligned(16))) uint8_t sList[4][8][K6_LIST_STRIDE];  // [wave][sub-row]: slots of sE, list order
 
   if (a.frame != nullptr && a.frame[2] == 0ull) {  // speculative launch vetoed
     if (a.gate_words != nullptr && blockIdx.x == 0 && threadIdx.x == 0) k6_frame_gate(a.gate_words, a.gate_seq, a.gate_polls);
@@ -244,15 +273,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   }
   const int total = (int)(r1 - r0);
   const char* const sEb = reinterpret_cast<const char*>(sE);
-  if (tid == 0) {
-    sE[CHUNK].a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    sE[CHUNK].b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    sE[CHUNK].c = make_float4(0.0f, __builtin_inff(), 0.0f, 0.0f);
+#ifdef GCR_EXPERIMENTS  // tools/k6_clocks.py: when every workgroup ran, and where
+  if (a.clock_buf != nullptr && tid == 0) {
+    unsigned long long* o = a.clock_buf + (size_t)tile * 16;
+    o[0] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    o[1] = __builtin_readcyclecounter();
+    o[3] = (unsigned long long)total;  // (needs the ranges: the store waits for them)
+    o[10] = __builtin_readcyclecounter();
   }
+#endif
+  if (tid == 0) {  // the sentinel: behind everything that borrows the record buffer (sort keys: 2 KB, lazy sort: 10 KB)
+    sE[K6_SENT_SLOT].a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    sE[K6_SENT_SLOT].b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    sE[K6_SENT_SLOT].c = make_float4(0.0f, __builtin_inff(), 0.0f, 0.0f);
+  }
+  static_assert(gcr_lazy_lds_keys(GCR_LAZY_CAP_K6) * 8 <= K6_SENT_SLOT * (int)ENTRY_BYTES, "the lazy sort's scratch must end below the sentinel");
 
   float Tw;
   {
-    const LaneGeom g0 = lane_geom(tid, tx, ty);
+    const LaneGeom6 g0 = lane_geom6(tid, tx, ty);
     Tw = (g0.pxi < a.W && g0.pyi < a.H) ? 1.0f : -1.0f;
   }
   float C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
@@ -271,7 +310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   if (SORT && total > 0) {
     const uint64_t* __restrict__ seg = a.pairs + r0;
     uint32_t* __restrict__ out = a.list_out + r0;
-    if (total <= CHUNK) {
+    if (total <= K6_SENT_SLOT) {
       // keys into LDS (aliasing the record buffer, which is not live yet), padded with ~0 to a multiple of 2
       uint64_t* sKey = reinterpret_cast<uint64_t*>(sE);
       const uint64_t mine = tid < total ? seg[tid] : ~0ull;
@@ -348,10 +387,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   }
   int tid_op = threadIdx.x;
   asm volatile("" : "+v"(tid_op));
-  const LaneGeom g = lane_geom(tid_op, tx, ty);
-  const int lane = g.lane, w = g.w;
+  const LaneGeom6 g = lane_geom6(tid_op, tx, ty);
+  const int lane = g.lane;
   const float pixx = (float)g.pxi, pixy = (float)g.pyi;
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  // wave-uniform by construction: this wave's lists and the place of its eight bits in a 2x4 block mask
+  const int w_u = __builtin_amdgcn_readfirstlane(g.w);
+  const int mask_sh = (w_u >> 1) * 16 + (w_u & 1) * 4;
+  uint8_t* const lw = &sList[w_u][0][0];
   for (; base < total; base += cs) {
     // block-wide vote (cr/forward.cu:284-286); also fences the previous chunk's LDS reads
     if (__syncthreads_count(!(Tw > 0.0f)) == 256) {
@@ -366,69 +408,102 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
       // does not sit in registers across the walk: 76 -> 71 VGPRs, seven waves per SIMD again)
       uint32_t t_op = threadIdx.x;
       asm volatile("" : "+v"(t_op));
-      a.ckpt[(size_t)(sbase + entered - 1u) * 256u + t_op] = make_float4(__builtin_fabsf(Tw), C0, C1, C2);
+      a.ckpt[(size_t)(sbase + entered - 1u) * 256u + lane6_to_k7_thread(t_op)] = make_float4(__builtin_fabsf(Tw), C0, C1, C2);
     }
     entered++;
     const int n = min(cs, total - base);
     uint32_t my_mask = 0;
     if (tid < n) {
       const uint32_t id = !SORT ? a.list[r0 + base + tid]
-                                : ((total <= CHUNK && cs == total) ? sorted_id : a.list_out[r0 + base + tid]);
+                                : ((total <= K6_SENT_SLOT && cs == total) ? sorted_id : a.list_out[r0 + base + tid]);
       const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
+#ifdef GCR_EXPERIMENTS  // hop clocks of thread 0's first entry: ids arrived (the address below needs them) / records arrived
+      if (a.clock_buf != nullptr && tid == 0 && base == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.clock_buf[(size_t)tile * 16 + 8] = __builtin_readcyclecounter();
+      }
+#endif
       const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+#ifdef GCR_EXPERIMENTS
+      if (a.clock_buf != nullptr && tid == 0 && base == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.clock_buf[(size_t)tile * 16 + 9] = __builtin_readcyclecounter();
+      }
+#endif
       const float pmin = gcr_alpha_skip_bound(q1.y);
-      my_mask = gcr_block_mask(q0.x, q0.y, q0.z, q0.w, q1.x, pmin, tile_x0, tile_y0);
+      my_mask = gcr_block_mask_2x4(q0.x, q0.y, q0.z, q0.w, q1.x, pmin, tile_x0, tile_y0);
       sE[tid].a = make_float4(q0.x, q0.y, -0.5f * q0.z, -q0.w);
       sE[tid].b = make_float4(-0.5f * q1.x, q1.y, q1.z, q1.w);
       sE[tid].c = make_float4(q2.x, pmin, 0.0f, 0.0f);
     }
     sMask[tid] = my_mask;
-    if (STATE && tid < n && a.mask_out != nullptr) a.mask_out[r0 + base + tid] = (uint16_t)my_mask;  // reused by the backward
+    if (STATE && tid < n && a.mask_out != nullptr)  // reused by the backward, whose rows are 4x4 blocks
+      a.mask_out[r0 + base + tid] = (uint16_t)gcr_block_mask_4x4_of_2x4(my_mask);
     __syncthreads();
+#ifdef GCR_EXPERIMENTS  // first chunk, wave 0: records staged / lists built / walk done
+    if (a.clock_buf != nullptr && tid == 0 && base == 0) a.clock_buf[(size_t)tile * 16 + 4] = __builtin_readcyclecounter();
+#endif
     if (__ballot(Tw > 0.0f) == 0ull) continue;  // this wave's quadrant is finished; keep voting
-    // compact the chunk into this wave's four row lists (ascending list order is preserved)
-    int cnt[4] = {0, 0, 0, 0};
+    // Every list starts as sentinels (shorter lists run on them up to the longest one, and the software pipeline below
+    // reads three slots ahead): 8 x 264 bytes = 132 quads, stored before the entries below (the LDS keeps a wave's order)
+    {
+      uint4* const f = reinterpret_cast<uint4*>(lw);
+      const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
+      f[lane] = ff;
+      f[64 + lane] = ff;
+      if (lane < 8 * K6_LIST_STRIDE / 16 - 128) f[128 + lane] = ff;
+    }
+    // compact the chunk into this wave's eight sub-row lists (ascending list order is preserved)
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (k * 64 < n) {  // wave-uniform
         const int jj = k * 64 + lane;
-        const uint32_t m = sMask[jj];
+        const uint32_t m = sMask[jj] >> mask_sh;  // bits 0..3: the upper band's four blocks, bits 8..11: the lower band's
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const bool rel = (m >> g.bit[rr]) & 1u;
+        for (int s = 0; s < 8; s++) {
+          uint32_t bit = m & (1u << (s < 4 ? s : s + 4));
+          asm volatile("" : "+v"(bit));  // (one compare for the ballot and the store's predicate, not two)
+          const bool rel = bit != 0u;
           const uint64_t bal = __ballot(rel);
-          if (rel) sList[w][rr][cnt[rr] + __popcll(bal & lt_mask)] = (uint16_t)(jj * (int)ENTRY_BYTES);
-          cnt[rr] += __popcll(bal);
+          const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          if (rel) lw[s * K6_LIST_STRIDE + cnt[s] + (int)before] = (uint8_t)jj;
+          cnt[s] += __popcll(bal);
         }
       }
     }
-    const int maxcnt = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
-    // shorter lists are padded with the sentinel up to the longest one, plus three slots the
-    // software pipeline below reads ahead (never consumed)
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++)
-      for (int s = cnt[rr] + lane; s < maxcnt + 3; s += 64) sList[w][rr][s] = (uint16_t)SENT_OFF;
+    const int maxcnt = __builtin_amdgcn_readfirstlane(
+        max(max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3])), max(max(cnt[4], cnt[5]), max(cnt[6], cnt[7]))));
     __builtin_amdgcn_wave_barrier();
+#ifdef GCR_EXPERIMENTS
+    if (a.clock_buf != nullptr && tid == 0 && base == 0) {
+      a.clock_buf[(size_t)tile * 16 + 5] = __builtin_readcyclecounter();
+      a.clock_buf[(size_t)tile * 16 + 7] = (unsigned long long)maxcnt;
+    }
+#endif
     // Software pipeline, two entries per trip with ping-pong registers: while entry i blends,
     // the record of entry i+1 and the list slot of entry i+2 are already in flight.
-    const uint16_t* lp = &sList[w][g.row][0];
+    const uint8_t* lp = &sList[w_u][g.sub][0];
     float4 qa0, qb0, qa1, qb1;
     float2 qc0, qc1;
-    uint32_t e0 = lp[0], e1 = lp[1];
+    uint32_t e0 = (uint32_t)lp[0] * ENTRY_BYTES, e1 = (uint32_t)lp[1] * ENTRY_BYTES;
     uint32_t last_off = NO_ENTRY;
     GCR_BLEND_LOAD(qa0, qb0, qc0, e0)
     for (int i = 0; i < maxcnt; i += 2, lp += 2) {
       GCR_BLEND_LOAD(qa1, qb1, qc1, e1)
       const uint32_t cur0 = e0;
-      e0 = lp[2];
+      e0 = (uint32_t)lp[2] * ENTRY_BYTES;
       GCR_BLEND_STEP(qa0, qb0, qc0, cur0)
       if (i + 1 >= maxcnt) break;
       GCR_BLEND_LOAD(qa0, qb0, qc0, e0)
       const uint32_t cur1 = e1;
-      e1 = lp[3];
+      e1 = (uint32_t)lp[3] * ENTRY_BYTES;
       GCR_BLEND_STEP(qa1, qb1, qc1, cur1)
       if (__ballot(Tw > 0.0f) == 0ull) break;  // every pixel of the wave is done
     }
+#ifdef GCR_EXPERIMENTS
+    if (a.clock_buf != nullptr && tid == 0 && base == 0) a.clock_buf[(size_t)tile * 16 + 6] = __builtin_readcyclecounter();
+#endif
     if (last_off != NO_ENTRY) last_contributor = (uint32_t)base + slot_of_offset(last_off) + 1u;
   }
   }
@@ -436,7 +511,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 #undef GCR_BLEND_LOAD
   int tid_end = threadIdx.x;
   asm volatile("" : "+v"(tid_end));
-  const LaneGeom g = lane_geom(tid_end, tx, ty);
+  const LaneGeom6 g = lane_geom6(tid_end, tx, ty);
   if (g.pxi < a.W && g.pyi < a.H && (!STATE || a.out_color != nullptr)) {  // (state-only pass: pixels already stored)
     const float Tout = __builtin_fabsf(Tw);
     const size_t pix_id = (size_t)a.W * g.pyi + g.pxi;
@@ -464,11 +539,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
       }
     }
   }
+#ifdef GCR_EXPERIMENTS
+  if (a.clock_buf != nullptr && tid == 0) a.clock_buf[(size_t)tile * 16 + 2] = __builtin_readcyclecounter();
+#endif
   if (STATE && a.work != nullptr) {
     // a tile that crossed a boundary also leaves its final colour (without background) in its last slot: a
     // backward piece that starts from a checkpoint needs C_final - C_prefix
     if (entered >= 2u)
-      a.ckpt[(size_t)(sbase + gcr_piece_count((uint32_t)total, piece_P) - 1u) * 256u + tid] =
+      a.ckpt[(size_t)(sbase + gcr_piece_count((uint32_t)total, piece_P) - 1u) * 256u + lane6_to_k7_thread((uint32_t)tid)] =
           make_float4(__builtin_fabsf(Tw), C0, C1, C2);
     // work items of the backward blend, one per slot of [slot_base(tile), slot_base(tile + 1)): the pieces this
     // workgroup walked into carry {tile, list start, list length, piece}; the others (behind a saturated tile's last

@@ -39,14 +39,18 @@
 
 #define GCR_CULL_EPS 0.01f  // pixels
 
-GCR_CULL_FN uint32_t gcr_block_mask(float gx, float gy, float cx, float cy, float cz, float pmin,
-                                    float tile_x0, float tile_y0) {
+// BW = width of a block in pixels (4: sixteen 4x4 blocks, bit by*4+bx; 2: thirty-two 2x4 blocks, bit by*8+bx); a
+// constant at every call site.
+GCR_CULL_FN uint32_t gcr_block_mask_bw(float gx, float gy, float cx, float cy, float cz, float pmin,
+                                       float tile_x0, float tile_y0, const int BW) {
 // Nothing here is part of the numerics contract (the result only has to be conservative, and the margins cover
 // a fused multiply-add's single rounding many times over): let the compiler contract, ~30 fewer VALU per entry.
 #pragma clang fp contract(fast)
+  const int NBX = 16 / BW;
+  const uint32_t ALL = BW == 4 ? 0xFFFFu : 0xFFFFFFFFu;
   if (!(pmin < 0.0f)) return 0u;  // alpha < 1/255 everywhere (power <= 0 always)
   const float det = cx * cz - cy * cy;
-  if (!(det > 0.0f) || !(cx > 0.0f) || !(cz > 0.0f)) return 0xFFFFu;
+  if (!(det > 0.0f) || !(cx > 0.0f) || !(cz > 0.0f)) return ALL;
   // centre relative to the tile origin; largest |dx|, |dy| any pixel of the tile sees
   const float rx = gx - tile_x0, ry = gy - tile_y0;
   const float ux = __builtin_fmaxf(__builtin_fabsf(rx), __builtin_fabsf(rx - 15.0f));
@@ -58,7 +62,7 @@ GCR_CULL_FN uint32_t gcr_block_mask(float gx, float gy, float cx, float cy, floa
   const float idet = GCR_CULL_RCP(det);
   const float ex = GCR_CULL_SQRT(t2 * cz * idet) * 1.0001f;  // half-extents of E
   const float ey = GCR_CULL_SQRT(t2 * cx * idet) * 1.0001f;
-  if (!(ex == ex) || !(ey == ey)) return 0xFFFFu;
+  if (!(ex == ex) || !(ey == ey)) return ALL;
   const float icx = GCR_CULL_RCP(cx);
   const float vr = -cy * ex * GCR_CULL_RCP(cz);  // v at which u is extremal (right: vr, left: -vr)
   const float k0 = t2 * cx * 1.0002f;            // discriminant 2 tau cx - det v^2, a hair generous
@@ -75,15 +79,33 @@ GCR_CULL_FN uint32_t gcr_block_mask(float gx, float gy, float cx, float cy, floa
     const float sl = GCR_CULL_SQRT(__builtin_fmaxf(k0 - det * vl * vl, 0.0f));
     const float u_hi = (sh - cy * vh) * icx;
     const float u_lo = (-sl - cy * vl) * icx;
-    // block bx covers centres [4bx, 4bx+3] (tile-relative): hit iff 4bx+3+eps >= lo and 4bx-eps <= hi
-    const float lo = u_lo + rx - (3.0f + GCR_CULL_EPS) - 1.0e-4f * __builtin_fabsf(u_lo);
+    // block bx covers centres [BW bx, BW bx + BW-1] (tile-relative): hit iff BW bx + BW-1 + eps >= lo and BW bx - eps <= hi
+    const float lo = u_lo + rx - ((float)(BW - 1) + GCR_CULL_EPS) - 1.0e-4f * __builtin_fabsf(u_lo);
     const float hi = u_hi + rx + GCR_CULL_EPS + 1.0e-4f * __builtin_fabsf(u_hi);
-    // fmax/fmin return the non-NaN operand: an unbounded row keeps all four blocks
-    const float flo = __builtin_fminf(__builtin_fmaxf(__builtin_ceilf(lo * 0.25f), 0.0f), 4.0f);
-    const float fhi = __builtin_fmaxf(__builtin_fminf(__builtin_floorf(hi * 0.25f), 3.0f), -1.0f);
-    const int ilo = (int)flo, ihi = (int)fhi;  // 0..4, -1..3
-    const uint32_t row = (a <= b && ilo <= ihi) ? ((2u << (ihi & 3)) - (1u << (ilo & 3))) : 0u;
-    mask |= row << (4 * by);
+    // fmax/fmin return the non-NaN operand: an unbounded row keeps all its blocks
+    const float inv = 1.0f / (float)BW;
+    const float flo = __builtin_fminf(__builtin_fmaxf(__builtin_ceilf(lo * inv), 0.0f), (float)NBX);
+    const float fhi = __builtin_fmaxf(__builtin_fminf(__builtin_floorf(hi * inv), (float)(NBX - 1)), -1.0f);
+    const int ilo = (int)flo, ihi = (int)fhi;  // 0..NBX, -1..NBX-1
+    const uint32_t row = (a <= b && ilo <= ihi) ? ((2u << (ihi & (NBX - 1))) - (1u << (ilo & (NBX - 1)))) : 0u;
+    mask |= row << (NBX * by);
   }
   return mask;
+}
+// the sixteen 4x4 blocks (K7's rows)
+GCR_CULL_FN uint32_t gcr_block_mask(float gx, float gy, float cx, float cy, float cz, float pmin,
+                                    float tile_x0, float tile_y0) {
+  return gcr_block_mask_bw(gx, gy, cx, cy, cz, pmin, tile_x0, tile_y0, 4);
+}
+// the thirty-two blocks of 2 (wide) x 4 (high) pixels (K6's sub-rows): bit by*8 + bx2
+GCR_CULL_FN uint32_t gcr_block_mask_2x4(float gx, float gy, float cx, float cy, float cz, float pmin,
+                                        float tile_x0, float tile_y0) {
+  return gcr_block_mask_bw(gx, gy, cx, cy, cz, pmin, tile_x0, tile_y0, 2);
+}
+// the 4x4 mask a 2x4 mask implies (a 4x4 block = two neighbouring 2x4 blocks): conservative like its argument
+GCR_CULL_FN uint32_t gcr_block_mask_4x4_of_2x4(uint32_t m) {
+  uint32_t t = (m | (m >> 1)) & 0x55555555u;  // bit 2k of every byte: column pair k
+  t = (t | (t >> 1)) & 0x33333333u;
+  t = (t | (t >> 2)) & 0x0F0F0F0Fu;           // one nibble per band, in the low half of its byte
+  return (t & 0xFu) | ((t >> 4) & 0xF0u) | ((t >> 8) & 0xF00u) | ((t >> 12) & 0xF000u);
 }

@@ -1,6 +1,7 @@
 // Brute-force check of gcr_block_mask (gaussiancity_amd/csrc/gcr_cull.h) on the host: for random ellipses, every
 // 4x4 block that contains a pixel the blend loop would evaluate (power in [pmin, 0], computed in fp32 exactly as
-// gcr_power does) must have its bit set.  Prints: cases, violations, set bits, needed bits.
+// gcr_power does) must have its bit set.  Prints: cases, violations, set bits, needed bits.  Second argument 2: the
+// thirty-two 2x4 blocks of K6's sub-rows (gcr_block_mask_2x4) instead, and the 4x4 mask derived from them.
 //   gcc -O2 -ffp-contract=off -I gaussiancity_amd/csrc tests/cull_mask_check.c -lm
 #include <math.h>
 #include <stdio.h>
@@ -18,6 +19,7 @@ static float power_fp32(float cx, float cy, float cz, float dx, float dy) {
 
 int main(int argc, char** argv) {
   const long n = argc > 1 ? atol(argv[1]) : 200000;
+  const int bw = argc > 2 ? atoi(argv[2]) : 4;
   long violations = 0, set_bits = 0, needed_bits = 0, allmask = 0;
   for (long it = 0; it < n; it++) {
     const int mode = it % 4;
@@ -39,19 +41,32 @@ int main(int argc, char** argv) {
     double reach = 3.4 * sqrt(a > d ? a : d) + 20.0;
     float gx = tile_x0 + 8.0f + (float)((urand() * 2 - 1) * reach), gy = tile_y0 + 8.0f + (float)((urand() * 2 - 1) * reach);
     if (it % 17 == 0) { gx = floorf(gx); gy = floorf(gy) + 0.5f; }
-    uint32_t m = gcr_block_mask(gx, gy, cx, cy, cz, pmin, tile_x0, tile_y0);
-    if (m == 0xFFFFu) allmask++;
+    uint32_t m = bw == 4 ? gcr_block_mask(gx, gy, cx, cy, cz, pmin, tile_x0, tile_y0)
+                         : gcr_block_mask_2x4(gx, gy, cx, cy, cz, pmin, tile_x0, tile_y0);
+    if (m == (bw == 4 ? 0xFFFFu : 0xFFFFFFFFu)) allmask++;
+    uint32_t need16 = 0;
     uint32_t need = 0;
     for (int y = 0; y < 16; y++)
       for (int x = 0; x < 16; x++) {
         float dx = gx - (tile_x0 + x), dy = gy - (tile_y0 + y);
         float pw = power_fp32(cx, cy, cz, dx, dy);
-        if (!(pw > 0.0f) && !(pw < pmin)) need |= 1u << ((y >> 2) * 4 + (x >> 2));
+        if (!(pw > 0.0f) && !(pw < pmin)) {
+          need |= bw == 4 ? 1u << ((y >> 2) * 4 + (x >> 2)) : 1u << ((y >> 2) * 8 + (x >> 1));
+          need16 |= 1u << ((y >> 2) * 4 + (x >> 2));
+        }
       }
+    if (bw != 4) {
+      // the derived 4x4 mask: conservative, and never more than the direct one
+      const uint32_t d = gcr_block_mask_4x4_of_2x4(m);
+      if ((need16 & ~d) || (d & ~gcr_block_mask(gx, gy, cx, cy, cz, pmin, tile_x0, tile_y0))) {
+        violations++;
+        if (violations <= 5) fprintf(stderr, "VIOLATION (derived 4x4) mask2x4=%08x derived=%04x need=%04x\n", m, d, need16);
+      }
+    }
     if (need & ~m) {
       violations++;
       if (violations <= 5)
-        fprintf(stderr, "VIOLATION g=(%g,%g) conic=(%g,%g,%g) pmin=%g tile=(%g,%g) mask=%04x need=%04x\n", gx, gy, cx, cy, cz,
+        fprintf(stderr, "VIOLATION g=(%g,%g) conic=(%g,%g,%g) pmin=%g tile=(%g,%g) mask=%08x need=%08x\n", gx, gy, cx, cy, cz,
                 pmin, tile_x0, tile_y0, m, need);
     }
     set_bits += __builtin_popcount(m);

@@ -21,3 +21,7 @@ def test_block_mask_is_conservative_and_tight():
         r = json.loads(subprocess.check_output([exe, "1500000"]).decode())
         assert r["violations"] == 0, (flags, r)
         assert r["needed_bits"] > 1000000 and r["set_bits"] <= 1.02 * r["needed_bits"], (flags, r)
+        # K6's thirty-two 2x4 blocks (and the 4x4 mask derived from them for the backward)
+        r = json.loads(subprocess.check_output([exe, "1500000", "2"]).decode())
+        assert r["violations"] == 0, (flags, r)
+        assert r["needed_bits"] > 2000000 and r["set_bits"] <= 1.03 * r["needed_bits"], (flags, r)
