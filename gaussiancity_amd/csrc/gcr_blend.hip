@@ -985,10 +985,14 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
 
 template <bool FAST_EXP, bool SORT>
 static void launch_blend_fwd_state(const GcrBlendArgs& a, int T, hipStream_t s) {
+  size_t pad = 0;
+#ifdef GCR_EXPERIMENTS  // unused dynamic LDS: fewer blend workgroups per CU (7 by default), room for another frame's kernels
+  if (const char* e = getenv("GCR_K6_LDS_PAD")) pad = (size_t)atoll(e);
+#endif
   if (a.work != nullptr)  // the backward's state is wanted (gcr_camera.backward == 1, or gcr_backward's regeneration pass)
-    k_blend_fwd<FAST_EXP, SORT, true><<<T, 256, 0, s>>>(a);
+    k_blend_fwd<FAST_EXP, SORT, true><<<T, 256, pad, s>>>(a);
   else
-    k_blend_fwd<FAST_EXP, SORT, false><<<T, 256, 0, s>>>(a);
+    k_blend_fwd<FAST_EXP, SORT, false><<<T, 256, pad, s>>>(a);
 }
 
 hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool fast_exp, bool sort_in_kernel, hipStream_t s) {
