@@ -32,10 +32,13 @@ namespace {
 
 constexpr int CHUNK = 256;
 constexpr uint32_t ENTRY_BYTES = 48;
-// K6 (round 4): eight sub-row lists of BYTES per wave -- a list element is the slot of a staged entry, 0..254, and
-// slot 255 is the sentinel, so a chunk holds at most 255 entries (GCR_PIECE_MAX)
-constexpr int K6_SENT_SLOT = 255;
-constexpr int K6_LIST_STRIDE = 264;          // bytes per sub-row list: 255 entries + 3 pipeline pads, 8-aligned
+// K6 (round 4): eight sub-row lists of BYTES per wave -- a list element is the slot of a staged entry, 0..222, and
+// slot 223 is the sentinel, so a chunk holds at most 223 entries (GCR_PIECE_MAX).  223, not 255: with 224 record slots
+// and 232-byte lists the workgroup's LDS is 19 456 bytes, EIGHT workgroups per CU instead of seven -- and the kernel
+// (which needs 64 VGPRs for that, and gets them: the walk was never what held 72) is as long as its occupancy lets it be
+// short: 129 / 108 / 103 us at 5 / 6 / 7 workgroups per CU (profiles/r04_k6_occupancy_cap_experiment.jsonl).
+constexpr int K6_SENT_SLOT = 223;
+constexpr int K6_LIST_STRIDE = 232;          // bytes per sub-row list: 223 entries + 3 pipeline pads, 8-aligned
 static_assert(GCR_PIECE_MAX <= K6_SENT_SLOT, "a K6 chunk must leave slot 255 to the sentinel");
 constexpr uint32_t NO_ENTRY = 0xFFFFFFFFu;
 
@@ -233,16 +236,17 @@ __device__ __noinline__ void k6_frame_gate(unsigned long long* words, unsigned i
   gcr_store_to_host(words + 4, (unsigned long long)seq);
 }
 
-// amdgpu_waves_per_eu(7, 8): the call above constrains the register assignment (what lives across it must sit in
-// callee-saved registers) and the allocator, left alone, ends at 78 VGPRs = six waves per SIMD; told to fit seven, it
-// finds a 71-register assignment without a spill and with the blend steps unchanged instruction for instruction.
+// amdgpu_waves_per_eu(8, 8): the call above constrains the register assignment (what lives across it must sit in
+// callee-saved registers) and the allocator, left alone, ends at 78 VGPRs = six waves per SIMD; told to fit eight (which
+// the workgroup's LDS allows since the chunk is 223 entries), it finds a 64-register assignment without a spill and with
+// the blend steps unchanged instruction for instruction (the walk uses 61; staging and list building held the rest).
 //
 // STATE (template): the backward's per-piece state -- checkpoints at the piece boundaries, work items, the block mask
 // of every staged entry -- is written only by frames rendered with gcr_camera.backward == 1.  Every other frame (the
 // headline inference workload) runs the instantiation without a single instruction of it; gcr_backward on such a
 // frame regenerates the state with one more pass of this kernel (a.out_color == nullptr: no pixel is stored).
 template <bool FAST_EXP, bool SORT, bool STATE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_blend_fwd(const GcrBlendArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blend_fwd(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[K6_SENT_SLOT + 1];
   __shared__ uint32_t sMask[CHUNK];
   __shared__ __attribute__((aligned(16))) uint8_t sList[4][8][K6_LIST_STRIDE];  // [wave][sub-row]: slots of sE, list order
@@ -445,13 +449,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 #endif
     if (__ballot(Tw > 0.0f) == 0ull) continue;  // this wave's quadrant is finished; keep voting
     // Every list starts as sentinels (shorter lists run on them up to the longest one, and the software pipeline below
-    // reads three slots ahead): 8 x 264 bytes = 132 quads, stored before the entries below (the LDS keeps a wave's order)
+    // reads three slots ahead): 8 x 232 bytes = 116 quads, stored before the entries below (the LDS keeps a wave's order)
     {
+      constexpr int NQ = 8 * K6_LIST_STRIDE / 16;  // quads of this wave's eight lists
+      static_assert(8 * K6_LIST_STRIDE % 16 == 0 && NQ > 64 && NQ <= 128, "list fill: two stores per lane");
       uint4* const f = reinterpret_cast<uint4*>(lw);
-      const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
+      const uint32_t sb = 0x01010101u * (uint32_t)K6_SENT_SLOT;
+      const uint4 ff = make_uint4(sb, sb, sb, sb);
       f[lane] = ff;
-      f[64 + lane] = ff;
-      if (lane < 8 * K6_LIST_STRIDE / 16 - 128) f[128 + lane] = ff;
+      if (64 + lane < NQ) f[64 + lane] = ff;
     }
     // compact the chunk into this wave's eight sub-row lists (ascending list order is preserved)
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};

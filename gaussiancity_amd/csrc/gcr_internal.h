@@ -123,7 +123,7 @@ struct GcrFillArgs {
 // forward walked into that piece, {GCR_NO_TILE} otherwise (a saturated tile's remaining pieces, the gap slot between two
 // tiles); the backward launches one wave per (slot, quadrant).
 #define GCR_PIECE_MIN 64
-#define GCR_PIECE_MAX 255  // (K6 keeps list slots in bytes; slot 255 is its sentinel)
+#define GCR_PIECE_MAX 223  // (K6 keeps list slots in bytes, slot 223 is its sentinel: 8 workgroups per CU, gcr_blend.hip)
 #define GCR_NO_TILE 0xFFFFFFFFu
 #define GCR_CKPT_BYTES 4096  // 256 pixels x float4
 static inline __host__ __device__ uint32_t gcr_piece_count(uint32_t len, uint32_t P) { return (len + P - 1u) / P; }
