@@ -738,7 +738,12 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
 
 
 template <bool FAST_EXP>
-__global__ __launch_bounds__(64) void k_blend_bwd(const GcrBlendArgs a) {
+#ifdef GCR_K7_WAVES_PER_EU  /* A/B builds: ask for that many waves per SIMD (4 = what 118-120 VGPRs give) */
+#define GCR_K7_OCC __attribute__((amdgpu_waves_per_eu(GCR_K7_WAVES_PER_EU, 8)))
+#else
+#define GCR_K7_OCC
+#endif
+__global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[WPASS + 1];
   __shared__ uint32_t sId[WPASS];
   __shared__ uint16_t sList[4][WLIST_STRIDE];
