@@ -960,12 +960,17 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
               if (!GCR_FLUSH_ON) continue;
               if (!a.deterministic) {
                 atomicAdd(&a.grad_rec[(size_t)sId[slot] * GCR_GRAD_REC_FLOATS + rec_idx], v);
-              } else {  // Q31.32, order-independent (gcr_internal.h); saturating conversion
-                const float sc = v * (float)GCR_DET_SCALE;  // exact: a power of two
+              } else {  // fixed point with the Gaussian's own binary point, order-independent (gcr_internal.h)
+                const uint32_t gid = sId[slot];
+                const float4 q2 = a.rec[(size_t)gid * GCR_REC_QUADS + 2];
+                const int kc = gcr_det_frac_bits(sE[slot].a.x, sE[slot].a.y, __float_as_uint(q2.z), __float_as_uint(q2.w), a.W, a.H, true);
+                const int ko = gcr_det_frac_bits(sE[slot].a.x, sE[slot].a.y, __float_as_uint(q2.z), __float_as_uint(q2.w), a.W, a.H, false);
+                const int kf = (rec_idx >= 6) ? kc : ko;  // record slots 6, 7, 8 = dL_dconic
+                const float sc = __builtin_ldexpf(v, kf);  // exact: a power of two (or +-inf: saturates below)
                 const long long q = sc >= 9.2e18f ? 0x7fffffffffffffffll : (sc <= -9.2e18f ? -0x7fffffffffffffffll : __float2ll_rn(sc));
-                atomicAdd(reinterpret_cast<unsigned long long*>(a.grad_rec) + (size_t)sId[slot] * (GCR_GRAD_REC_FLOATS_DET / 2) +
-                              rec_idx,
-                          (unsigned long long)q);
+                unsigned long long* const r64 = reinterpret_cast<unsigned long long*>(a.grad_rec) + (size_t)gid * (GCR_GRAD_REC_FLOATS_DET / 2);
+                atomicAdd(r64 + rec_idx, (unsigned long long)q);
+                r64[GCR_DET_K_SLOT] = (unsigned long long)(kc + 64) | ((unsigned long long)(ko + 64) << 8);  // (the same from every flush)
               }
             }
           }

@@ -89,13 +89,44 @@ struct GcrPreprocessBwdArgs {
 // memory-side transaction (scattered over four arrays they were 44 % of K7: DESIGN.md section 5).
 // K8 reads the record with three dwordx4 loads and writes the API's dL_dmeans2D / dL_dcolors / dL_dopacity.
 #define GCR_GRAD_REC_FLOATS 16
-// Option "deterministic_backward": the record is nine 64-bit FIXED-POINT sums (same order, Q31.32) in a 128-byte
-// slot instead of nine floats in a 64-byte one.  Integer addition is associative, so the per-Gaussian totals no longer
-// depend on the order in which the tiles' waves reach the memory-side atomic units -- two runs give the same bits
-// (SURVEY.md section 5 asks for such a debug mode; the float atomics of the default path differ in the last bits from
-// run to run, like the reference's).  Resolution 2^-32 = 2.3e-10 per addend, range +-2.1e9.
+// Option "deterministic_backward": the record is nine 64-bit FIXED-POINT sums (same order) in a 128-byte slot instead
+// of nine floats in a 64-byte one.  Integer addition is associative, so the per-Gaussian totals no longer depend on the
+// order in which the tiles' waves reach the memory-side atomic units -- two runs give the same bits (SURVEY.md section
+// 5 asks for such a debug mode; the float atomics of the default path differ in the last bits from run to run, like the
+// reference's).
+// The binary point is PER GAUSSIAN (round 4; a fixed Q31.32 before): the sums of a Gaussian that covers many pixels far
+// from its centre are large -- dL_dconic adds 0.5 d.x^2 dL_dG per pixel, 3.5e9 for a 300-pixel footprint, beyond Q31.32
+// (found by tools/fuzz_parity.py, seed 41 case 635: gradients wrong by 15 x max, silently) -- while a small Gaussian's
+// need the fine end.  k = fractional bits, a function of the Gaussian's projected record and the image size alone, one
+// for the three conic sums and one for the other six (a conic-sized range would cost the dL_dmean2D sums, which the
+// projection multiplies by focal / depth afterwards, their precision: 0.27 on a dL_dmean3D of 12 in the same case):
+//     B_conic = pixels of its tile rectangle * max(squared distance centre -> farthest rectangle corner, 8 max(W, H)) * 64
+//     B_other = pixels of its tile rectangle * 8 max(W, H) * 64
+//     k = clamp(61 - (floor(log2 B) + 1), -16, 32)
+// (the sums are bounded by pixels * {d^2 | W, 1} * |dL_dG|: B leaves |dL_dG| up to 64 per pixel before a sum can wrap;
+// an addend beyond the range still saturates).  The blend gradient kernel computes both when it flushes and leaves
+// (k_conic + 64) | (k_other + 64) << 8 in the record's last slot (every flush of a Gaussian stores the same value); the
+// preprocess gradient kernel reads them.
 #define GCR_GRAD_REC_FLOATS_DET 32
-#define GCR_DET_SCALE 4294967296.0  // 2^32
+#define GCR_DET_K_SLOT 15   // 64-bit slot of the record that holds k + 64 (0 = never flushed: all sums are zero)
+static inline __host__ __device__ int gcr_det_frac_bits(float x, float y, uint32_t rect_x, uint32_t rect_y, int W, int H,
+                                                        bool conic) {
+  const float minx = 16.0f * (float)(rect_x & 0xffffu), maxx = 16.0f * (float)(rect_x >> 16);
+  const float miny = 16.0f * (float)(rect_y & 0xffffu), maxy = 16.0f * (float)(rect_y >> 16);
+  const float npix = (maxx - minx) * (maxy - miny);
+  const float ax = x - minx, bx = x - maxx, ay = y - miny, by = y - maxy;
+  const float dx2 = ax * ax > bx * bx ? ax * ax : bx * bx, dy2 = ay * ay > by * by ? ay * ay : by * by;
+  const float wh = 8.0f * (float)(W > H ? W : H);
+  float d2 = conic ? dx2 + dy2 : wh;
+  d2 = d2 > wh ? d2 : wh;  // (a NaN centre compares false: wh)
+  float B = npix * d2 * 64.0f;
+  B = B > 1.0f ? B : 1.0f;
+  union { float f; uint32_t u; } c;
+  c.f = B;
+  const int e = (int)((c.u >> 23) & 0xffu) - 127 + 1;  // > log2 B (255 - 126 for inf / NaN: the coarse end)
+  const int k = 61 - e;
+  return k > 32 ? 32 : (k < -16 ? -16 : k);
+}
 
 // The dense zero fill of the backward's outputs (every Gaussian K8 does not visit keeps gradient 0): up to eight
 // float arrays, streamed by the first `blocks` workgroups of the K7 launch while its tile workgroups -- which

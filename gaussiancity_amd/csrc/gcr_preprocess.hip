@@ -830,12 +830,15 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
     g0 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 0];
     g1 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 1];
     g2 = a.grad_rec[(size_t)idx * (GCR_GRAD_REC_FLOATS / 4) + 2];
-  } else {  // nine Q31.32 sums (option "deterministic_backward")
+  } else {  // nine fixed-point sums with the Gaussian's own binary point (option "deterministic_backward")
     const long long* __restrict__ r64 =
         reinterpret_cast<const long long*>(a.grad_rec) + (size_t)idx * (GCR_GRAD_REC_FLOATS_DET / 2);
+    const long long kslot = r64[GCR_DET_K_SLOT];
+    const int kc = kslot != 0 ? (int)(kslot & 0xff) - 64 : 32;  // (never flushed: every sum is zero)
+    const int ko = kslot != 0 ? (int)((kslot >> 8) & 0xff) - 64 : 32;
     float f[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) f[k] = (float)((double)r64[k] * (1.0 / GCR_DET_SCALE));
+    for (int k = 0; k < 9; k++) f[k] = (float)__builtin_ldexp((double)r64[k], k >= 6 ? -kc : -ko);
     g0 = make_float4(f[0], f[1], f[2], f[3]);
     g1 = make_float4(f[4], f[5], f[6], f[7]);
     g2 = make_float4(f[8], 0.0f, 0.0f, 0.0f);

@@ -341,7 +341,7 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *   "split_preprocess" 1: K1 as two kernels (streaming cull, then exact pass) instead of   default 0
  *                     the fused one (A/B)
  *   "deterministic_backward" 1: gcr_backward accumulates the per-Gaussian blend gradients as 64-bit       default 0
- *                     fixed-point sums (Q31.32) instead of fp32 atomics: integer addition is associative, so two runs
+ *                     fixed-point sums (binary point per Gaussian) instead of fp32 atomics: integer addition is associative, so two runs
  *                     give bit-identical gradients whatever order the tiles' waves arrive in (a debug mode: fp32
  *                     atomics -- here and in the reference -- differ in the last bits from run to run).
  *                     gcr_grad_record_floats() then returns 32: size gcr_grads.dL_dconic AFTER setting the option.

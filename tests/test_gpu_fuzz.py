@@ -42,3 +42,22 @@ def test_randomised_parity_sweep(oracle_mod, cuda_device):
     assert len(regimes) >= 4
     assert strict >= 20, "only %d cases were held to 1e-4 * max" % strict
     assert not bad, bad[:3]
+
+
+def test_deterministic_records_hold_a_large_footprint(oracle_mod, cuda_device):
+    """Case 635 of `tools/fuzz_parity.py --seed 41` (round 4): scales up to 11 x scale_modifier 1.7, a footprint of
+    hundreds of pixels -- max |dL_dconic| is 3.5e9, beyond the Q31.32 records the deterministic mode had, and the
+    gradients came back wrong by 15 x max without a word.  The records carry a per-Gaussian binary point now
+    (gcr_internal.h gcr_det_frac_bits); the same scene must pass in both modes."""
+    import json
+
+    import fuzz_parity as F
+    import gpu_util as G
+    import scenes
+    from gaussiancity_amd import _native as N
+    here = os.path.dirname(os.path.abspath(__file__))
+    c = json.load(open(os.path.join(here, "golden", "fuzz_case_deterministic_range.json")))
+    assert c["deterministic"] == 1 and c["backward"]
+    assert F.run_case(dict(c), oracle_mod, G, scenes, N, cuda_device) == []
+    assert F.run_case(dict(c, deterministic=0), oracle_mod, G, scenes, N, cuda_device) == []
+    assert F.run_case(dict(c, train_frame=True, piece=128), oracle_mod, G, scenes, N, cuda_device) == []
