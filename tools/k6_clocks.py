@@ -2,6 +2,11 @@
 tail?  Needs the experiment build:  make -C gaussiancity_amd/csrc experiments  (tools/_build/libgcr_hip_exp.so).
 
     python tools/k6_clocks.py [--config C3] [--pose 0]
+
+Reading the numbers: a workgroup's life and the per-CU residency are clock reads only; the phase split of wave 0 puts
+`s_waitcnt vmcnt(0)` in front of the hop clocks, which also waits for the tool's OWN clock stores -- the "ranges -> ids"
+hop (4.3-4.5 us) is an upper bound, and the tile-head experiment (profiles/r04_tile_head_experiment.jsonl: that hop
+removed, nothing gained) says how loose.
 """
 import argparse
 import ctypes as C
