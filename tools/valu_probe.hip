@@ -120,6 +120,38 @@ __global__ __launch_bounds__(256) void k_probe(float* out, int iters, float seed
 #define S(r, q) asm volatile("v_mov_b32_dpp %0, %1 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(r) : "v"(q));
       REP8(S(a0, b0) S(a1, b1) S(a2, b2) S(a3, b3) S(a4, b4) S(a5, b5) S(a6, b6) S(a7, b7))
 #undef S
+    } else if (KIND == 26) {  // v_fmaak_f32: a 32-bit LITERAL addend (the exp polynomial's coefficients)
+#define S(r) asm volatile("v_fmaak_f32 %0, %0, %1, 0x3d2aaa75" : "+v"(r) : "v"(m));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 27) {  // v_fmamk_f32: literal multiplier
+#define S(r) asm volatile("v_fmamk_f32 %0, %0, 0x3f7fbe77, %1" : "+v"(r) : "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 28) {  // v_fmac_f32 with a literal source
+#define S(r) asm volatile("v_fmac_f32 %0, 0x3a83126f, %1" : "+v"(r) : "v"(m));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 29) {  // v_min_f32 with a literal
+#define S(r) asm volatile("v_min_f32 %0, 0x3f7d70a4, %0" : "+v"(r));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 30) {  // v_lshl_add_u32 (VOP3, integer)
+#define S(r) asm volatile("v_lshl_add_u32 %0, %1, 23, %0" : "+v"(r) : "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 31) {  // v_mul_u32_u24 with an inline constant
+#define S(r) asm volatile("v_mul_u32_u24 %0, 48, %0" : "+v"(r));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 32) {  // v_sub_f32 (VOP2, two VGPRs)
+#define S(r) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(r) : "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 33) {  // v_cndmask_b32_e64 with the abs/neg modifiers K6's Tw select uses
+#define S(r) asm volatile("v_cndmask_b32_e64 %0, -|%0|, %1, s[20:21]" : "+v"(r) : "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
     } else if (KIND == 18) {  // v_fma_f32 with two literal-free inline constants (VOP3, 3 VGPR reads vs 2)
 #define S(r) asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(r) : "v"(m));
       REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
@@ -191,6 +223,14 @@ int main(int argc, char** argv) {
   run<23>("v_add_f32_dpp quad_perm", out, blocks, iters, mhz);
   run<24>("v_add_f32_dpp row_shr:4 bank_mask", out, blocks, iters, mhz);
   run<25>("v_mov_b32_dpp row_shl:4 bank_mask", out, blocks, iters, mhz);
+  run<26>("v_fmaak_f32 (literal addend)", out, blocks, iters, mhz);
+  run<27>("v_fmamk_f32 (literal multiplier)", out, blocks, iters, mhz);
+  run<28>("v_fmac_f32 (literal source)", out, blocks, iters, mhz);
+  run<29>("v_min_f32 (literal)", out, blocks, iters, mhz);
+  run<30>("v_lshl_add_u32", out, blocks, iters, mhz);
+  run<31>("v_mul_u32_u24 (inline constant)", out, blocks, iters, mhz);
+  run<32>("v_sub_f32", out, blocks, iters, mhz);
+  run<33>("v_cndmask_b32_e64 (sgpr-pair mask, -|x| modifier)", out, blocks, iters, mhz);
   run<19>("v_cmp_lt_u64 -> vcc", out, blocks, iters, mhz);
   run<20>("v_cmp_lt_u32 -> vcc", out, blocks, iters, mhz);
   run<21>("v_addc_co_u32", out, blocks, iters, mhz);
