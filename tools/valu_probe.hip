@@ -152,6 +152,58 @@ __global__ __launch_bounds__(256) void k_probe(float* out, int iters, float seed
 #define S(r) asm volatile("v_cndmask_b32_e64 %0, -|%0|, %1, s[20:21]" : "+v"(r) : "v"(c));
       REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
 #undef S
+    } else if (KIND == 34) {  // v_add_u32
+#define S(r) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r) : "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 35) {  // v_lshlrev_b32
+#define S(r) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(r));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 36) {  // v_and_b32
+#define S(r) asm volatile("v_and_b32 %0, %1, %0" : "+v"(r) : "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 37) {  // v_cvt_f32_ubyte0
+#define S(r) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(r));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 38) {  // v_med3_f32
+#define S(r) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(m));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 39) {  // v_max_f32
+#define S(r) asm volatile("v_max_f32 %0, %0, %1" : "+v"(r) : "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 40) {  // v_cndmask_b32_e32 on vcc, destination distinct from the sources' producer chain
+#define S(r, q) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(r) : "v"(q), "v"(c));
+      REP8(S(a0, b0) S(a1, b1) S(a2, b2) S(a3, b3) S(a4, b4) S(a5, b5) S(a6, b6) S(a7, b7))
+#undef S
+    } else if (KIND == 41) {  // v_mul_f32 with the clamp output modifier (VOP3)
+#define S(r) asm volatile("v_mul_f32_e64 %0, %0, %1 clamp" : "+v"(r) : "v"(m));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 42) {  // v_fma_f32 with an SGPR operand
+#define S(r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r) : "s"(m), "v"(c));
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 43) {  // pair: compare into VCC, select on VCC (VOP2 form)
+#define S(r, q) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc" : "+v"(r) : "v"(q), "v"(c) : "vcc");
+      REP8(S(a0, b0) S(a1, b1) S(a2, b2) S(a3, b3) S(a4, b4) S(a5, b5) S(a6, b6) S(a7, b7))
+#undef S
+    } else if (KIND == 44) {  // pair: compare into an SGPR pair, select on it (VOP3 form)
+#define S(r, q) asm volatile("v_cmp_lt_f32 s[20:21], %1, %2\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]" : "+v"(r) : "v"(q), "v"(c) : "s20", "s21");
+      REP8(S(a0, b0) S(a1, b1) S(a2, b2) S(a3, b3) S(a4, b4) S(a5, b5) S(a6, b6) S(a7, b7))
+#undef S
+    } else if (KIND == 45) {  // pair: SALU writes VCC, select on VCC (what the compiler emits behind `a && b`)
+#define S(r) asm volatile("s_and_b64 vcc, s[20:21], s[22:23]\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(r) : "v"(c) : "vcc");
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
+    } else if (KIND == 46) {  // pair: SALU writes an SGPR pair, select on it
+#define S(r) asm volatile("s_and_b64 s[24:25], s[20:21], s[22:23]\n\tv_cndmask_b32_e64 %0, %0, %1, s[24:25]" : "+v"(r) : "v"(c) : "s24", "s25");
+      REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
+#undef S
     } else if (KIND == 18) {  // v_fma_f32 with two literal-free inline constants (VOP3, 3 VGPR reads vs 2)
 #define S(r) asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(r) : "v"(m));
       REP8(S(a0) S(a1) S(a2) S(a3) S(a4) S(a5) S(a6) S(a7))
@@ -231,6 +283,19 @@ int main(int argc, char** argv) {
   run<31>("v_mul_u32_u24 (inline constant)", out, blocks, iters, mhz);
   run<32>("v_sub_f32", out, blocks, iters, mhz);
   run<33>("v_cndmask_b32_e64 (sgpr-pair mask, -|x| modifier)", out, blocks, iters, mhz);
+  run<34>("v_add_u32", out, blocks, iters, mhz);
+  run<35>("v_lshlrev_b32", out, blocks, iters, mhz);
+  run<36>("v_and_b32", out, blocks, iters, mhz);
+  run<37>("v_cvt_f32_ubyte0", out, blocks, iters, mhz);
+  run<38>("v_med3_f32", out, blocks, iters, mhz);
+  run<39>("v_max_f32", out, blocks, iters, mhz);
+  run<40>("v_cndmask_b32_e32 (vcc, dst != src)", out, blocks, iters, mhz);
+  run<41>("v_mul_f32_e64 clamp", out, blocks, iters, mhz);
+  run<42>("v_fma_f32 (sgpr operand)", out, blocks, iters, mhz);
+  run<43>("PAIR v_cmp -> vcc ; v_cndmask_e32 vcc", out, blocks, iters, mhz);
+  run<44>("PAIR v_cmp -> s[20:21] ; v_cndmask_e64 s[20:21]", out, blocks, iters, mhz);
+  // (kinds 45 / 46 -- SALU-written masks -- did not finish within the run's timeout on the box they were tried on:
+  //  they read SGPRs the compiler may own; left out of the default list until they are rewritten with operands)
   run<19>("v_cmp_lt_u64 -> vcc", out, blocks, iters, mhz);
   run<20>("v_cmp_lt_u32 -> vcc", out, blocks, iters, mhz);
   run<21>("v_addc_co_u32", out, blocks, iters, mhz);
