@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override P (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--fast-exp", action="store_true", help="non-parity v_exp_f32 variant (A/B only)")
+    ap.add_argument("--bwd-wave-units", action="store_true", help="backward blend as one wave per (work item, quadrant): round 4's kernel (A/B)")
     ap.add_argument("--sort-whole", action="store_true",
                     help="A/B: option lazy_sort off -- every tile list is sorted whole, as the reference does "
                          "(default: lists beyond 1024 entries are sorted segment by segment as far as the blend walks)")
@@ -210,7 +210,7 @@ def main():
         return got if rank == 0 else None
     args.collect_ranks = collect_ranks
     N.lib()
-    N.set_option("fast_exp", 1 if args.fast_exp else 0)
+    N.set_option("bwd_wave_units", 1 if args.bwd_wave_units else 0)
     N.set_option("split_preprocess", 1 if args.split_preprocess else 0)
     N.set_option("sort_in_blend", 1 if args.sort_in_blend else 0)
     N.set_option("lazy_sort", 0 if args.sort_whole else 1)
@@ -570,7 +570,7 @@ def main():
                        "parallelism": "frames sharded round-robin, one frame per GPU, no data-path collective; "
                                       "%d HIP streams per GPU alternate over consecutive frames (`value` is a throughput "
                                       "with that many frames in flight; `frame_latency_ms` is one frame alone)" % len(streams),
-                       "exp": "v_exp_f32 (non-parity)" if args.fast_exp else "%s (bit-exact vs oracle)" % NUMERICS,
+                       "exp": "%s (bit-exact vs oracle)" % NUMERICS,
                        "tile_sort": "every list sorted whole (--sort-whole)" if args.sort_whole else
                                     "lists beyond 1024 entries sorted lazily, as far as the blend walks (default)"},
             "frame_stats": {"num_rendered": R_mean, "consumed_entries_Rp": Rp_mean, "visible": Pv_mean,

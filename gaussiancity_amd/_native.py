@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = (
     "gcr_backward", "gcr_mark_visible", "gcr_rasterize_forward", "gcr_set_option",
     "gcr_get_stage_ms", "gcr_grad_record_floats", "gcr_grad_record_floats_opt", "gcr_binning_bytes_lean",
     "gcr_forward_async", "gcr_ticket_poll", "gcr_ticket_wait", "gcr_host_words_alloc", "gcr_host_words_free", "gcr_rescue_count",
+    "gcr_get_option", "gcr_rescue_dropped_count",
 )
 GRAD_REC_FLOATS = 16  # gcr_grad_record_floats() by default (32 under option "deterministic_backward": ext asks per call)
 
@@ -29,8 +30,8 @@ STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "ranges", "blend_fwd", "ble
 class Options(C.Structure):
     """gcr_options: per-call overrides of the gcr_set_option() defaults (-1 = the default)."""
     _fields_ = [(n, C.c_int32) for n in (
-        "fast_exp", "lazy_sort", "sort_in_blend", "bwd_piece", "deterministic_backward", "split_preprocess",
-        "force_radix", "force_global_cursor")]
+        "lazy_sort", "sort_in_blend", "bwd_piece", "deterministic_backward", "split_preprocess",
+        "force_radix", "force_global_cursor", "bwd_wave_units")]
 
     def __init__(self, **kw):
         super().__init__(*([-1] * 8))
@@ -97,7 +98,7 @@ class FrameInfo(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("max_tile_instances", C.c_int64)]
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 TICKET_WORDS = 8  # 64-bit pinned host words per asynchronous frame (include/gcr.h, gcr_forward_async)
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -156,6 +157,7 @@ def lib():
     L.gcr_ticket_wait.restype = C.c_int
     L.gcr_ticket_wait.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_void_p, C.POINTER(FrameInfo)]
     L.gcr_rescue_count.restype = C.c_long
+    L.gcr_rescue_dropped_count.restype = C.c_long
     L.gcr_grad_record_floats_opt.restype = C.c_int
     L.gcr_grad_record_floats_opt.argtypes = [C.POINTER(Options)]
     L.gcr_forward_render.restype = C.c_int
@@ -175,6 +177,8 @@ def lib():
                                         C.c_void_p, C.c_void_p, C.c_void_p]
     L.gcr_set_option.restype = C.c_int
     L.gcr_set_option.argtypes = [C.c_char_p, C.c_int]
+    L.gcr_get_option.restype = C.c_int
+    L.gcr_get_option.argtypes = [C.c_char_p]
     L.gcr_get_stage_ms.restype = C.c_int
     L.gcr_get_stage_ms.argtypes = [C.POINTER(C.c_float), C.c_int]
     L.gcr_grad_record_floats.restype = C.c_int
@@ -199,27 +203,17 @@ def get_layout(P, W, H, R):
     return out
 
 
-_option_mirror = {}  # name -> last value set through set_option() (the library has no getter)
-
-
 def set_option(name, value):
-    prev = lib().gcr_set_option(name.encode(), int(value))
-    if prev >= 0:
-        _option_mirror[name] = int(value)
-    return prev
+    return lib().gcr_set_option(name.encode(), int(value))
 
 
 def get_option(name):
-    """Current process-wide default of a gcr_set_option() option.  Options set through this module are mirrored here;
-    one that never was is read once by setting it to 0 and restoring it (not for code that races with other threads:
-    tests and tools).  Per-call values travel in gcr_options (ext.options), not here."""
-    if name in _option_mirror:
-        return _option_mirror[name]
-    prev = lib().gcr_set_option(name.encode(), 0)
-    lib().gcr_set_option(name.encode(), prev)
-    if prev >= 0:
-        _option_mirror[name] = prev
-    return prev
+    """Current process-wide default of a gcr_set_option() option (gcr_get_option, ABI v7: a plain read, safe beside other
+    threads' frames).  Per-call values travel in gcr_options (ext.options), not here."""
+    v = lib().gcr_get_option(name.encode())
+    if v == -2 ** 31:
+        raise KeyError("unknown rasterizer option %r" % name)
+    return v
 
 
 def stage_ms():

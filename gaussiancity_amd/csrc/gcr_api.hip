@@ -7,16 +7,18 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
+
+#include <pthread.h>
 
 #include "gcr_internal.h"
 
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_fast_exp{0};
 std::atomic<int> g_timing{0};
 std::atomic<int> g_force_radix{0};
 std::atomic<int> g_force_global_cursor{0};
@@ -24,6 +26,10 @@ std::atomic<int> g_lazy_sort{1};         // 1: long tile lists are sorted segmen
 std::atomic<int> g_sort_in_blend{0};     // 1: the forward blend sorts short tile lists itself (lower frame latency, lower throughput)
 std::atomic<int> g_split_preprocess{0};  // 1: K1 as two kernels (streaming cull, then exact pass) instead of the fused one
 std::atomic<int> g_deterministic{0};  // 1: fixed-point gradient records (order-independent sums), gcr_internal.h
+std::atomic<int> g_bwd_wave_units{0};  // 1: the backward blend as one wave per (work item, quadrant) (round 4) instead of one workgroup per item
+std::atomic<int> g_rescue_hold{0};  // test hook ("rescue_hold"): 1 = the rescue thread answers no call for help
+std::atomic<int> g_gate_polls{400000};  // polls before a frame gate gives up waiting for a rescue to START: about two seconds
+                                        // (~5 us per poll: a PCIe round trip + two s_sleep 127); tests shorten it
 std::atomic<int> g_bwd_piece{128};  // entries per backward piece of frames rendered for a backward (gcr_camera.backward)
 #ifdef GCR_EXPERIMENTS  // make EXTRA=-DGCR_EXPERIMENTS: timing experiments, never in the shipping library
 std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results are wrong when set
@@ -34,11 +40,10 @@ std::atomic<unsigned long long*> g_clock_buf{nullptr};  // K7 per-wave phase clo
 // One call's options: the process-wide defaults above, overridden field by field by gcr_camera.options (ABI v6).
 // Resolved once at the top of every entry point and handed down by value -- nothing below reads the globals.
 struct Opts {
-  int fast_exp, lazy_sort, sort_in_blend, bwd_piece, deterministic, split_preprocess, force_radix, force_global_cursor;
+  int lazy_sort, sort_in_blend, bwd_piece, deterministic, split_preprocess, force_radix, force_global_cursor, bwd_wave_units;
 };
 Opts resolve_options(const gcr_options* o) {
   Opts r;
-  r.fast_exp = g_fast_exp.load();
   r.lazy_sort = g_lazy_sort.load();
   r.sort_in_blend = g_sort_in_blend.load();
   r.bwd_piece = g_bwd_piece.load();
@@ -46,8 +51,9 @@ Opts resolve_options(const gcr_options* o) {
   r.split_preprocess = g_split_preprocess.load();
   r.force_radix = g_force_radix.load();
   r.force_global_cursor = g_force_global_cursor.load();
+  r.bwd_wave_units = g_bwd_wave_units.load();
   if (o != nullptr) {
-    if (o->fast_exp >= 0) r.fast_exp = o->fast_exp != 0;
+    if (o->bwd_wave_units >= 0) r.bwd_wave_units = o->bwd_wave_units != 0;
     if (o->lazy_sort >= 0) r.lazy_sort = o->lazy_sort != 0;
     if (o->sort_in_blend >= 0) r.sort_in_blend = o->sort_in_blend != 0;
     if (o->bwd_piece >= 0)
@@ -279,7 +285,9 @@ int gcr_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* out) 
 
 int gcr_set_option(const char* name, int value) {
   if (!name) return -1;
-  if (!strcmp(name, "fast_exp")) return g_fast_exp.exchange(value);
+  if (!strcmp(name, "bwd_wave_units")) return g_bwd_wave_units.exchange(value != 0);
+  if (!strcmp(name, "rescue_hold")) return g_rescue_hold.exchange(value != 0);
+  if (!strcmp(name, "gate_polls")) return g_gate_polls.exchange(value < 1 ? 1 : value);
   if (!strcmp(name, "timing")) return g_timing.exchange(value);
   if (!strcmp(name, "force_radix")) return g_force_radix.exchange(value);
   if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.exchange(value);
@@ -296,6 +304,26 @@ int gcr_set_option(const char* name, int value) {
     return g_bwd_piece.exchange(v);
   }
   return -1;
+}
+
+int gcr_get_option(const char* name) {
+  if (!name) return INT32_MIN;
+  if (!strcmp(name, "bwd_wave_units")) return g_bwd_wave_units.load();
+  if (!strcmp(name, "rescue_hold")) return g_rescue_hold.load();
+  if (!strcmp(name, "gate_polls")) return g_gate_polls.load();
+  if (!strcmp(name, "timing")) return g_timing.load();
+  if (!strcmp(name, "force_radix")) return g_force_radix.load();
+  if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.load();
+  if (!strcmp(name, "split_preprocess")) return g_split_preprocess.load();
+  if (!strcmp(name, "sort_in_blend")) return g_sort_in_blend.load();
+  if (!strcmp(name, "lazy_sort")) return g_lazy_sort.load();
+  if (!strcmp(name, "deterministic_backward")) return g_deterministic.load();
+  if (!strcmp(name, "bwd_piece")) return g_bwd_piece.load();
+#ifdef GCR_EXPERIMENTS
+  if (!strcmp(name, "k7_skip_flush")) return g_k7_skip_flush.load();
+  if (!strcmp(name, "k6_debug")) return g_k6_debug.load();
+#endif
+  return INT32_MIN;
 }
 
 int gcr_get_stage_ms(float* ms_out, int capacity) {
@@ -504,14 +532,14 @@ static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_g
   set_piece_args(op, b, cam->backward == 1, L, R_layout > 0 ? binning : nullptr, geom);
   b.gate_words = gate_words;  // asynchronous frames: the forward blend is the frame's last kernel and carries the gate
   b.gate_seq = gate_seq;
-  b.gate_polls = 400000u;  // about two seconds before a gate gives up (~5 us per poll: a PCIe round trip + two s_sleep 127)
+  b.gate_polls = (unsigned int)g_gate_polls.load();
 #ifdef GCR_EXPERIMENTS
   b.debug_flags = g_k6_debug.load();
   b.clock_buf = g_clock_buf.load();  // K6: [tile][8] = {hw id | xcc id << 32, clock at entry, at exit, list length, staged, lists built, walk done, steps}
 #endif
   {
     StageTimer t(s, ST_BLEND_FWD);
-    HIP_TRY(gcr_launch_blend_fwd(b, op.fast_exp != 0, sort_in_blend, s), "blend forward");
+    HIP_TRY(gcr_launch_blend_fwd(b, sort_in_blend, s), "blend forward");
   }
   return debug_sync(cam, s, "blend forward");
 }
@@ -547,9 +575,33 @@ struct FrameReadback {
 };
 thread_local FrameReadback g_readback;
 
-unsigned long long* gcr_host_words_alloc(size_t n_words) { return host_words_alloc(n_words); }
+// allocations handed out by gcr_host_words_alloc (pointer -> words): gcr_host_words_free must take the rescue thread's
+// eyes off a block before it unmaps it
+static std::mutex g_words_mu;
+static std::map<unsigned long long*, size_t> g_words_blocks;
+static void rescue_forget_words(const unsigned long long* base, size_t n);  // (RescueService, below)
+
+unsigned long long* gcr_host_words_alloc(size_t n_words) {
+  unsigned long long* p = host_words_alloc(n_words);
+  if (p) {
+    std::lock_guard<std::mutex> lk(g_words_mu);
+    g_words_blocks[p] = n_words;
+  }
+  return p;
+}
 void gcr_host_words_free(unsigned long long* words) {
-  if (words) (void)hipHostFree(words);
+  if (!words) return;
+  size_t n = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_words_mu);
+    auto it = g_words_blocks.find(words);
+    if (it != g_words_blocks.end()) {
+      n = it->second;
+      g_words_blocks.erase(it);
+    }
+  }
+  if (n) rescue_forget_words(words, n);
+  (void)hipHostFree(words);
 }
 
 int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* geom,
@@ -651,12 +703,20 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
 // ------------------------------------------------------------------------------------ asynchronous frames + rescue
 // gcr_forward_async (include/gcr.h): the frame is enqueued and the call returns.  What the synchronous entry point
 // does on the host when the capacity guess was short -- allocate an exactly sized buffer, render again -- is done here
-// by a RESCUE THREAD, while the frame's last kernel (k_frame_gate) holds the caller's stream: words[3] = seq is the
-// gate's call for help, words[2] = seq releases it, words[5] = seq says the rescue failed, words[6] = seq that the
-// frame was rendered by the rescue (its state is not in the caller's binning buffer).  The thread is started by the
-// first asynchronous call, sleeps while no asynchronous frame is outstanding and otherwise looks at the outstanding
-// frames' words every 100 us; a frame that fitted (the overwhelming majority: the caller's guess carries a margin)
-// leaves the list as soon as its num_rendered is known.
+// by a RESCUE THREAD, while the frame's last kernel (the gate in k_blend_fwd's first thread, gcr_blend.hip) holds the
+// caller's stream.  Protocol words of a frame (pinned host memory, `seq` = the frame's tag in each):
+//   [3] gate -> host: the frame overflowed, every kernel of it has run, the stream is held
+//   [7] host -> gate: a rescue has STARTED (from here on it writes geom / img / out_color)
+//   [2] host -> gate: release (the rescue is complete, or has failed)
+//   [4] gate -> host: gave up waiting for a rescue to start (about two seconds)
+//   [5] the rescue failed          [6] the frame was handled by the rescue (its state is not in the caller's buffer)
+// [4] and [7] are decided the Dekker way (k6_frame_gate): a rescue that finds [4] set after announcing itself touches
+// nothing -- the stream may long have gone on and the buffers may belong to somebody else -- and a gate
+// that finds [7] set after giving up goes on waiting for [2] (sixteen times as long: never a device hung for good).
+// The thread is started by the first asynchronous call, sleeps while no asynchronous frame is outstanding and
+// otherwise looks at the outstanding frames' words every 100 us; a frame that fitted (the overwhelming majority: the
+// caller's guess carries a margin) leaves the list as soon as its num_rendered is known; any entry older than 120 s
+// (a stream that died, a gate that never launched) is dropped.
 struct AsyncFrame {
   unsigned long long* words;
   unsigned int seq;
@@ -684,14 +744,24 @@ class RescueService {
   void* scratch_[64] = {};        // per device: the rescue's binning buffer, kept from one rescue to the next (grow only)
   size_t scratch_bytes_[64] = {};
   std::atomic<long> rescued_{0};
+  std::atomic<long> dropped_{0};  // calls for help that came too late (the gate had given up)
 
   static void publish(unsigned long long* w, int idx, unsigned int seq) {
     std::atomic_thread_fence(std::memory_order_seq_cst);
     ((volatile unsigned long long*)w)[idx] = (unsigned long long)seq;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
   }
 
   void rescue(AsyncFrame& f) {
     volatile unsigned long long* w = f.words;
+    // announce, THEN look whether the gate has given up (k6_frame_gate does the same the other way round)
+    publish(f.words, 7, f.seq);
+    if ((unsigned int)w[4] == f.seq) {  // too late: the stream has gone on (or is about to) -- nothing may be written
+      publish(f.words, 5, f.seq);
+      publish(f.words, 2, f.seq);  // (a gate that saw word 7 after giving up is waiting for this)
+      dropped_.fetch_add(1);
+      return;
+    }
     const unsigned long long R = w[0] & 0xffffffffull;
     bool ok = false;
     void* stale = nullptr;  // a scratch buffer that was too small: freed AFTER the gate is released (hipFree waits for
@@ -700,7 +770,15 @@ class RescueService {
       if (R > 0x7fffffffull) break;
       if (hipSetDevice(f.device) != hipSuccess) break;
       const int d = f.device & 63;
-      if (!streams_[d] && hipStreamCreateWithFlags(&streams_[d], hipStreamNonBlocking) != hipSuccess) break;
+      if (!streams_[d]) {
+        // highest priority: a queue of its own where the runtime has one -- the rescue's kernels must never sit in a
+        // hardware queue BEHIND the gate that is waiting for them (streams are multiplexed onto a few queues)
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+        if (hipStreamCreateWithPriority(&streams_[d], hipStreamNonBlocking, hi) != hipSuccess &&
+            hipStreamCreateWithFlags(&streams_[d], hipStreamNonBlocking) != hipSuccess)
+          break;
+      }
       hipStream_t s = streams_[d];
       gcr_camera cam = f.cam;
       cam.backward = 0;  // the temporary buffer dies with the rescue: no backward state (gcr_forward_render with
@@ -749,6 +827,7 @@ class RescueService {
       std::unique_lock<std::mutex> lk(mu_);
       cv_.wait(lk, [&] { return !frames_.empty(); });
       const auto now = std::chrono::steady_clock::now();
+      const bool hold = g_rescue_hold.load() != 0;
       for (auto it = frames_.begin(); it != frames_.end();) {
         volatile unsigned long long* w = it->words;
         const unsigned long long v = w[0];
@@ -757,7 +836,12 @@ class RescueService {
             it = frames_.erase(it);
             continue;
           }
-          if ((unsigned int)w[3] == it->seq) {  // the gate is holding the stream: every kernel of the frame is done
+          if ((unsigned int)w[4] == it->seq) {  // its gate has given up: the frame is lost, the ticket says so
+            dropped_.fetch_add(1);
+            it = frames_.erase(it);
+            continue;
+          }
+          if (!hold && (unsigned int)w[3] == it->seq) {  // the gate is holding the stream: every kernel of the frame is done
             AsyncFrame f = *it;
             frames_.erase(it);
             lk.unlock();
@@ -765,7 +849,8 @@ class RescueService {
             lk.lock();
             break;  // iterators are gone: rescan on the next round
           }
-        } else if (now - it->born > std::chrono::seconds(120)) {  // a frame whose stream died: stop looking at it
+        }
+        if (now - it->born > std::chrono::seconds(120)) {  // a stream that died, a gate that never launched: stop looking
           it = frames_.erase(it);
           continue;
         }
@@ -790,15 +875,46 @@ class RescueService {
     }
     if (was_empty) cv_.notify_one();  // (with frames outstanding the thread is polling, not waiting)
   }
+  void forget(const unsigned long long* base, size_t n) {  // gcr_host_words_free: these words are about to be unmapped
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto it = frames_.begin(); it != frames_.end();) it = (it->words >= base && it->words < base + n) ? frames_.erase(it) : it + 1;
+  }
+  void remove(const unsigned long long* words, unsigned int seq) {  // a frame whose enqueue failed after add()
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto it = frames_.begin(); it != frames_.end();) it = (it->words == words && it->seq == seq) ? frames_.erase(it) : it + 1;
+  }
   long rescued() const { return rescued_.load(); }
+  long dropped() const { return dropped_.load(); }
+  // fork(): the child has this object's memory but not its thread (and no usable HIP context).  The handler below runs in
+  // the child: a fresh service state, so that a child that initialises HIP itself and renders asynchronously starts a
+  // thread of its own instead of trusting `started_`.  (The mutex may have been held by the parent's thread at the
+  // moment of the fork: it is re-constructed in place, never unlocked.)
+  void reset_after_fork() {
+    new (&mu_) std::mutex();
+    new (&cv_) std::condition_variable();
+    new (&frames_) std::deque<AsyncFrame>();
+    started_ = false;
+    for (int i = 0; i < 64; i++) {
+      streams_[i] = nullptr;
+      scratch_[i] = nullptr;
+      scratch_bytes_[i] = 0;
+    }
+  }
 };
 // never destroyed: the detached thread may outlive static destruction at process exit
 static RescueService& rescue_service() {
-  static RescueService* r = new RescueService();
+  static RescueService* r = [] {
+    RescueService* p = new RescueService();
+    (void)pthread_atfork(nullptr, nullptr, [] { rescue_service().reset_after_fork(); });
+    return p;
+  }();
   return *r;
 }
 
+static void rescue_forget_words(const unsigned long long* base, size_t n) { rescue_service().forget(base, n); }
+
 long gcr_rescue_count(void) { return rescue_service().rescued(); }  // diagnostics: frames that needed the rescue so far
+long gcr_rescue_dropped_count(void) { return rescue_service().dropped(); }  // ... and calls for help that came after the gate had given up
 
 int gcr_forward_async(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes, void* binning,
                       size_t binning_bytes, int64_t binning_capacity, int64_t tile_list_capacity, void* img,
@@ -848,8 +964,10 @@ int gcr_forward_async(const gcr_camera* cam, const gcr_gaussians* g, void* geom,
   f.capacity = binning_capacity;
   f.born = std::chrono::steady_clock::now();
   rescue_service().add(f);  // (before the kernel that may call for it is enqueued)
-  return enqueue_render_lds(op, cam, g, geom, binning, img, binning_capacity, list_hint, true,
-                            (unsigned long long)binning_capacity, ~0ull, out_color, s, words_host + 1, words_host, seq);
+  const int rc = enqueue_render_lds(op, cam, g, geom, binning, img, binning_capacity, list_hint, true,
+                                    (unsigned long long)binning_capacity, ~0ull, out_color, s, words_host + 1, words_host, seq);
+  if (rc < 0) rescue_service().remove(words_host, seq);  // no gate was enqueued: nobody will ever call for this frame
+  return rc;
 }
 
 static int ticket_state(const unsigned long long* words_host, uint32_t seq, int64_t capacity, gcr_frame_info* info) {
@@ -862,7 +980,7 @@ static int ticket_state(const unsigned long long* words_host, uint32_t seq, int6
   if (R > (unsigned long long)capacity) {  // the frame needed the rescue: resolved when that is complete
     if ((unsigned int)w[5] == seq) return fail(GCR_ERR_DEVICE, "the overflow rescue of an asynchronous frame failed");
     if ((unsigned int)w[2] != seq) {
-      if ((unsigned int)w[4] == seq)
+      if ((unsigned int)w[4] == seq && (unsigned int)w[7] != seq)  // (with word 7 set the gate is waiting for word 2)
         return fail(GCR_ERR_DEVICE, "an asynchronous frame overflowed its binning buffer and was not rescued in time");
       return 1;
     }
@@ -979,7 +1097,7 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   set_piece_args(op, b, cam->backward == 1, L, binning, geom);
   {
     StageTimer t(s, ST_BLEND_FWD);
-    HIP_TRY(gcr_launch_blend_fwd(b, op.fast_exp != 0, false, s), "blend forward");
+    HIP_TRY(gcr_launch_blend_fwd(b, false, s), "blend forward");
   }
   return debug_sync(cam, s, "blend forward");
 }
@@ -1098,7 +1216,7 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     b.debug_flags = g_k7_skip_flush.load();  // bit 0: no global flush, bit 1: no zero fill, bit 2: no LDS adds
     b.clock_buf = g_clock_buf.load();
 #endif
-    HIP_TRY(gcr_launch_blend_bwd(b, op.fast_exp != 0, s), "blend backward");
+    HIP_TRY(gcr_launch_blend_bwd(b, op.bwd_wave_units != 0, s), "blend backward");
   } else {
     HIP_TRY(gcr_launch_fill(fill, s), "gradient zero fill");
   }

@@ -1,28 +1,27 @@
 // gcr_blend.hip -- K6 forward alpha compositing and K7 reverse-walk gradient for gfx950.
 //
-// One 256-thread workgroup (4 x wave64) per 16x16 tile.  Wave w owns the 8x8-pixel quadrant
-// (w&1, w>>1) of the tile and each of its four 16-lane DPP ROWS owns one 4x4-pixel BLOCK of that
-// quadrant (lane = row*16 + y*4 + x).  A tile's depth-sorted list is consumed in chunks of 256
-// entries: the 256 threads gather one 48-byte Gaussian record each (3 x dwordx4 from <= 2 cache
-// lines) and stage it in LDS, so the blend loop never touches global memory.  Differences from
-// cr/forward.cu:238-346 that do not change results:
+// K6 (k_blend_fwd): one 256-thread workgroup (4 x wave64) per 16x16 tile.  Wave w owns the 8x8-pixel quadrant
+// (w&1, w>>1) of the tile, cut into EIGHT sub-rows of 8 lanes, each a block of 2 (wide) x 4 (high) pixels with a list
+// of its own (lane_geom6 below).  A tile's depth-sorted list is consumed in chunks of <= 223 entries: one thread per
+// entry gathers the 48-byte Gaussian record (3 x dwordx4 from <= 2 cache lines) and stages it in LDS, so the blend loop
+// never touches global memory.  Differences from cr/forward.cu:238-346 that do not change results:
 //   * colour is staged in LDS too (the reference gathers it per contributing pixel, :328);
-//   * a per-Gaussian conservative bound pmin = -ln(255*opacity) - 1e-3 is staged; pixels with
-//     power < pmin are skipped before exp() -- exactly pixels the alpha < 1/255 test (:318)
-//     would skip anyway;
-//   * BLOCK CULLING: the staging thread computes which of the tile's sixteen 4x4 blocks the
-//     ellipse {power >= pmin} can reach (gcr_cull.h: exact per block row, conservative, checked
-//     by brute force on the host).  Every wave compacts the chunk into FOUR lists, one per row,
-//     and each row walks only its own block's entries: the four rows of a wave work on different
-//     Gaussians in the same instruction (per-lane LDS addresses, identical inside a row).  An
-//     entry missing from a block's list has power < pmin for its 16 pixels, i.e. it is skipped
-//     by those pixels upstream as well, and skipped entries never change a pixel's state -- so
-//     n_contrib / final_T / colour are unchanged.  Measured on the BASELINE scenes this walks
-//     32 % (C3) to 45 % (C2) fewer wave-steps than 8x8 bounding-box culling;
+//   * a per-Gaussian conservative bound pmin = -ln(255*opacity) - 1e-3 is staged; pixels with power < pmin are skipped
+//     before exp() -- exactly pixels the alpha < 1/255 test (:318) would skip anyway;
+//   * BLOCK CULLING: the staging thread computes which of the tile's thirty-two 2x4 blocks the ellipse {power >= pmin}
+//     can reach (gcr_cull.h, gcr_block_mask_2x4: exact per 4-pixel band, conservative, checked by brute force on the
+//     host).  Every wave compacts the chunk into EIGHT lists of byte slots, one per sub-row, and each sub-row walks only
+//     its own block's entries: the eight sub-rows of a wave work on different Gaussians in the same instruction (per-lane
+//     LDS addresses, identical inside a sub-row).  An entry missing from a block's list has power < pmin for its 8
+//     pixels, i.e. it is skipped by those pixels upstream as well, and skipped entries never change a pixel's state -- so
+//     n_contrib / final_T / colour are unchanged;
 //   * `contributor` is recovered from the list position instead of a per-lane counter;
 //   * a wave stops as soon as its own 64 pixels are done, on top of the block vote (:284-286).
-// Arithmetic: gcr-fp32-v2 (gcr_device.h) -> out_color / final_T / n_contrib are bit-identical
-// to the oracle.
+// K7: two kernels walk the same per-(tile, piece) work items the training-type K6 leaves behind -- k_blend_bwd_item (one
+// workgroup per item: the records of a piece are gathered ONCE for the tile's four quadrant waves and every entry leaves
+// as ONE record update) and k_blend_bwd (one independent wave per (item, quadrant); the deterministic mode's kernel).
+// Its rows are 16-lane DPP rows = 4x4-pixel blocks (lane_geom below).
+// Arithmetic: gcr-fp32-v2 (gcr_device.h) -> out_color / final_T / n_contrib are bit-identical to the oracle.
 #include "gcr_cull.h"
 #include "gcr_device.h"
 #include "gcr_internal.h"
@@ -59,10 +58,9 @@ GCR_DEV float gcr_alpha_skip_bound(float opacity) {
   return gcr_max(-87.0f, -__builtin_logf(255.0f * opacity) - 1.0e-3f);
 }
 
-template <bool FAST_EXP>
-GCR_DEV float blend_exp(float x) {
-  return FAST_EXP ? gcr_expf_fast(x) : gcr_expf_noguard(x);
-}
+// the blend kernels' exponential: gcr-fp32-v2 (gcr_device.h), reproduced bit for bit by the oracle.  (A v_exp_f32
+// "fast_exp" mode existed until round 4; it was slower than this one on the eight-workgroup kernel and is gone.)
+GCR_DEV float blend_exp(float x) { return gcr_expf_noguard(x); }
 
 // Lane geometry shared by K6 and K7: which pixel a lane owns and which mask bits its wave's rows use.
 struct LaneGeom {
@@ -145,11 +143,12 @@ GCR_DEV uint8_t gcr_video_byte(float c) {
 GCR_DEV uint32_t slot_of_offset(uint32_t off) { return (off * 1366u) >> 16; }
 
 // ------------------------------------------------------------------------------------- K6
-// What bounds this loop is VALU issue (tools/valu_probe.hip: a wave64 v_fma_f32 occupies its SIMD
-// for two cycles; v_cmp -> SGPR, SGPR operands and v_cndmask with an SGPR-pair mask cost ~1.7x that;
-// v_pk_*_f32 cost 1.9x for two results, so packing buys nothing).  Hence
-//   * per-row lists (above) -- fewer steps;
-//   * each step is branch-free with ONE wave-uniform skip and 38 VALU instructions:
+// What bounds this loop is VALU issue, priced per kind (tools/valu_probe.hip, profiles/r04_valu_probe.jsonl): fp32 add /
+// mul / fma and integer add / and issue in ~2.5 cycles per wave64; compares, selects, min / max, shifts, v_lshl_add_u32,
+// v_mul_u32_u24, DPP operations and SGPR operands in ~4.2; v_pk_*_f32 cost as much as the two plain ones they replace.
+// Hence
+//   * per-sub-row lists (above) -- fewer steps;
+//   * each step is branch-free, 40 VALU instructions (27 full-rate, 13 half-rate), NO wave-uniform skip:
 //       - conic pre-scaled by the staging thread (-0.5*cx, -cy, -0.5*cz): power in 6 instead of 7
 //         (a scaling by a power of two commutes with every rounding, so `power` has the bits of
 //         fma(-(cy*dx), dy, -0.5*fma(cz*dy, dy, (cx*dx)*dx)) whenever no product is denormal, and a
@@ -163,20 +162,20 @@ GCR_DEV uint32_t slot_of_offset(uint32_t off) { return (off * 1366u) >> 16; }
 //         A pixel that skips the entry has a_eff = 0 -> test_T = Tw (>= 1e-4 while live) -> keep, w = 0;
 //         a finished pixel has Tw < 0 -> !keep -> Tw unchanged.  (colour*0)*Tw adds an exact zero.
 //         Two corner cases are knowingly different from upstream, both on garbage input only: a
-//         NON-FINITE colour poisons every pixel of the 4x4 blocks whose list holds the Gaussian (the conservative
+//         NON-FINITE colour poisons every pixel of the 2x4 blocks whose list holds the Gaussian (the conservative
 //         block mask; upstream: only pixels it contributes to), and an accumulator that is exactly -0.0 (needs a
 //         colour below 1e-40) may become +0.0.
 //   * SORT (template): the workgroup sorts its own tile first.  GaussianCity's scenes have ~150 entries per tile, and
 //     sorting 150 keys is a microsecond of work for the workgroup that is about to gather them anyway -- as a
-//     separate kernel (K4) it is a latency-bound launch of 18 us on the frame's critical path.  Lists of up to
-//     CHUNK keys are rank-sorted in LDS (every thread counts the keys below its own through wave-uniform 16-byte
+//     separate kernel (K4) it is a latency-bound launch of 18 us on the frame's critical path.  Lists of up to one
+//     chunk (223 keys) are rank-sorted in LDS (every thread counts the keys below its own through wave-uniform 16-byte
 //     reads; unique keys => rank = position); a longer list -- only possible when the caller's length hint was
 //     stale, the host then switches to the K4 path -- is ranked the same way through global loads: slow, correct.
 //     The sorted indices are also written to `list_out` for the backward.
-// The step's wave-uniform skip ("no lane of the wave is in range of its row's entry").  With four rows on four different
-// entries it almost never fires, the body is exact for a wave without a lane in range (every use is behind a select), and
-// without the branch the two steps of a trip are one basic block: round 4 A/B at C3, same box, blend alone 106.4 -> 104.0 us,
-// 5 125-5 134 -> 5 161-5 192 frames/s (profiles/r04_micro_ab.jsonl).  1 = the branch (A/B builds).
+// The step's wave-uniform skip ("no lane of the wave is in range of its sub-row's entry") is compiled OUT: with eight
+// sub-rows on eight different entries it almost never fires, the body is exact for a wave without a lane in range (every use
+// is behind a select), and without the branch the two steps of a trip are one basic block: round 4 A/B at C3, same box, blend
+// alone 106.4 -> 104.0 us, 5 125-5 134 -> 5 161-5 192 frames/s (profiles/r04_micro_ab.jsonl).  1 = the branch (A/B builds).
 #ifndef GCR_K6_SKIP_BRANCH
 #define GCR_K6_SKIP_BRANCH 0
 #endif
@@ -223,8 +222,14 @@ __device__ __noinline__ uint32_t k6_lazy_extend(uint64_t* s, const uint64_t* key
 // nothing on the caller's stream: the first thread of the forward blend -- the frame's LAST kernel -- tells the host
 // (words[3] = seq) and keeps the kernel, and with it the stream, from finishing until the library's rescue thread has
 // rendered the frame with an exactly sized buffer on a stream of its own (words[2] = seq): everything the caller
-// enqueued behind the frame sees the finished image.  The wait is bounded (about two seconds): a gate that gives up
-// says so in words[4] and the ticket resolves to an error instead of a hung device.
+// enqueued behind the frame sees the finished image.
+// The wait for a rescue to START is bounded (about two seconds); a gate that gives up says so in words[4] and the ticket
+// resolves to an error instead of a hung device.  Once the rescue has started (words[7] = seq: from then on it writes
+// the frame's buffers) the gate goes on waiting for it, sixteen times as long -- letting the stream go on would hand
+// buffers that are still being written to whatever the caller enqueued behind the frame.  The two sides decide who was
+// first the Dekker way: the gate stores words[4] and THEN reads words[7]; the rescue stores words[7] and THEN reads
+// words[4] (a PCIe read does not pass the posted write in front of it, the host side fences): at least one of them
+// sees the other.  A rescue that sees words[4] touches nothing and releases the gate with the failure word set.
 __device__ __noinline__ void k6_frame_gate(unsigned long long* words, unsigned int seq, unsigned int max_polls) {
   gcr_store_to_host(words + 3, (unsigned long long)seq);
   for (unsigned int i = 0; i < max_polls; i++) {
@@ -234,6 +239,19 @@ __device__ __noinline__ void k6_frame_gate(unsigned long long* words, unsigned i
     __builtin_amdgcn_s_sleep(127);
   }
   gcr_store_to_host(words + 4, (unsigned long long)seq);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store is acknowledged before the load below is issued
+  const unsigned long long st = __hip_atomic_load(words + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((unsigned int)st != seq) return;  // nobody started: the stream goes on with an unrendered frame, the ticket says so
+  // a rescue is writing the frame's buffers: hold the stream until it says it is done (or has failed) -- sixteen times
+  // longer than the wait for its start (about half a minute by default); only a rescue that is stuck for that long (its
+  // own stream starved behind this very kernel, a dead host thread) lets the stream go on: a device that hangs for good
+  // would be the worse failure, and the ticket then never resolves to a success
+  for (unsigned long long i = 0; i < 16ull * max_polls; i++) {
+    const unsigned long long v = __hip_atomic_load(words + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned int)v == seq) return;
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
+  }
 }
 
 // amdgpu_waves_per_eu(8, 8): the call above constrains the register assignment (what lives across it must sit in
@@ -245,7 +263,7 @@ __device__ __noinline__ void k6_frame_gate(unsigned long long* words, unsigned i
 // of every staged entry -- is written only by frames rendered with gcr_camera.backward == 1.  Every other frame (the
 // headline inference workload) runs the instantiation without a single instruction of it; gcr_backward on such a
 // frame regenerates the state with one more pass of this kernel (a.out_color == nullptr: no pixel is stored).
-template <bool FAST_EXP, bool SORT, bool STATE>
+template <bool SORT, bool STATE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blend_fwd(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[K6_SENT_SLOT + 1];
   __shared__ uint32_t sMask[CHUNK];
@@ -354,7 +372,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const bool in_range = !(power > 0.0f) && !(power < QC.y);                                \
     if (GCR_K6_WAVE_SKIP(in_range) && GCR_K6_STEP_ON) { /* wave-uniform */                    \
       /* lanes outside [pmin, 0] may produce garbage; every use below is behind a select */  \
-      const float araw = __builtin_fminf(0.99f, QB.y * blend_exp<FAST_EXP>(power));          \
+      const float araw = __builtin_fminf(0.99f, QB.y * blend_exp(power));          \
       const bool valid = in_range && !(araw < 1.0f / 255.0f);                                \
       const float a_eff = valid ? araw : 0.0f;                                               \
       const float test_T = Tw * (1 - a_eff);                                                 \
@@ -611,8 +629,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #define GCR_FLUSH_ON !(a.debug_flags & 1)
 #define GCR_LDS_ADD_ON !(a.debug_flags & 4)
 #define GCR_STEP_ON !(a.debug_flags & 16)   /* knock-out: the step's arithmetic (loads and loop stay) */
+#define GCR_K7_IEEE_DIV (a.debug_flags & 64) /* attribution (tools/fuzz_f64.py): the step's two quotients as IEEE divisions, like the oracle */
 #define GCR_PASSES_ON !(a.debug_flags & 32) /* knock-out: everything after the unit's prologue */
 #else
+#define GCR_K7_IEEE_DIV false
 #define GCR_STEP_ON true
 #define GCR_PASSES_ON true
 #define GCR_K7_CLK(i)
@@ -660,14 +680,14 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
                           !(power_raw < QC.y);                                                 \
     if (GCR_K7_WAVE_SKIP(in_range) && GCR_STEP_ON) { /* else the whole wave skips this step */   \
       const float power = in_range ? power_raw : 0.0f;                                         \
-      const float G = blend_exp<FAST_EXP>(power);                                              \
+      const float G = blend_exp(power);                                              \
       const float alpha = __builtin_fminf(0.99f, QB.y * G);                                    \
       const bool use = in_range && !(alpha < 1.0f / 255.0f);                                   \
       const float a_eff = use ? alpha : 0.0f;                                                  \
       const float om = 1.f - a_eff;                                                            \
       const float rc0 = __builtin_amdgcn_rcpf(om);                                             \
       const float rcp = __builtin_fmaf(rc0, __builtin_fmaf(-om, rc0, 1.0f), rc0);              \
-      T = T * rcp;                                                                             \
+      T = GCR_K7_IEEE_DIV ? T / om : T * rcp;                                                  \
       const float dchannel_dcolor = a_eff * T;                                                 \
       const float oml = 1.f - last_alpha;                                                      \
       acc0 = __builtin_fmaf(last_alpha, lc0, oml * acc0);                                      \
@@ -682,7 +702,7 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
       dL_dalpha = __builtin_fmaf(lc1 - acc1, dLp1, dL_dalpha);                                 \
       dL_dalpha = __builtin_fmaf(lc2 - acc2, dLp2, dL_dalpha);                                 \
       dL_dalpha *= T;                                                                          \
-      dL_dalpha += (neg_T_final * rcp) * bg_dot_dpixel;                                        \
+      dL_dalpha += (GCR_K7_IEEE_DIV ? neg_T_final / om : neg_T_final * rcp) * bg_dot_dpixel;   \
       dL_dalpha = use ? dL_dalpha : 0.0f;                                                      \
       const float dL_dG = QB.y * dL_dalpha;                                                    \
       const float gdx = G * dx, gdy = G * dy;                                                  \
@@ -713,6 +733,9 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
 #ifndef GCR_K7_SKIP_BRANCH
 #define GCR_K7_SKIP_BRANCH 0
 #endif
+#ifndef GCR_K7_XCD_MAP  /* 0 = round 4's unit order (A/B builds) */
+#define GCR_K7_XCD_MAP 1
+#endif
 #if GCR_K7_SKIP_BRANCH
 #define GCR_K7_WAVE_SKIP(x) (__ballot(x) != 0ull)
 #else
@@ -737,7 +760,6 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
 
 
 
-template <bool FAST_EXP>
 #ifdef GCR_K7_WAVES_PER_EU  /* A/B builds: ask for that many waves per SIMD (4 = what 118-120 VGPRs give) */
 #define GCR_K7_OCC __attribute__((amdgpu_waves_per_eu(GCR_K7_WAVES_PER_EU, 8)))
 #else
@@ -785,14 +807,25 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
   for (int k = 0; k < 9; k++) sAcc[k * WPASS + lane] = 0.0f;  // kept zero by the flush from here on
 
   // the grid covers the units the host expects; should the forward have used a smaller piece, the waves stride on
-  for (unsigned long long unit = (unsigned long long)blockIdx.x - (unsigned long long)a.fill.blocks; unit < nunits;
-       unit += (unsigned long long)gridDim.x - (unsigned long long)a.fill.blocks) {
-    uint4 d = work[unit >> 2];
+  // Which unit a workgroup takes: 32 consecutive workgroups share 8 items x 4 quadrants so that the four quadrants of an
+  // item are 8 workgroups apart -- workgroup b runs on XCD b % 8 (observed, for speed only), so an item's records,
+  // masks, list entries and checkpoints are fetched into ONE of the eight L2s instead of up to four (round 5).
+  const unsigned long long nvirt = (nunits + 31ull) & ~31ull;
+  for (unsigned long long v = (unsigned long long)blockIdx.x - (unsigned long long)a.fill.blocks; v < nvirt;
+       v += (unsigned long long)gridDim.x - (unsigned long long)a.fill.blocks) {
+#if GCR_K7_XCD_MAP
+    const unsigned long long item = (v >> 5) * 8ull + (v & 7ull);
+    const int q = (int)((v >> 3) & 3ull);  // quadrant of the tile: the `wave` of K6's lane geometry
+#else
+    const unsigned long long item = v >> 2;
+    const int q = (int)(v & 3ull);
+#endif
+    if (4ull * item >= nunits) continue;
+    uint4 d = work[item];
     // (one 16-byte load: left alone the compiler fetches d.x, tests it, and only then fetches the rest -- a second
     // dependent round trip at the head of every unit's chain)
     asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
     if (d.x == GCR_NO_TILE) continue;  // wave-uniform
-    const int q = (int)(unit & 3ull);  // quadrant of the tile: the `wave` of K6's lane geometry
     const int tile = (int)d.x;
     const uint32_t r0 = d.y, len = d.z, kpiece = d.w;
     const uint32_t npieces = gcr_piece_count(len, piece_P), cs = gcr_piece_size(len, piece_P);
@@ -994,53 +1027,241 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------- K7, one workgroup per item
+// Round 5.  The wave-per-(item, quadrant) kernel above gathers every list entry of a piece once per
+// quadrant that can see it and flushes it once per quadrant (counter traffic 6.9x the algorithmic bytes at C2, 2.5
+// record updates per consumed entry).  Here ONE 256-thread workgroup owns a (tile, piece) item:
+//   1. prologue, all loads of a thread independent of each other: the work item, the thread's pixel state (final T,
+//      n_contrib, dL/dpixel, the two checkpoints), and -- thread t < n -- block mask and Gaussian id of list entry
+//      hi - 1 - t (the piece back to front: a piece is <= 223 entries, one per thread);
+//   2. thread t gathers that entry's record ONCE (if its mask reaches any block of the tile) and stages it; barrier;
+//   3. every wave builds the four row lists of its quadrant from the shared masks (its own rows' max n_contrib bounds
+//      them, no cross-wave value is needed) and walks them exactly as above -- no barrier inside the walk; the row
+//      sums of all four waves meet in ONE LDS accumulator column per entry (ds_add_f32 is atomic across waves);
+//   4. barrier; the nine sums of an entry leave as ONE record update per (entry, piece), nine adjacent lanes.
+// Two barriers in a workgroup's life, none in the walk.  The float sums of different waves meet in LDS in arrival order, so
+// the deterministic mode (whose promise is bit-identical reruns) stays on the kernel above.
+constexpr int IPASS = GCR_PIECE_MAX;                 // entries a workgroup stages: one whole piece
+constexpr int ILIST_STRIDE = IPASS + 9;              // u16 slots per row list: entries + pipeline pads (232)
+constexpr uint32_t ISENT_OFF = IPASS * ENTRY_BYTES;  // byte offset of the sentinel entry
+static_assert(IPASS < 256 && ISENT_OFF < 65536u, "one thread per piece entry, u16 list slots");
+
+__global__ __launch_bounds__(256) void k_blend_bwd_item(const GcrBlendArgs a) {
+  __shared__ StagedEntry sE[IPASS + 1];
+  __shared__ uint32_t sId[IPASS + 1];
+  __shared__ uint16_t sMask[256];
+  __shared__ uint16_t sList[4][4][ILIST_STRIDE];
+  __shared__ float sAcc[IPASS * 9];  // entry-major: the nine sums of slot j at [9j, 9j+9)
+
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < a.fill.blocks) {  // the launch's leading workgroups: zero fill of the dense outputs
+    for (int sgi = 0; sgi < a.fill.nseg; sgi++)
+      gcr_fill_zero_segment<256>(a.fill.ptr[sgi], a.fill.n[sgi], (int)blockIdx.x, a.fill.blocks, tid);
+    return;
+  }
+  if (!gcr_frame_has_state(a.frame_in, a.binning_bytes)) return;  // (see k_blend_bwd)
+  const uint32_t piece_P = (uint32_t)a.frame_in[GCR_FRAME_PIECE];
+  const unsigned long long nitems = gcr_piece_slots(a.R, (unsigned long long)(a.gx * a.gy), piece_P);
+  const float4* __restrict__ ckpt = reinterpret_cast<const float4*>(a.binning_base + a.frame_in[GCR_FRAME_CKPT_OFF]);
+  const uint4* __restrict__ work = reinterpret_cast<const uint4*>(a.binning_base + a.frame_in[GCR_FRAME_WORK_OFF]);
+  const uint16_t* __restrict__ masks = reinterpret_cast<const uint16_t*>(a.binning_base + a.frame_in[GCR_FRAME_MASK_OFF]);
+  const int lane = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's quadrant of the tile
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const int acc_slot = GCR_K7_ROW_SLOT;
+  const float bg0 = GCR_CAM(a, bg, a.bg, 0), bg1 = GCR_CAM(a, bg, a.bg, 1), bg2 = GCR_CAM(a, bg, a.bg, 2);
+  const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
+  const char* const sEb = reinterpret_cast<const char*>(sE);
+  char* const acc_base = reinterpret_cast<char*>(&sAcc[acc_slot >= 0 ? acc_slot : 0]);
+  if (tid == 0) {
+    sE[IPASS].a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    sE[IPASS].b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    sE[IPASS].c = make_float4(0.0f, __builtin_inff(), __uint_as_float(NO_ENTRY), 0.0f);
+  }
+
+  bool first = true;
+  for (unsigned long long item = (unsigned long long)blockIdx.x - (unsigned long long)a.fill.blocks; item < nitems;
+       item += (unsigned long long)gridDim.x - (unsigned long long)a.fill.blocks) {
+    uint4 d = work[item];
+    asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));  // one 16-byte load (see k_blend_bwd)
+    if (d.x == GCR_NO_TILE) continue;  // workgroup-uniform
+    if (!first) __syncthreads();       // (a second item only when the forward used a smaller piece than the host expects)
+    first = false;
+    const int tile = (int)d.x;
+    const uint32_t r0 = d.y, len = d.z, kpiece = d.w;
+    const uint32_t npieces = gcr_piece_count(len, piece_P), cs = gcr_piece_size(len, piece_P);
+    const uint32_t lo = kpiece * cs, hi = min(len, lo + cs);  // the piece: list entries [lo, hi), walked back to front
+    const int n = (int)min(hi - lo, (uint32_t)IPASS);         // (cs <= piece_P <= 223)
+    const uint32_t sbase = r0 / piece_P + (uint32_t)tile;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const LaneGeom g = lane_geom(tid, tx, ty);
+    const bool inside = g.pxi < a.W && g.pyi < a.H;
+    const float pixx = (float)g.pxi, pixy = (float)g.pyi;
+    const size_t pix_id = (size_t)a.W * g.pyi + g.pxi;
+
+    // ---- prologue: every load below is independent of the others
+    const bool hv = tid < n;
+    const uint32_t e_t = hi - 1u - (uint32_t)(hv ? tid : 0);  // staging slot `tid` holds list entry hi - 1 - tid
+    const uint32_t m16 = hv ? (uint32_t)masks[r0 + e_t] : 0u;
+    const uint32_t id = hv ? a.list[r0 + e_t] : 0u;
+    const float T_final = inside ? a.final_T[pix_id] : 0.0f;
+    const uint32_t last_contributor = inside ? a.n_contrib[pix_id] : 0u;
+    float dLp0 = 0.0f, dLp1 = 0.0f, dLp2 = 0.0f;
+    if (inside) {
+      size_t iplane;
+      const long long in_id = gcr_out_index(a, g.pxi, g.pyi, &iplane);
+      if (in_id >= 0) {
+        dLp0 = a.dL_dpix[in_id];
+        dLp1 = a.dL_dpix[iplane + in_id];
+        dLp2 = a.dL_dpix[2 * iplane + in_id];
+      }
+    }
+    float4 ck = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cf = ck;
+    if (kpiece + 1u < npieces) {  // the list goes on behind this piece
+      ck = ckpt[(size_t)(sbase + kpiece) * 256u + (uint32_t)tid];
+      cf = ckpt[(size_t)(sbase + npieces - 1u) * 256u + (uint32_t)tid];
+    }
+    // the accumulators of this item's entries start at zero (stores, no wait)
+    for (int k = tid; k < n * 9; k += 256) sAcc[k] = 0.0f;
+
+    // ---- the entry's record, gathered once for the whole tile
+    if (m16 != 0u) {
+      const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
+      const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+      sE[tid].a = q0;
+      sE[tid].b = q1;
+      sE[tid].c = make_float4(q2.x, gcr_alpha_skip_bound(q1.y), __uint_as_float(e_t), __uint_as_float((uint32_t)tid * 36u));
+      sId[tid] = id;
+    }
+    sMask[tid] = (uint16_t)m16;
+
+    float bg_dot_dpixel = 0;
+    bg_dot_dpixel += bg0 * dLp0;
+    bg_dot_dpixel += bg1 * dLp1;
+    bg_dot_dpixel += bg2 * dLp2;
+    uint32_t row_max = last_contributor;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const uint32_t t = __shfl_xor(row_max, o, 64);
+      row_max = t > row_max ? t : row_max;
+    }
+    uint32_t rmax[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) rmax[rr] = __shfl(row_max, rr * 16, 64);
+    const uint32_t wave_max = max(max(rmax[0], rmax[1]), max(rmax[2], rmax[3]));
+
+    float T = T_final;
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;  // accum_rec; start state as in k_blend_bwd
+    if (last_contributor > hi) {
+      T = ck.x;
+      acc0 = (cf.y - ck.y) / ck.x;
+      acc1 = (cf.z - ck.z) / ck.x;
+      acc2 = (cf.w - ck.w) / ck.x;
+    }
+    const float neg_T_final = -T_final;
+    float last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;
+    __syncthreads();  // records, masks, zeroed accumulators
+
+    if (wave_max > lo && GCR_PASSES_ON) {  // wave-uniform: else this quadrant consumed nothing of the piece
+      // the four row lists: block bit set and list entry below the row's max n_contrib (slot order = walk order)
+      uint16_t* const lw = &sList[q][0][0];
+      int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (k * 64 < n) {  // wave-uniform
+          const int j = k * 64 + lane;
+          const uint32_t m = (uint32_t)sMask[j];  // (0 for slots >= n)
+          const uint32_t e_j = hi - 1u - (uint32_t)j;
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const bool rel = ((m >> g.bit[rr]) & 1u) && e_j < rmax[rr];
+            const uint64_t bal = __ballot(rel);
+            if (rel) lw[rr * ILIST_STRIDE + cnt[rr] + __popcll(bal & lt_mask)] = (uint16_t)(j * (int)ENTRY_BYTES);
+            cnt[rr] += __popcll(bal);
+          }
+        }
+      }
+      const int maxcnt = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+        for (int s = cnt[rr] + lane; s < maxcnt + 3; s += 64) lw[rr * ILIST_STRIDE + s] = (uint16_t)ISENT_OFF;
+      __builtin_amdgcn_wave_barrier();
+
+      // software pipeline, two entries per trip (see K6)
+      const uint16_t* lp = &sList[q][g.row][0];
+      float4 qa0, qb0, qc0, qa1, qb1, qc1;
+      uint32_t e0 = lp[0], e1 = lp[1];
+      GCR_BWD_LOAD(qa0, qb0, qc0, e0)
+      for (int i = 0; i < maxcnt; i += 2, lp += 2) {
+        GCR_BWD_LOAD(qa1, qb1, qc1, e1)
+        e0 = lp[2];
+        GCR_BWD_STEP(qa0, qb0, qc0)
+        if (i + 1 >= maxcnt) break;
+        GCR_BWD_LOAD(qa0, qb0, qc0, e0)
+        e1 = lp[3];
+        GCR_BWD_STEP(qa1, qb1, qc1)
+      }
+    }
+    __syncthreads();  // every wave's row sums are in the accumulators
+    // flush: 16 entries per trip, nine adjacent lanes each -> one 64-byte record update per (entry, piece)
+    {
+      const int comp = tid & 15;
+      const int rec_idx = comp < 3 ? comp : (comp == 8 ? 3 : comp + 1);  // record layout: gcr_internal.h
+      if (comp < 9 && GCR_FLUSH_ON) {
+        for (int i = tid >> 4; i < n; i += 16) {
+          const float v = sAcc[i * 9 + comp];
+          if (v != 0.0f) atomicAdd(&a.grad_rec[(size_t)sId[i] * GCR_GRAD_REC_FLOATS + rec_idx], v);
+        }
+      }
+    }
+  }
+}
+
 #undef GCR_BWD_STEP
 #undef GCR_BWD_LOAD
 
 }  // namespace
 
-template <bool FAST_EXP, bool SORT>
+template <bool SORT>
 static void launch_blend_fwd_state(const GcrBlendArgs& a, int T, hipStream_t s) {
   size_t pad = 0;
-#ifdef GCR_EXPERIMENTS  // unused dynamic LDS: fewer blend workgroups per CU (7 by default), room for another frame's kernels
+#ifdef GCR_EXPERIMENTS  // unused dynamic LDS: fewer blend workgroups per CU (8 by default), room for another frame's kernels
   if (const char* e = getenv("GCR_K6_LDS_PAD")) pad = (size_t)atoll(e);
 #endif
   if (a.work != nullptr)  // the backward's state is wanted (gcr_camera.backward == 1, or gcr_backward's regeneration pass)
-    k_blend_fwd<FAST_EXP, SORT, true><<<T, 256, pad, s>>>(a);
+    k_blend_fwd<SORT, true><<<T, 256, pad, s>>>(a);
   else
-    k_blend_fwd<FAST_EXP, SORT, false><<<T, 256, pad, s>>>(a);
+    k_blend_fwd<SORT, false><<<T, 256, pad, s>>>(a);
 }
 
-hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool fast_exp, bool sort_in_kernel, hipStream_t s) {
+hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool sort_in_kernel, hipStream_t s) {
   const int T = a.gx * a.gy;
   if (T <= 0) return hipSuccess;
-  if (sort_in_kernel) {
-    if (fast_exp)
-      launch_blend_fwd_state<true, true>(a, T, s);
-    else
-      launch_blend_fwd_state<false, true>(a, T, s);
-  } else {
-    if (fast_exp)
-      launch_blend_fwd_state<true, false>(a, T, s);
-    else
-      launch_blend_fwd_state<false, false>(a, T, s);
-  }
+  if (sort_in_kernel)
+    launch_blend_fwd_state<true>(a, T, s);
+  else
+    launch_blend_fwd_state<false>(a, T, s);
   return hipGetLastError();
 }
 
-hipError_t gcr_launch_blend_bwd(const GcrBlendArgs& a, bool fast_exp, hipStream_t s) {
+hipError_t gcr_launch_blend_bwd(const GcrBlendArgs& a, bool wave_units, hipStream_t s) {
   const int T = a.gx * a.gy;
   if (T <= 0) return hipSuccess;
-  // one wave per (work item, quadrant) for the piece size the host expects the forward to have used; the number of
-  // items is only known on the device, the slot count bounds it
-  unsigned long long units = 4ull * gcr_piece_slots(a.R, (unsigned long long)T, (unsigned long long)a.piece);
+  // one workgroup per work item (or one wave per (item, quadrant)) for the piece size the host expects the forward to
+  // have used; the number of items is only known on the device, the slot count bounds it
+  unsigned long long items = gcr_piece_slots(a.R, (unsigned long long)T, (unsigned long long)a.piece);
+  if (wave_units || a.deterministic) {
+    unsigned long long units = (4ull * items + 31ull) & ~31ull;
 #ifdef GCR_EXPERIMENTS
-  if (const char* env = getenv("GCR_K7_BLOCKS")) units = (unsigned long long)atoll(env);
+    if (const char* env = getenv("GCR_K7_BLOCKS")) units = (unsigned long long)atoll(env);
 #endif
-  const unsigned int grid = (unsigned int)(units > 0x3fffffffull ? 0x3fffffffull : units) + (unsigned int)a.fill.blocks;
-  if (fast_exp)
-    k_blend_bwd<true><<<grid, 64, 0, s>>>(a);
-  else
-    k_blend_bwd<false><<<grid, 64, 0, s>>>(a);
+    const unsigned int grid = (unsigned int)(units > 0x3fffffe0ull ? 0x3fffffe0ull : units) + (unsigned int)a.fill.blocks;
+    k_blend_bwd<<<grid, 64, 0, s>>>(a);
+  } else {
+    GcrBlendArgs b = a;
+    b.fill.blocks = (a.fill.blocks + 3) / 4;  // the same number of filling threads in 256-thread workgroups
+    const unsigned int grid = (unsigned int)(items > 0x3fffffffull ? 0x3fffffffull : items) + (unsigned int)b.fill.blocks;
+    k_blend_bwd_item<<<grid, 256, 0, s>>>(b);
+  }
   return hipGetLastError();
 }

@@ -64,9 +64,6 @@ GCR_DEV float gcr_expf(float x) {
 // exp -> 0 -> alpha = 0 < 1/255 -> skipped).  Bit-identical to gcr_expf on that domain.
 GCR_DEV float gcr_expf_noguard(float x) { return gcr_expf_core(x); }
 
-// Non-parity variant (option "fast_exp"): hardware v_exp_f32, ~1 ulp, NOT bit-reproducible.
-GCR_DEV float gcr_expf_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-
 // power = -0.5f*(a*dx*dx + c*dy*dy) - b*dx*dy   (cr/forward.cu:309-310, cr/backward.cu:520-521)
 // with the explicit-FMA sites of gcr-fp32-v1.
 GCR_DEV float gcr_power(float cx, float cy, float cz, float dx, float dy) {

@@ -273,8 +273,9 @@ hipError_t gcr_launch_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v
 int gcr_sort_passes(int end_bit);
 hipError_t gcr_launch_tile_ranges(const uint64_t* keys, int64_t R, uint32_t* ranges, int T,
                                   hipStream_t s);
-hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool fast_exp, bool sort_in_kernel, hipStream_t s);
-hipError_t gcr_launch_blend_bwd(const GcrBlendArgs& a, bool fast_exp, hipStream_t s);
+hipError_t gcr_launch_blend_fwd(const GcrBlendArgs& a, bool sort_in_kernel, hipStream_t s);
+// wave_units: one wave per (work item, quadrant) [round 4; always in the deterministic mode] instead of one workgroup per item
+hipError_t gcr_launch_blend_bwd(const GcrBlendArgs& a, bool wave_units, hipStream_t s);
 hipError_t gcr_launch_preprocess_bwd(const GcrPreprocessBwdArgs& a, hipStream_t s);
 
 // cr/rasterizer_impl.cu:35-48

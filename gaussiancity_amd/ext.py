@@ -102,38 +102,47 @@ _RING = 32  # asynchronous frames a host thread may have outstanding (the ring's
 # H): the host runs ahead of the device, so that number may be a few frames old -- twice it, plus a constant
 _ASYNC_FACTOR, _ASYNC_MARGIN = 2, 65536
 _SYNC_ONLY = os.environ.get("GCR_EXT_SYNC") == "1"  # measurement aid: keep the reference's host wait in every frame
+_guess_hook = None  # fault injection (tests/test_gpu_async.py): callable(key, capacity) -> capacity of the next asynchronous frame
 
 
 class FrameTicket:
     """Lazy num_rendered of one frame.  int(ticket) / ticket.wait() block until the device has published it (and, for a
-    frame that overflowed its capacity guess, until the library's rescue has re-rendered it); .done() never blocks."""
+    frame that overflowed its capacity guess, until the library's rescue has re-rendered it); .done() never blocks.
+    A frame that FAILED (overflow of the 32-bit instance index, a rescue that failed or was not there in time) raises
+    from ITS OWN wait() / int() -- every time -- and from nowhere else: the ring and the hint table treat it as
+    resolved, so one lost frame does not take the thread's later frames with it."""
 
-    __slots__ = ("words", "addr", "seq", "capacity", "stream", "key", "stateful", "_R", "_longest", "_lib")
+    __slots__ = ("words", "addr", "seq", "capacity", "stream", "key", "stateful", "_R", "_longest", "_lib", "_err")
 
     def __init__(self, lib, words, addr, seq, capacity, stream, key, stateful, R=None, longest=0):
         self._lib, self.words, self.addr, self.seq, self.capacity = lib, words, addr, seq, capacity
         self.stream, self.key, self.stateful = stream, key, stateful
-        self._R, self._longest = R, longest
+        self._R, self._longest, self._err = R, longest, None
 
     def _resolve(self, block):
-        if self._R is not None:
+        """True once the ticket is resolved (successfully or not); never raises."""
+        if self._R is not None or self._err is not None:
             return True
-        v = self.words[0]
-        if (v >> 32) != self.seq or (v & 0xFFFFFFFF) > self.capacity:  # not yet / overflow: the library's protocol
-            info = N.FrameInfo()
-            if block:
-                rc = N.check(self._lib.gcr_ticket_wait(self.addr, self.seq, self.capacity, self.stream, C.byref(info)),
-                             "gcr_ticket_wait")
+        try:
+            v = self.words[0]
+            if (v >> 32) != self.seq or (v & 0xFFFFFFFF) > self.capacity:  # not yet / overflow: the library's protocol
+                info = N.FrameInfo()
+                if block:
+                    rc = N.check(self._lib.gcr_ticket_wait(self.addr, self.seq, self.capacity, self.stream, C.byref(info)),
+                                 "gcr_ticket_wait")
+                else:
+                    rc = N.check(self._lib.gcr_ticket_poll(self.addr, self.seq, self.capacity, C.byref(info)),
+                                 "gcr_ticket_poll")
+                if rc != 0:
+                    return False
+                self._R, self._longest = int(info.num_rendered), int(info.max_tile_instances)
             else:
-                rc = N.check(self._lib.gcr_ticket_poll(self.addr, self.seq, self.capacity, C.byref(info)), "gcr_ticket_poll")
-            if rc != 0:
-                return False
-            self._R, self._longest = int(info.num_rendered), int(info.max_tile_instances)
-        else:
-            if (v & 0xFFFFFFFF) > 0x7FFFFFFF:
-                raise RuntimeError("num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)")
-            self._R, self._longest = int(v & 0xFFFFFFFF), int(self.words[1])
-        if self.key is not None and self._R > 0:
+                if (v & 0xFFFFFFFF) > 0x7FFFFFFF:
+                    raise RuntimeError("num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)")
+                self._R, self._longest = int(v & 0xFFFFFFFF), int(self.words[1])
+        except RuntimeError as e:
+            self._err = e
+        if self._err is None and self.key is not None and self._R > 0:
             _hint_put(self.key, (self._R, self._longest))
         self.words = None  # the ring slot may be reused
         return True
@@ -141,8 +150,15 @@ class FrameTicket:
     def done(self):
         return self._resolve(False)
 
+    @property
+    def failed(self):
+        """The frame's error once the ticket is resolved (None: rendered, or not resolved yet)."""
+        return self._err
+
     def wait(self):
         self._resolve(True)
+        if self._err is not None:
+            raise RuntimeError(str(self._err))
         return self._R
 
     @property
@@ -155,11 +171,13 @@ class FrameTicket:
     __index__ = wait
 
     def __repr__(self):
-        return "FrameTicket(%s)" % (self._R if self._R is not None else "pending")
+        return "FrameTicket(%s)" % ("failed" if self._err is not None else self._R if self._R is not None else "pending")
 
 
 class _TicketRing:
-    """Per host thread: _RING sets of eight pinned host words (gcr_host_words_alloc) handed out round-robin."""
+    """Per host thread: _RING sets of eight pinned host words (gcr_host_words_alloc) handed out round-robin.  The block
+    is given back when the thread ends (the ring lives in a threading.local): what is still unresolved then is waited
+    for first, so neither a device store nor the library's rescue thread meets unmapped memory."""
 
     def __init__(self, lib):
         self.lib = lib
@@ -177,7 +195,7 @@ class _TicketRing:
         self.next = (i + 1) % _RING
         old = self.tickets[i]
         if old is not None:
-            old.wait()  # back-pressure: at most _RING frames of this thread are unresolved
+            old._resolve(True)  # back-pressure: at most _RING frames of this thread are unresolved (its error stays its own)
         self.seq = (self.seq % 0xFFFFFFFE) + 1  # never 0
         return i, self.words[i], self.base + 8 * N.TICKET_WORDS * i, self.seq
 
@@ -187,10 +205,25 @@ class _TicketRing:
         while p and p[0].done():
             p.popleft()
 
+    def close(self):
+        base, self.base = self.base, None
+        if not base:
+            return
+        try:
+            for t in self.tickets:
+                if t is not None:
+                    t._resolve(True)
+            self.lib.gcr_host_words_free(base)
+        except Exception:  # noqa: BLE001  (interpreter shutdown: the process is going away with the block)
+            pass
+
+    def __del__(self):
+        self.close()
+
 
 def _ring(lib):
     r = getattr(_tls, "ring", None)
-    if r is None:
+    if r is None or r.base is None:
         r = _tls.ring = _TicketRing(lib)
     return r
 
@@ -364,6 +397,8 @@ def _forward(L, device, cam, g, P, H, W, ticket=False):
         # The guess is made from a frame that may be several frames old (the host runs ahead of the device): twice its
         # num_rendered.  A frame that still does not fit is rendered correctly by the library's rescue (include/gcr.h).
         capacity = _ASYNC_FACTOR * R_seen + _ASYNC_MARGIN
+        if _guess_hook is not None:
+            capacity = max(1, int(_guess_hook(key, capacity)))
         binning = torch.empty((nbytes(capacity, W, H),), **byte)
         slot, words, addr, seq = ring.take()
         N.check(L.gcr_forward_async(C.byref(cam), C.byref(g), geom.data_ptr(), gbytes, binning.data_ptr(), binning.numel(),

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GCR_ABI_VERSION 6
+#define GCR_ABI_VERSION 7
 #define GCR_BLOCK_X 16 /* cr/config.h:16 */
 #define GCR_BLOCK_Y 16 /* cr/config.h:17 */
 #define GCR_NUM_CHANNELS 3 /* cr/config.h:15 */
@@ -59,12 +59,11 @@ typedef enum gcr_status {
   GCR_ERR_ALLOC = -5             /* a resize callback returned NULL */
 } gcr_status;
 
-/* Per-call options (ABI v6).  Every field: -1 = the process-wide default (gcr_set_option), >= 0 = this call's value.
+/* Per-call options (ABI v6; v7: "fast_exp" is gone, "bwd_wave_units" added at the end).  Every field: -1 = the process-wide default (gcr_set_option), >= 0 = this call's value.
  * The reference's entry points are re-entrant and carry no global state (dgr/rasterize_points.cu:37-93); with this
  * record two host threads can render with different options at the same time.  The forward and the backward of one
  * frame must be given the same values (as with the process-wide knobs).  Meanings: see gcr_set_option below. */
 typedef struct gcr_options {
-  int32_t fast_exp;
   int32_t lazy_sort;
   int32_t sort_in_blend;
   int32_t bwd_piece;
@@ -72,6 +71,7 @@ typedef struct gcr_options {
   int32_t split_preprocess;
   int32_t force_radix;
   int32_t force_global_cursor;
+  int32_t bwd_wave_units;
 } gcr_options;
 #define GCR_OPTIONS_DEFAULT {-1, -1, -1, -1, -1, -1, -1, -1}
 
@@ -270,14 +270,19 @@ int gcr_forward(const gcr_camera *cam, const gcr_gaussians *g, void *geom, size_
  *   binning_capacity  > 0: the caller's guess of num_rendered; `binning` holds gcr_binning_bytes(binning_capacity)
  *               (gcr_binning_bytes_lean(binning_capacity) suffices when cam->backward == 0)
  * When num_rendered turns out larger than binning_capacity the frame is still rendered correctly, IN STREAM ORDER:
- * the frame ends with a one-wave gate kernel that returns at once for a frame that fitted and otherwise holds the
- * stream until a rescue thread of the library (started by the first asynchronous call) has rendered the frame on a
- * stream of its own with a temporary, exactly sized binning buffer (hipMalloc / hipFree, the one place the library
- * allocates device memory) -- so whatever the caller enqueued behind the frame sees the right image.  The state of
- * such a frame is NOT in the caller's `binning` buffer: before gcr_backward, call gcr_forward_render with
+ * the first thread of the frame's last kernel (the forward blend) is a gate that a frame that fitted never reaches
+ * and that otherwise holds the stream until a rescue thread of the library (started by the first asynchronous call)
+ * has rendered the frame on a high-priority stream of its own with a temporary, exactly sized binning buffer
+ * (hipMalloc / hipFree, the one place the library allocates device memory) -- so whatever the caller enqueued behind
+ * the frame sees the right image.  The gate waits about two seconds (option "gate_polls") for a rescue to START; a
+ * gate that gives up lets the stream go on with an unrendered image and the ticket resolves to GCR_ERR_DEVICE; a rescue
+ * that comes later than that touches nothing.  Once a rescue has started the gate waits for it sixteen times as long.
+ * The state of a rescued frame is NOT in the caller's `binning` buffer: before gcr_backward, call gcr_forward_render with
  * out_color == NULL and a buffer of gcr_binning_bytes(num_rendered).  Until the ticket is resolved the caller keeps
  * geom / img / radii / out_color and the Gaussians' arrays alive or releases them stream-ordered on `hip_stream`
- * (torch's caching allocator does): the rescue reads them while the gate holds that stream.
+ * (torch's caching allocator does): the rescue reads and writes them only while the gate holds that stream.
+ * fork(): the child starts without a rescue thread and without outstanding frames (pthread_atfork handler); it must
+ * initialise HIP itself, as with any HIP library.
  * Returns 0, or < 0 on an argument / launch error (nothing useful was enqueued). */
 unsigned long long *gcr_host_words_alloc(size_t n_words); /* pinned, coherent, zero-filled; NULL on failure */
 void gcr_host_words_free(unsigned long long *words);
@@ -294,6 +299,7 @@ int gcr_ticket_poll(const unsigned long long *words_host, uint32_t seq, int64_t 
 int gcr_ticket_wait(const unsigned long long *words_host, uint32_t seq, int64_t binning_capacity,
                     void *hip_stream, gcr_frame_info *info_host);
 long gcr_rescue_count(void); /* diagnostics: asynchronous frames of this process that needed the rescue so far */
+long gcr_rescue_dropped_count(void); /* ... and calls for help that were not answered before their gate gave up */
 
 /* K3 (instance emit) + K4 (depth sort inside every tile, ties in ascending Gaussian index ==
  * the reference's stable radix sort by tile|depth) + K5 (tile ranges) + K6 (blend).
@@ -332,7 +338,6 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
 
 /* Process-wide DEFAULTS of the per-call gcr_options (the shipping/parity configuration unless changed; a call that
  * carries gcr_camera.options overrides them for itself only):
- *   "fast_exp"     1: v_exp_f32 in the blend kernels (NOT bit-reproducible)          default 0
  *   "force_radix"  1: always use the global LSD radix sort path for binning          default 0
  *   "force_global_cursor" 1: count/scatter with device-scope atomics instead of LDS  default 0
  *                     tile tables (the variant used when T*4 B does not fit in LDS)
@@ -351,9 +356,19 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *                     as the forward blend walks them (saturating scenes never read most of a long list); the entries
  *                     behind the last one consumed stay unsorted (gcr_layout.img_tile_lazy says how far the order is
  *                     final).  0: every list is sorted whole, as the reference does.
+ *   "bwd_wave_units" 1: the backward blend runs as one wave per (work item, 8x8 quadrant) -- round 4's    default 0
+ *                     kernel, and always the deterministic mode's -- instead of one workgroup per (tile, piece) work
+ *                     item that gathers a piece's records once for the tile's four quadrant waves and leaves one
+ *                     record update per (entry, piece) (A/B)
  *   "timing"       1: record per-stage HIP events (see gcr_get_stage_ms)             default 0
- * Returns the previous value or <0 if the name is unknown. */
+ *   "gate_polls"   polls (about 5 us each) a frame gate waits for an overflow rescue to START before it       default 400000
+ *                     gives up and the ticket resolves to GCR_ERR_DEVICE (gcr_forward_async)
+ *   "rescue_hold"  1: the rescue thread answers no call for help (test hook for the gate's timeout path)     default 0
+ * Returns the previous value or <0 if the name is unknown.  (The v_exp_f32 mode "fast_exp" of ABI <= 6 is gone: on the
+ * round-4 forward blend it was slower than the bit-exact exponential it replaced.) */
 int gcr_set_option(const char *name, int value);
+/* The current process-wide value of an option, without changing it (ABI v7); INT32_MIN if the name is unknown. */
+int gcr_get_option(const char *name);
 
 /* Average per-stage device time (ms) on this thread since the previous call,
  * measured with hipEvents on the caller's stream (non-blocking) when gcr_set_option("timing",1).

@@ -15,12 +15,14 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libgcr_oracle.so")
+_SO64 = os.path.join(_HERE, "_build", "libgcr_oracle_f64.so")  # the same statements in binary64 (gcr_oracle.c, ORC_F64)
 
 
 def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     src = os.path.join(_HERE, "gcr_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    if (force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src)
+            or not os.path.exists(_SO64) or os.path.getmtime(_SO64) < os.path.getmtime(src)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -33,6 +35,10 @@ class _Camera(C.Structure):
         ("bg", C.c_void_p), ("view_matrix", C.c_void_p),
         ("proj_matrix", C.c_void_p), ("campos", C.c_void_p),
     ]
+
+
+class _Camera64(C.Structure):
+    _fields_ = [(n, C.c_double if t is C.c_float else t) for n, t in _Camera._fields_]
 
 
 class _Gaussians(C.Structure):
@@ -65,6 +71,27 @@ class _Grads(C.Structure):
 
 
 _lib = None
+_lib64 = None
+
+
+def lib64():
+    """The binary64 build (Frame64): a rounding-noise yardstick for tools/, never a parity target."""
+    global _lib64
+    if _lib64 is None:
+        build()
+        L = C.CDLL(_SO64)
+        L.orc_preprocess.restype = C.c_int64
+        L.orc_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_bin.restype = None
+        L.orc_bin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.orc_render.restype = None
+        L.orc_render.argtypes = [C.c_void_p] * 6
+        L.orc_render_backward.restype = None
+        L.orc_render_backward.argtypes = [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]
+        L.orc_preprocess_backward.restype = None
+        L.orc_preprocess_backward.argtypes = [C.c_void_p] * 4
+        _lib64 = L
+    return _lib64
 
 
 def lib():
@@ -111,10 +138,22 @@ def _ptr(a):
 class Frame:
     """One forward pass through the oracle; keeps every intermediate for stage-wise parity."""
 
+    FT = np.float32        # Frame64 below: np.float64 + the ORC_F64 build
+    _camera_t = _Camera
+    _lib_fn = staticmethod(lambda: lib())
+
+    @classmethod
+    def _f(cls, a, shape=None):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(np.asarray(a, dtype=cls.FT))
+        return a.reshape(shape) if shape is not None else a
+
     def __init__(self, *, img_h, img_w, tanfovx, tanfovy, bg, scale_modifier, view_matrix,
                  proj_matrix, sh_degree, campos, means3D, opacities, shs=None,
                  colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
-        L = lib()
+        L = self._lib_fn()
+        _f32, FT = self._f, self.FT
         self.H, self.W = int(img_h), int(img_w)
         self.means3D = _f32(means3D, (-1, 3))
         P = self.P = self.means3D.shape[0]
@@ -129,20 +168,20 @@ class Frame:
         self.view = _f32(view_matrix, (16,))
         self.proj = _f32(proj_matrix, (16,))
         self.campos = _f32(campos, (3,))
-        self.cam = _Camera(self.H, self.W, float(tanfovx), float(tanfovy), float(scale_modifier),
+        self.cam = self._camera_t(self.H, self.W, float(tanfovx), float(tanfovy), float(scale_modifier),
                            int(sh_degree), _ptr(self.bg), _ptr(self.view), _ptr(self.proj),
                            _ptr(self.campos))
         self.g = _Gaussians(P, self.M, _ptr(self.means3D), _ptr(self.opacities), _ptr(self.shs),
                             _ptr(self.colors_precomp), _ptr(self.scales), _ptr(self.rotations),
                             _ptr(self.cov3D_precomp))
         n = max(P, 1)
-        self.depths = np.zeros(n, np.float32)
+        self.depths = np.zeros(n, FT)
         self.clamped = np.zeros((n, 3), np.uint8)
         self.radii = np.zeros(n, np.int32)
-        self.means2D = np.zeros((n, 2), np.float32)
-        self.cov3D = np.zeros((n, 6), np.float32)
-        self.conic_opacity = np.zeros((n, 4), np.float32)
-        self.rgb = np.zeros((n, 3), np.float32)
+        self.means2D = np.zeros((n, 2), FT)
+        self.cov3D = np.zeros((n, 6), FT)
+        self.conic_opacity = np.zeros((n, 4), FT)
+        self.rgb = np.zeros((n, 3), FT)
         self.tiles_touched = np.zeros(n, np.uint32)
         self.point_offsets = np.zeros(n, np.uint32)
         self.geo = _Geom(*[_ptr(a) for a in (self.depths, self.clamped, self.radii, self.means2D,
@@ -152,9 +191,9 @@ class Frame:
         T = self.gx * self.gy
         self.ranges = np.zeros((T, 2), np.uint32)
         self.n_contrib = np.zeros(self.H * self.W, np.uint32)
-        self.final_T = np.zeros(self.H * self.W, np.float32)
+        self.final_T = np.zeros(self.H * self.W, FT)
         self.img = _Image(_ptr(self.ranges), _ptr(self.n_contrib), _ptr(self.final_T))
-        self.out_color = np.zeros((3, self.H, self.W), np.float32)
+        self.out_color = np.zeros((3, self.H, self.W), FT)
 
         # K1 + K2
         self.R = int(L.orc_preprocess(C.byref(self.cam), C.byref(self.g), C.byref(self.geo))) if P else 0
@@ -175,15 +214,16 @@ class Frame:
 
     def backward(self, dL_dpix):
         """K7 + K8; returns dict with the reference's eight gradient tensors (+dL_dconic)."""
-        L = lib()
+        L = self._lib_fn()
+        _f32, FT = self._f, self.FT
         P, M = max(self.P, 1), self.M
         dpix = _f32(dL_dpix, (3, self.H, self.W))
         g = dict(
-            dL_dmean2D=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 4), np.float32),
-            dL_dopacity=np.zeros((P, 1), np.float32), dL_dcolor=np.zeros((P, 3), np.float32),
-            dL_dmean3D=np.zeros((P, 3), np.float32), dL_dcov3D=np.zeros((P, 6), np.float32),
-            dL_dsh=np.zeros((P, max(M, 0), 3), np.float32), dL_dscale=np.zeros((P, 3), np.float32),
-            dL_drot=np.zeros((P, 4), np.float32))
+            dL_dmean2D=np.zeros((P, 3), FT), dL_dconic=np.zeros((P, 4), FT),
+            dL_dopacity=np.zeros((P, 1), FT), dL_dcolor=np.zeros((P, 3), FT),
+            dL_dmean3D=np.zeros((P, 3), FT), dL_dcov3D=np.zeros((P, 6), FT),
+            dL_dsh=np.zeros((P, max(M, 0), 3), FT), dL_dscale=np.zeros((P, 3), FT),
+            dL_drot=np.zeros((P, 4), FT))
         gs = _Grads(*[_ptr(g[k]) for k in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor",
                                            "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale",
                                            "dL_drot")])
@@ -206,6 +246,14 @@ class Frame:
                 blk = nc[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16]
                 tot += int(blk.max()) if blk.size else 0
         return tot
+
+
+class Frame64(Frame):
+    """The same statements evaluated in binary64 (gcr_oracle.c built with -DORC_F64): how far is the binary32 oracle from
+    the exact value of the reference's formulas on THIS scene?  tools/fuzz_f64.py; never a parity target."""
+    FT = np.float64
+    _camera_t = _Camera64
+    _lib_fn = staticmethod(lambda: lib64())
 
 
 def mark_visible(means3D, view_matrix, proj_matrix):

@@ -1,4 +1,4 @@
-"""-m gpu: ABI v6 -- frames without the host wait (gcr_forward_async / FrameTicket), the overflow rescue behind the
+"""-m gpu: ABI v6 / v7 -- frames without the host wait (gcr_forward_async / FrameTicket), the overflow rescue behind the
 frame gate, frames rendered without the backward's state, per-call options from several host threads, and the global
 radix path on a scene with empty tiles.  Everything against the CPU oracle on identical seeded inputs, through the
 native-module surface (ext -> C ABI -> gfx950 kernels)."""
@@ -185,7 +185,7 @@ def test_backward_on_a_frame_without_state_is_binned_again_or_poisoned_never_sil
 
 def test_three_host_threads_with_different_per_call_options(oracle_mod, cuda_device):
     """gcr_options travel with the call (ABI v6): three host threads render and differentiate the same scene at the same
-    time, one with the defaults (bit-exact image), one with fast_exp + 64-entry pieces, one with the deterministic
+    time, one with the defaults (bit-exact image), one with the wave-per-quadrant backward kernel + 64-entry pieces, one with the deterministic
     backward (bit-identical gradients run to run) -- and the process-wide defaults are what they were."""
     from gaussiancity_amd import _native as N, ext
     P, W, H, seed = 9000, 96, 80, 41
@@ -209,19 +209,16 @@ def test_three_host_threads_with_different_per_call_options(oracle_mod, cuda_dev
         except Exception as e:  # noqa: BLE001
             errs.append((name, repr(e)))
 
-    th = [threading.Thread(target=worker, args=a) for a in (("default", {}, 4), ("fast", dict(fast_exp=1, bwd_piece=64), 4),
+    th = [threading.Thread(target=worker, args=a) for a in (("default", {}, 4), ("waves", dict(bwd_wave_units=1, bwd_piece=64), 4),
                                                             ("det", dict(deterministic_backward=1), 4))]
     for t in th:
         t.start()
     for t in th:
         t.join()
     assert not errs, errs
-    for img, _ in res["default"]:
-        assert np.array_equal(img.view(np.uint32), fr.out_color.view(np.uint32))
-    tol = GRAD_TOL * max(1.0, float(np.abs(fr.out_color).max()))
-    for img, _ in res["fast"]:
-        off = np.abs(img - fr.out_color).max(axis=0) > tol
-        assert int(off.sum()) <= 2 and not np.array_equal(img.view(np.uint32), fr.out_color.view(np.uint32))
+    for name in res:
+        for img, _ in res[name]:
+            assert np.array_equal(img.view(np.uint32), fr.out_color.view(np.uint32)), name
     for name in res:
         for _, g in res[name]:
             _check_grads(gref, g, ALL_GRADS)
@@ -229,7 +226,7 @@ def test_three_host_threads_with_different_per_call_options(oracle_mod, cuda_dev
     for _, g in res["det"][1:]:
         for n in ALL_GRADS:
             assert np.array_equal(g[n].view(np.uint32), d0[n].view(np.uint32)), n + " differs between deterministic runs"
-    assert N.lib().gcr_grad_record_floats() == 16 and N.get_option("fast_exp") == 0 and N.get_option("bwd_piece") == 128
+    assert N.lib().gcr_grad_record_floats() == 16 and N.get_option("bwd_wave_units") == 0 and N.get_option("bwd_piece") == 128
 
 
 def test_global_radix_path_on_a_scene_with_empty_tiles(oracle_mod, cuda_device):
@@ -331,3 +328,183 @@ def test_long_lazily_sorted_lists_in_asynchronous_frames(oracle_mod, cuda_device
                                              G.to_dev(dpix, cuda_device), sh, deg, campos, o[3], o[0], o[4], o[5], False)
         _check_grads(gref, {n: x.cpu().numpy() for n, x in zip(names, g)},
                      ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dscale", "dL_drot"])
+
+
+def test_soak_threads_streams_mixed_frames_with_forced_overflows(oracle_mod, cuda_device, monkeypatch):
+    """VERDICT r04 item 7 / ADVICE r04: three host threads x three streams each (nine caller streams + the rescue's) x
+    GCR_SOAK_FRAMES (default 2 000) mixed inference / training frames per thread, the capacity guess of about one frame
+    in twenty cut to 36 instances so that it overflows and needs the rescue -- several at once, from different threads.
+    Every image is compared on the device with the oracle's (bit-exact), a sample of the training frames is
+    differentiated and compared with the oracle's gradients (rescued frames among them: their backward bins again), every
+    ticket resolves, nobody times out."""
+    import os
+    import random
+    from gaussiancity_amd import _native as N, ext
+    nframes = int(os.environ.get("GCR_SOAK_FRAMES", "2000"))
+    W, H = 160, 112
+    cut = {}
+
+    def hook(key, capacity):
+        return 36 if cut.pop(threading.get_ident(), False) else capacity
+
+    monkeypatch.setattr(ext, "_guess_hook", hook)
+    L = N.lib()
+    rescued0, dropped0 = L.gcr_rescue_count(), L.gcr_rescue_dropped_count()
+    scenes_t = []
+    for ti in range(3):
+        P = 3000 + 300 * ti
+        sc = scenes.blob_scene(P, 90 + ti, 1)
+        cams = [scenes.camera(W, H, pose_index=i)._replace(sh_degree=1) for i in (2 + ti, 8 + ti, 14 + ti)]
+        scenes_t.append((P, sc, cams, [_frame(oracle_mod, rs, sc) for rs in cams]))
+    dpix = np.random.default_rng(5).normal(size=(3, H, W)).astype(np.float32)
+    errs, stats = [], []
+
+    def worker(ti):
+        try:
+            torch.cuda.set_device(cuda_device)
+            P, sc, cams, frames = scenes_t[ti]
+            rng = random.Random(1000 + ti)
+            streams = [torch.cuda.Stream(device=cuda_device) for _ in range(3)]
+            argsets = [_args(rs, sc, cuda_device) for rs in cams]
+            want = [torch.from_numpy(fr.out_color.view(np.int32)).to(cuda_device) for fr in frames]
+            dp = G.to_dev(dpix, cuda_device)
+            grefs = [None] * len(cams)
+            bad = torch.zeros((), dtype=torch.int64, device=cuda_device)
+            torch.cuda.synchronize()
+            tickets, n_over, n_bwd = [], 0, 0
+            for f in range(nframes):
+                k = rng.randrange(len(cams))
+                train = rng.random() < 0.25
+                over = f > 3 and rng.random() < 0.05
+                if over:
+                    cut[threading.get_ident()] = True
+                st = streams[rng.randrange(3)]
+                with torch.cuda.stream(st):
+                    out = ext.rasterize_gaussians_ticket(*argsets[k], _for_backward=train)
+                    bad += (out[1].view(torch.int32) != want[k]).any()   # enqueued behind the frame (and its gate)
+                    n_over += int(over and out[0].seq != 0)
+                    tickets.append((out[0], k))
+                    if train and rng.random() < 0.04:   # a sample of the backward passes, rescued frames included
+                        (bg, m3, col, opa, scl, rot, smod, cov, view, proj, tfx, tfy, h, w, sh, deg, campos, _, _) = argsets[k]
+                        g = ext.rasterize_gaussians_backward(bg, m3, out[2], col, scl, rot, smod, cov, view, proj, tfx, tfy,
+                                                             dp, sh, deg, campos, out[3], out[0], out[4], out[5], False)
+                        if grefs[k] is None:
+                            grefs[k] = frames[k].backward(dpix)
+                        names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
+                        _check_grads(grefs[k], {n: x.cpu().numpy() for n, x in zip(names, g)},
+                                     ["dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"])
+                        n_bwd += 1
+                if len(tickets) > 64:   # resolve in the background, as a frame loop that logs num_rendered would
+                    t, kk = tickets.pop(0)
+                    assert int(t) == frames[kk].R
+            for t, kk in tickets:
+                assert int(t) == frames[kk].R
+            for st in streams:
+                st.synchronize()
+            assert int(bad.item()) == 0, "%d frames of thread %d differ from the oracle" % (int(bad.item()), ti)
+            stats.append((ti, n_over, n_bwd))
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errs.append((ti, repr(e), traceback.format_exc()))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    torch.cuda.synchronize()
+    forced = sum(s[1] for s in stats)
+    assert L.gcr_rescue_count() - rescued0 == forced, (L.gcr_rescue_count() - rescued0, forced)
+    assert L.gcr_rescue_dropped_count() == dropped0
+    assert forced > (50 if nframes >= 2000 else 0), stats
+    print("soak: %d frames, %d rescued, %d sampled backward passes" % (3 * nframes, forced, sum(s[2] for s in stats)))
+
+
+def test_a_gate_that_times_out_fails_its_own_ticket_and_nothing_else(oracle_mod, cuda_device, monkeypatch):
+    """The gate's timeout path: with the rescue thread held, a frame that overflows is
+    NOT rendered, its gate gives up after `gate_polls`, the stream goes on, and the frame's own ticket -- nobody else's --
+    raises.  The rescue that would come afterwards must not touch the frame's buffers (the stream has long handed them
+    on): it is counted as dropped.  The thread's next frames render as if nothing had happened."""
+    import time
+    from gaussiancity_amd import _native as N, ext
+    P, W, H = 3500, 176, 128
+    rs = scenes.camera(W, H)._replace(sh_degree=2)
+    sc = scenes.blob_scene(P, 71, 2)
+    fr = _frame(oracle_mod, rs, sc)
+    key = (cuda_device.index, P, W, H)
+    a = _args(rs, sc, cuda_device)
+    L = N.lib()
+    out0 = ext.rasterize_gaussians_ticket(*a)   # the key's first frame: synchronous, sets the hint
+    assert int(out0[0]) == fr.R
+    monkeypatch.setattr(ext, "_guess_hook", lambda k, c: 36)
+    rescued0, dropped0 = L.gcr_rescue_count(), L.gcr_rescue_dropped_count()
+    prev_polls = N.set_option("gate_polls", 20000)   # ~0.1-0.2 s instead of ~2 s
+    N.set_option("rescue_hold", 1)
+    try:
+        out = ext.rasterize_gaussians_ticket(*a)
+        t = out[0]
+        assert t.seq != 0 and t.capacity == 36
+        t0 = time.time()
+        torch.cuda.synchronize()                 # returns: the gate gave up, the device is not hung
+        assert time.time() - t0 < 30.0
+        with pytest.raises(RuntimeError, match="not rescued in time"):
+            int(t)
+        assert t.done() and t.failed is not None
+        out[1].fill_(7.0)                        # "the allocator handed the block to somebody else"
+        torch.cuda.synchronize()
+    finally:
+        N.set_option("rescue_hold", 0)
+        N.set_option("gate_polls", prev_polls)
+    monkeypatch.setattr(ext, "_guess_hook", None)
+    deadline = time.time() + 10.0
+    while L.gcr_rescue_dropped_count() == dropped0 and time.time() < deadline:
+        time.sleep(0.01)
+    assert L.gcr_rescue_dropped_count() == dropped0 + 1 and L.gcr_rescue_count() == rescued0
+    time.sleep(0.05)
+    assert bool((out[1] == 7.0).all()), "a rescue that came after its gate had given up wrote into the frame's buffers"
+    with pytest.raises(RuntimeError, match="not rescued in time"):   # the failure stays with its ticket ...
+        t.wait()
+    for _ in range(40):                                               # ... and only there: the ring goes round past it
+        o = ext.rasterize_gaussians_ticket(*a)
+        assert int(o[0]) == fr.R
+    assert np.array_equal(o[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
+    assert ext._capacity_hint[key][0] == fr.R
+
+
+def test_the_ticket_ring_is_given_back_when_its_thread_ends(cuda_device):
+    """Pinned host words are a per-thread ring (ext._TicketRing): a thread that rendered asynchronously and ended must
+    not leave its block mapped -- the frames it left unresolved are waited for first, the library's
+    rescue thread is told to forget the block (gcr_host_words_free), and other threads' frames go on."""
+    import gc
+    import weakref
+    from gaussiancity_amd import ext
+    P, W, H = 2000, 96, 64
+    rs = scenes.camera(W, H)._replace(sh_degree=1)
+    sc = scenes.blob_scene(P, 3, 1)
+    a = _args(rs, sc, cuda_device)
+    first = ext.rasterize_gaussians_ticket(*a)
+    R = int(first[0])
+    seen = {}
+
+    def worker():
+        torch.cuda.set_device(cuda_device)
+        outs = [ext.rasterize_gaussians_ticket(*a) for _ in range(6)]   # the last ones stay unresolved
+        seen["ring"] = weakref.ref(ext._tls.ring)
+        seen["tickets"] = [o[0] for o in outs]
+
+    for _ in range(3):
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+        gc.collect()
+        assert seen["ring"]() is None, "the thread's ring outlived the thread"
+        assert all(x.done() and int(x) == R for x in seen["tickets"])   # resolved by the ring's close()
+    o = ext.rasterize_gaussians_ticket(*a)
+    assert int(o[0]) == R
+    torch.cuda.synchronize()
+    ring = ext._tls.ring   # explicit close is idempotent, a closed ring is replaced on the next frame
+    ring.close()
+    ring.close()
+    ext._tls.ring = None
+    assert int(ext.rasterize_gaussians_ticket(*a)[0]) == R

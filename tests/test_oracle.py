@@ -71,6 +71,36 @@ def test_oracle_matches_dense_float64(oracle_mod, name, deg, mode, bg, seed):
         assert np.abs(ref - got).max() <= 2e-4 * max(1.0, np.abs(ref).max()), kd
 
 
+@pytest.mark.parametrize("name,deg,mode,bg,seed", CASES, ids=[c[0] for c in CASES])
+def test_oracle_statements_in_binary64_equal_the_autograd_formulation(oracle_mod, name, deg, mode, bg, seed):
+    """Round 5: gcr_oracle.c compiled with -DORC_F64 evaluates the SAME statements in binary64 (oracle.Frame64).  Against
+    the float64 autograd formulation -- which shares no code with it and derives its gradients mechanically -- image and
+    every gradient agree to 2e-7 * max (measured 3e-9 .. 7e-8: what the restatement's binary32-rounded literals such as
+    0.3f leave).  The 2e-4 of the binary32 comparison above is therefore rounding, not a slip in the hand-derived backward
+    of cr/backward.cu as restated here; and Frame64 can stand in for the dense formulation on scenes where that one takes
+    hours (tools/fuzz_f64.py)."""
+    W, H, P = 44, 36, 120
+    rs = scenes.camera(W, H, pose_index=seed)._replace(sh_degree=deg, bg=torch.tensor(bg))
+    sc = scenes.blob_scene(P, seed, deg)
+    kw = scenes.settings_kwargs(rs)
+    extra = dict(shs=sc["shs"]) if mode == "sh" else dict(colors_precomp=sc["colors_precomp"])
+    f64 = oracle_mod.Frame64(**kw, means3D=sc["means3D"], opacities=sc["opacities"], scales=sc["scales"],
+                             rotations=sc["rotations"], **extra)
+    f32 = _frame(oracle_mod, rs, sc, mode)
+    dpix = np.random.default_rng(seed).normal(size=(3, H, W)).astype(np.float32)
+    g = f64.backward(dpix)
+    img, radii, gd = _dense(rs, sc, mode, dpix)
+    np.testing.assert_array_equal(radii, f64.radii)
+    np.testing.assert_array_equal(f32.radii, f64.radii)
+    assert f64.out_color.dtype == np.float64 and np.abs(img - f64.out_color).max() < 2e-7
+    pairs = [("means3D", "dL_dmean3D"), ("means2D", "dL_dmean2D"), ("opacities", "dL_dopacity"),
+             ("scales", "dL_dscale"), ("rotations", "dL_drot")]
+    pairs.append(("shs", "dL_dsh") if mode == "sh" else ("colors_precomp", "dL_dcolor"))
+    for kd, ko in pairs:
+        ref, got = gd[kd], g[ko].reshape(gd[kd].shape)
+        assert np.abs(ref - got).max() <= 2e-7 * max(1.0, np.abs(ref).max()), kd
+
+
 def _compare_with_dense(fr, g, img, radii, gd, pairs, max_flip_pixels=0):
     """Oracle (float32, reference association) vs the float64 formulation.  The two may disagree on a discrete
     decision (alpha < 1/255, T < 1e-4, power > 0) at a handful of pixels of a large case -- float32 vs float64

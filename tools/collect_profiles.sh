@@ -95,5 +95,4 @@ for hc in "--host-camera device" "--host-camera reference" "--host-camera closed
 done > $O/${TAG}_bench_inference_loop.jsonl
 python $R/bench.py --config C2 --backward --no-secondary --steps 200 > $O/${TAG}_bench_c2_fwd_bwd.json 2>/dev/null
 python $R/bench.py --steps 20 --no-cpu-baseline --no-secondary > $O/${TAG}_bench_c3_k20.json 2>/dev/null
-python $R/bench.py --fast-exp --no-cpu-baseline > $O/${TAG}_bench_c3_fast_exp.json 2>/dev/null
 echo collected $TAG; ls $O | grep "^${TAG}_"
