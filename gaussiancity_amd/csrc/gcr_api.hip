@@ -1239,6 +1239,7 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   a.frame = R > 0 ? (const unsigned long long*)(gb + L.geom_num_rendered) : nullptr;
   a.binning_bytes = (unsigned long long)binning_bytes;
   a.grad_rec = (const float4*)gr->dL_dconic;
+  a.rec = (const float4*)(gb + L.geom_rec);
   a.deterministic = det;
   a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dcolor = gr->dL_dcolors; a.dL_dopacity = gr->dL_dopacity;
   a.dL_dmean3D = gr->dL_dmeans3D; a.dL_dcov3D = gr->dL_dcov3D; a.dL_dsh = gr->dL_dsh;

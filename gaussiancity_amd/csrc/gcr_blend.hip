@@ -672,15 +672,27 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
 #define GCR_K7_ROW_SLOT ((lane & 15) <= 8 ? (lane & 15) : -1)
 #define GCR_K7_ROW_SUMS const float rsum = gcr_row_reduce_scatter9(v, lane);
 #endif
+// ROUND 5 -- MOMENTS.  cr/backward.cu:540-575 turns dL/dalpha of a (pixel, Gaussian) pair into nine addends.  Six of them
+// are the same number u = G * dL/dalpha times a polynomial in the pixel offset d = (dx, dy):
+//     dL_dopacity += u                          dL_dconic.x += -0.5 o u dx dx        dL_dmean2D.x += -o (cx u dx + cy u dy) W/2
+//                                               dL_dconic.y += -0.5 o u dx dy        dL_dmean2D.y += -o (cz u dy + cy u dx) H/2
+//                                               dL_dconic.w += -0.5 o u dy dy        (o = opacity, c = conic, dL_dG = o dL/dalpha)
+// so the walk accumulates the six MOMENTS  S = sum u, Sx = sum u dx, Sy = sum u dy, Sxx, Sxy, Syy  (6 multiplications per
+// step instead of 20) and the per-Gaussian factors are applied ONCE per Gaussian by the preprocess gradient kernel,
+// which reads the moments from the accumulation record (gcr_internal.h): [0..2] colour sums, [3] S, [4] Sx, [5] Sy,
+// [6] Sxx, [7] Sxy, [8] Syy.  Sums of products are re-associated (within the 1e-4 gradient bar; tools/fuzz_parity.py).
+// The background term's pixel constant -T_final * (bg . dL/dpixel) is formed once per pixel (`nbg`).  The conic the step
+// reads is K6's pre-scaled one (-0.5 cx, -cy, -0.5 cz): `power` in 6 instructions and with the bits -- hence the alpha
+// and skip decisions -- of the forward blend that rendered the frame.
 #define GCR_BWD_STEP(QA, QB, QC)                                                               \
   {                                                                                            \
     const float dx = QA.x - pixx, dy = QA.y - pixy;                                            \
-    const float power_raw = gcr_power(QA.z, QA.w, QB.x, dx, dy);                               \
+    const float power_raw = __builtin_fmaf(QA.w * dx, dy, __builtin_fmaf(QB.x * dy, dy, (QA.z * dx) * dx)); \
     const bool in_range = __float_as_uint(QC.z) < last_contributor && !(power_raw > 0.0f) &&   \
                           !(power_raw < QC.y);                                                 \
     if (GCR_K7_WAVE_SKIP(in_range) && GCR_STEP_ON) { /* else the whole wave skips this step */   \
       const float power = in_range ? power_raw : 0.0f;                                         \
-      const float G = blend_exp(power);                                              \
+      const float G = blend_exp(power);                                                        \
       const float alpha = __builtin_fminf(0.99f, QB.y * G);                                    \
       const bool use = in_range && !(alpha < 1.0f / 255.0f);                                   \
       const float a_eff = use ? alpha : 0.0f;                                                  \
@@ -697,35 +709,37 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
       lc1 = QB.w;                                                                              \
       lc2 = QC.x;                                                                              \
       last_alpha = a_eff;                                                                      \
-      float dL_dalpha = 0.0f;                                                                  \
-      dL_dalpha = __builtin_fmaf(lc0 - acc0, dLp0, dL_dalpha);                                 \
+      float dL_dalpha = (lc0 - acc0) * dLp0;                                                   \
       dL_dalpha = __builtin_fmaf(lc1 - acc1, dLp1, dL_dalpha);                                 \
       dL_dalpha = __builtin_fmaf(lc2 - acc2, dLp2, dL_dalpha);                                 \
-      dL_dalpha *= T;                                                                          \
-      dL_dalpha += (GCR_K7_IEEE_DIV ? neg_T_final / om : neg_T_final * rcp) * bg_dot_dpixel;   \
+      dL_dalpha = GCR_K7_IEEE_DIV ? dL_dalpha * T + nbg / om : __builtin_fmaf(nbg, rcp, dL_dalpha * T); \
       dL_dalpha = use ? dL_dalpha : 0.0f;                                                      \
-      const float dL_dG = QB.y * dL_dalpha;                                                    \
-      const float gdx = G * dx, gdy = G * dy;                                                  \
-      const float dG_ddelx = -gdx * QA.z - gdy * QA.w;                                         \
-      const float dG_ddely = -gdy * QB.x - gdx * QA.w;                                         \
-      const float hG = -0.5f * dL_dG;                                                          \
+      const float u = G * dL_dalpha;                                                           \
+      const float ux = u * dx, uy = u * dy;                                                    \
       float v[9];                                                                              \
       v[0] = dchannel_dcolor * dLp0;                                                           \
       v[1] = dchannel_dcolor * dLp1;                                                           \
       v[2] = dchannel_dcolor * dLp2;                                                           \
-      v[3] = dL_dG * dG_ddelx * ddelx_dx;                                                      \
-      v[4] = dL_dG * dG_ddely * ddely_dy;                                                      \
-      v[5] = gdx * dx * hG;                                                                    \
-      v[6] = gdx * dy * hG;                                                                    \
-      v[7] = gdy * dy * hG;                                                                    \
-      v[8] = G * dL_dalpha;                                                                    \
+      v[3] = ux;                                                                               \
+      v[4] = uy;                                                                               \
+      v[5] = ux * dx;                                                                          \
+      v[6] = ux * dy;                                                                          \
+      v[7] = uy * dy;                                                                          \
+      v[8] = u;                                                                                \
       /* reduce-scatter over each 16-lane row, then ONE ds_add_f32: nine lanes of every row    */ \
       /* add their row's sum of one term each into the column of the row's entry               */ \
       GCR_K7_ROW_SUMS                                                                          \
       if (acc_slot >= 0 && GCR_LDS_ADD_ON && (GCR_K7_ADD_SENTINEL || __float_as_uint(QC.z) != NO_ENTRY))                 \
-        atomicAdd(reinterpret_cast<float*>(acc_base + __float_as_uint(QC.w)), rsum);                                      \
+        atomicAdd(reinterpret_cast<double*>(acc_base + __float_as_uint(QC.w)), (double)rsum);                             \
     }                                                                                          \
   }
+// LDS FLOAT ATOMICS (round 5).  The row sums meet in DOUBLE accumulators: on gfx950 ds_add_f32 (and ds_pk_add_f16) is
+// serialised lane by lane -- 193 cycles of the CU's LDS pipeline for a full wave64, 109 for this step's 36 lanes -- while
+// ds_add_f64, ds_add_u32 / u64 and ds_max_f32 run at the rate of a plain store (13 cycles for the same 36 lanes):
+// tools/lds_atomic_probe.hip, profiles/r05_lds_atomic_probe.jsonl.  The one ds_add_f32 per step was 65 us of LDS pipeline
+// time per launch at C2 -- the knock-out that removed it shortened the launch by a quarter in rounds 3, 4 and 5, and nothing
+// else ever had.  One v_cvt_f64_f32 per step and 4.6 KB more LDS per wave buy it back (and sums that are exact to the
+// last float bit per item).
 // The wave-uniform skip of a step no lane is in range of: K6 keeps it; here a step of a row list almost always has a lane
 // in range (the list holds the entries whose block mask reaches the row's block, below the row's max n_contrib), the body
 // is correct for a wave without one (alpha_eff = 0 everywhere), and without the branch the two steps of a trip are ONE basic
@@ -770,7 +784,7 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
   __shared__ uint32_t sId[WPASS];
   __shared__ uint16_t sList[4][WLIST_STRIDE];
   __shared__ uint16_t sRel[WPASS];   // pass slots with something to flush, compacted
-  __shared__ float sAcc[WPASS * 9];  // entry-major: the nine sums of pass slot j at [9j, 9j+9)
+  __shared__ double sAcc[WPASS * 9];  // entry-major: the nine sums of pass slot j at [9j, 9j+9); DOUBLES -- see "LDS float atomics" below
 
   const int lane = threadIdx.x;
   if ((int)blockIdx.x < a.fill.blocks) {  // the launch's leading waves: zero fill of the dense outputs
@@ -795,7 +809,6 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const int acc_slot = GCR_K7_ROW_SLOT;  // which of the nine terms this lane adds to the accumulators
   const float bg0 = GCR_CAM(a, bg, a.bg, 0), bg1 = GCR_CAM(a, bg, a.bg, 1), bg2 = GCR_CAM(a, bg, a.bg, 2);
-  const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
   const char* const sEb = reinterpret_cast<const char*>(sE);
   char* const acc_base = reinterpret_cast<char*>(&sAcc[acc_slot >= 0 ? acc_slot : 0]);
   if (lane == 0) {
@@ -804,7 +817,7 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
     sE[WPASS].c = make_float4(0.0f, __builtin_inff(), __uint_as_float(NO_ENTRY), 0.0f);
   }
 #pragma unroll
-  for (int k = 0; k < 9; k++) sAcc[k * WPASS + lane] = 0.0f;  // kept zero by the flush from here on
+  for (int k = 0; k < 9; k++) sAcc[k * WPASS + lane] = 0.0;  // kept zero by the flush from here on
 
   // the grid covers the units the host expects; should the forward have used a smaller piece, the waves stride on
   // Which unit a workgroup takes: 32 consecutive workgroups share 8 items x 4 quadrants so that the four quadrants of an
@@ -888,7 +901,7 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
       acc1 = (cf.z - ck.z) / ck.x;
       acc2 = (cf.w - ck.w) / ck.x;
     }
-    const float neg_T_final = -T_final;
+    const float nbg = -T_final * bg_dot_dpixel;  // the background term's pixel constant (cr/backward.cu:556-560)
     float last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;
 
     // ---- passes of 64 list entries, back to front: pass slot `lane` of pass k holds list entry top - 1 - 64 k - lane.
@@ -938,10 +951,10 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
       const uint64_t rel_bal = __ballot(any_rel);
       if (rel_bal == 0ull) continue;  // wave-uniform: nothing of these 64 entries concerns the quadrant
       if (any_rel) {
-        sE[lane].a = q0;
-        sE[lane].b = q1;
+        sE[lane].a = make_float4(q0.x, q0.y, -0.5f * q0.z, -q0.w);  // (K6's pre-scaled conic)
+        sE[lane].b = make_float4(-0.5f * q1.x, q1.y, q1.z, q1.w);
         sE[lane].c = make_float4(q2.x, gcr_alpha_skip_bound(q1.y), __uint_as_float((uint32_t)e_l),
-                                 __uint_as_float((uint32_t)lane * 36u));
+                                 __uint_as_float((uint32_t)lane * 72u));
         sId[lane] = id;
         sRel[__popcll(rel_bal & lt_mask)] = (uint16_t)lane;
       }
@@ -987,9 +1000,9 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
         if (comp < 9) {
           for (int i = lane >> 4; i < nrel; i += 4) {
             const int slot = (int)sRel[i];
-            const float v = sAcc[slot * 9 + comp];
+            const float v = (float)sAcc[slot * 9 + comp];
             if (v != 0.0f) {
-              sAcc[slot * 9 + comp] = 0.0f;
+              sAcc[slot * 9 + comp] = 0.0;
               if (!GCR_FLUSH_ON) continue;
               if (!a.deterministic) {
                 atomicAdd(&a.grad_rec[(size_t)sId[slot] * GCR_GRAD_REC_FLOATS + rec_idx], v);
@@ -998,7 +1011,7 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
                 const float4 q2 = a.rec[(size_t)gid * GCR_REC_QUADS + 2];
                 const int kc = gcr_det_frac_bits(sE[slot].a.x, sE[slot].a.y, __float_as_uint(q2.z), __float_as_uint(q2.w), a.W, a.H, true);
                 const int ko = gcr_det_frac_bits(sE[slot].a.x, sE[slot].a.y, __float_as_uint(q2.z), __float_as_uint(q2.w), a.W, a.H, false);
-                const int kf = (rec_idx >= 6) ? kc : ko;  // record slots 6, 7, 8 = dL_dconic
+                const int kf = (rec_idx >= 4) ? kc : ko;  // record slots 4..8 = the five moments with a pixel offset in them
                 const float sc = __builtin_ldexpf(v, kf);  // exact: a power of two (or +-inf: saturates below)
                 const long long q = sc >= 9.2e18f ? 0x7fffffffffffffffll : (sc <= -9.2e18f ? -0x7fffffffffffffffll : __float2ll_rn(sc));
                 unsigned long long* const r64 = reinterpret_cast<unsigned long long*>(a.grad_rec) + (size_t)gid * (GCR_GRAD_REC_FLOATS_DET / 2);
@@ -1042,16 +1055,15 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
 // Two barriers in a workgroup's life, none in the walk.  The float sums of different waves meet in LDS in arrival order, so
 // the deterministic mode (whose promise is bit-identical reruns) stays on the kernel above.
 constexpr int IPASS = GCR_PIECE_MAX;                 // entries a workgroup stages: one whole piece
-constexpr int ILIST_STRIDE = IPASS + 9;              // u16 slots per row list: entries + pipeline pads (232)
-constexpr uint32_t ISENT_OFF = IPASS * ENTRY_BYTES;  // byte offset of the sentinel entry
-static_assert(IPASS < 256 && ISENT_OFF < 65536u, "one thread per piece entry, u16 list slots");
+constexpr int ILIST_STRIDE = IPASS + 9;              // byte slots per row list: entries + pipeline pads (232)
+static_assert(IPASS < 256, "one thread per piece entry, byte list slots (slot IPASS = the sentinel)");
 
 __global__ __launch_bounds__(256) void k_blend_bwd_item(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[IPASS + 1];
   __shared__ uint32_t sId[IPASS + 1];
   __shared__ uint16_t sMask[256];
-  __shared__ uint16_t sList[4][4][ILIST_STRIDE];
-  __shared__ float sAcc[IPASS * 9];  // entry-major: the nine sums of slot j at [9j, 9j+9)
+  __shared__ uint8_t sList[4][4][ILIST_STRIDE];
+  __shared__ double sAcc[IPASS * 9];  // entry-major: the nine sums of slot j at [9j, 9j+9), as doubles
 
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < a.fill.blocks) {  // the launch's leading workgroups: zero fill of the dense outputs
@@ -1070,7 +1082,6 @@ __global__ __launch_bounds__(256) void k_blend_bwd_item(const GcrBlendArgs a) {
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const int acc_slot = GCR_K7_ROW_SLOT;
   const float bg0 = GCR_CAM(a, bg, a.bg, 0), bg1 = GCR_CAM(a, bg, a.bg, 1), bg2 = GCR_CAM(a, bg, a.bg, 2);
-  const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
   const char* const sEb = reinterpret_cast<const char*>(sE);
   char* const acc_base = reinterpret_cast<char*>(&sAcc[acc_slot >= 0 ? acc_slot : 0]);
   if (tid == 0) {
@@ -1091,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd_item(const GcrBlendArgs a) {
     const uint32_t r0 = d.y, len = d.z, kpiece = d.w;
     const uint32_t npieces = gcr_piece_count(len, piece_P), cs = gcr_piece_size(len, piece_P);
     const uint32_t lo = kpiece * cs, hi = min(len, lo + cs);  // the piece: list entries [lo, hi), walked back to front
-    const int n = (int)min(hi - lo, (uint32_t)IPASS);         // (cs <= piece_P <= 223)
+    const int n = __builtin_amdgcn_readfirstlane((int)min(hi - lo, (uint32_t)IPASS));  // (cs <= piece_P <= 223)
     const uint32_t sbase = r0 / piece_P + (uint32_t)tile;
     const int tx = tile % a.gx, ty = tile / a.gx;
     const LaneGeom g = lane_geom(tid, tx, ty);
@@ -1122,15 +1133,15 @@ __global__ __launch_bounds__(256) void k_blend_bwd_item(const GcrBlendArgs a) {
       cf = ckpt[(size_t)(sbase + npieces - 1u) * 256u + (uint32_t)tid];
     }
     // the accumulators of this item's entries start at zero (stores, no wait)
-    for (int k = tid; k < n * 9; k += 256) sAcc[k] = 0.0f;
+    for (int k = tid; k < n * 9; k += 256) sAcc[k] = 0.0;
 
     // ---- the entry's record, gathered once for the whole tile
     if (m16 != 0u) {
       const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
       const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-      sE[tid].a = q0;
-      sE[tid].b = q1;
-      sE[tid].c = make_float4(q2.x, gcr_alpha_skip_bound(q1.y), __uint_as_float(e_t), __uint_as_float((uint32_t)tid * 36u));
+      sE[tid].a = make_float4(q0.x, q0.y, -0.5f * q0.z, -q0.w);  // (K6's pre-scaled conic)
+      sE[tid].b = make_float4(-0.5f * q1.x, q1.y, q1.z, q1.w);
+      sE[tid].c = make_float4(q2.x, gcr_alpha_skip_bound(q1.y), __uint_as_float(e_t), __uint_as_float((uint32_t)tid * 72u));
       sId[tid] = id;
     }
     sMask[tid] = (uint16_t)m16;
@@ -1158,13 +1169,13 @@ __global__ __launch_bounds__(256) void k_blend_bwd_item(const GcrBlendArgs a) {
       acc1 = (cf.z - ck.z) / ck.x;
       acc2 = (cf.w - ck.w) / ck.x;
     }
-    const float neg_T_final = -T_final;
+    const float nbg = -T_final * bg_dot_dpixel;
     float last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;
     __syncthreads();  // records, masks, zeroed accumulators
 
     if (wave_max > lo && GCR_PASSES_ON) {  // wave-uniform: else this quadrant consumed nothing of the piece
       // the four row lists: block bit set and list entry below the row's max n_contrib (slot order = walk order)
-      uint16_t* const lw = &sList[q][0][0];
+      uint8_t* const lw = &sList[q][0][0];
       int cnt[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -1176,29 +1187,29 @@ __global__ __launch_bounds__(256) void k_blend_bwd_item(const GcrBlendArgs a) {
           for (int rr = 0; rr < 4; rr++) {
             const bool rel = ((m >> g.bit[rr]) & 1u) && e_j < rmax[rr];
             const uint64_t bal = __ballot(rel);
-            if (rel) lw[rr * ILIST_STRIDE + cnt[rr] + __popcll(bal & lt_mask)] = (uint16_t)(j * (int)ENTRY_BYTES);
+            if (rel) lw[rr * ILIST_STRIDE + cnt[rr] + __popcll(bal & lt_mask)] = (uint8_t)j;
             cnt[rr] += __popcll(bal);
           }
         }
       }
-      const int maxcnt = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
+      const int maxcnt = __builtin_amdgcn_readfirstlane(max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3])));
 #pragma unroll
       for (int rr = 0; rr < 4; rr++)
-        for (int s = cnt[rr] + lane; s < maxcnt + 3; s += 64) lw[rr * ILIST_STRIDE + s] = (uint16_t)ISENT_OFF;
+        for (int s = cnt[rr] + lane; s < maxcnt + 3; s += 64) lw[rr * ILIST_STRIDE + s] = (uint8_t)IPASS;
       __builtin_amdgcn_wave_barrier();
 
       // software pipeline, two entries per trip (see K6)
-      const uint16_t* lp = &sList[q][g.row][0];
+      const uint8_t* lp = &sList[q][g.row][0];
       float4 qa0, qb0, qc0, qa1, qb1, qc1;
-      uint32_t e0 = lp[0], e1 = lp[1];
+      uint32_t e0 = (uint32_t)lp[0] * ENTRY_BYTES, e1 = (uint32_t)lp[1] * ENTRY_BYTES;
       GCR_BWD_LOAD(qa0, qb0, qc0, e0)
       for (int i = 0; i < maxcnt; i += 2, lp += 2) {
         GCR_BWD_LOAD(qa1, qb1, qc1, e1)
-        e0 = lp[2];
+        e0 = (uint32_t)lp[2] * ENTRY_BYTES;
         GCR_BWD_STEP(qa0, qb0, qc0)
         if (i + 1 >= maxcnt) break;
         GCR_BWD_LOAD(qa0, qb0, qc0, e0)
-        e1 = lp[3];
+        e1 = (uint32_t)lp[3] * ENTRY_BYTES;
         GCR_BWD_STEP(qa1, qb1, qc1)
       }
     }
@@ -1209,7 +1220,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd_item(const GcrBlendArgs a) {
       const int rec_idx = comp < 3 ? comp : (comp == 8 ? 3 : comp + 1);  // record layout: gcr_internal.h
       if (comp < 9 && GCR_FLUSH_ON) {
         for (int i = tid >> 4; i < n; i += 16) {
-          const float v = sAcc[i * 9 + comp];
+          const float v = (float)sAcc[i * 9 + comp];
           if (v != 0.0f) atomicAdd(&a.grad_rec[(size_t)sId[i] * GCR_GRAD_REC_FLOATS + rec_idx], v);
         }
       }

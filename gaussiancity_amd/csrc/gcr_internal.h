@@ -73,6 +73,7 @@ struct GcrPreprocessBwdArgs {
   const uint32_t *vis_list, *vis_count;  // K1's per-block survivor lists
   int nblocks, chunk;
   const float4* grad_rec;  // K7's per-Gaussian accumulation records (GCR_GRAD_REC_FLOATS each)
+  const float4* rec;       // K1's projected records (conic, opacity: the factors of the records' moments)
   const unsigned long long* frame;  // device frame words (null when nothing was rendered): a frame without backward
   unsigned long long binning_bytes; //   state, or one whose carve exceeds the buffer handed in, gets NaN gradients
   float *dL_dmean2D, *dL_dcolor, *dL_dopacity;  // written here from the records (API outputs)
@@ -84,10 +85,13 @@ struct GcrPreprocessBwdArgs {
 };
 
 // K7 accumulates its nine per-(tile, Gaussian) sums into ONE 64-byte record per Gaussian
-//   [0..3] = dL_dcolor.rgb, dL_dopacity   [4..7] = dL_dmean2D.xy, dL_dconic.x, dL_dconic.y   [8] = dL_dconic.w
+//   [0..2] = dL_dcolor.rgb   [3] = S   [4] = Sx  [5] = Sy  [6] = Sxx  [7] = Sxy  [8] = Syy
 // so that the nine global atomics of a flush land in one cache line and leave the CU as one
 // memory-side transaction (scattered over four arrays they were 44 % of K7: DESIGN.md section 5).
-// K8 reads the record with three dwordx4 loads and writes the API's dL_dmeans2D / dL_dcolors / dL_dopacity.
+// S.. are MOMENTS of u = G * dL/dalpha over the pixel offset (dx, dy) from the Gaussian's centre (round 5, gcr_blend.hip
+// "MOMENTS"): dL_dopacity = S, dL_dconic = -0.5 o (Sxx, Sxy, Syy), dL_dmean2D = -o ((cx Sx + cy Sy) W/2, (cz Sy + cy Sx) H/2).
+// K8 reads the record with three dwordx4 loads, applies those factors and writes the API's dL_dmeans2D / dL_dcolors /
+// dL_dopacity.
 #define GCR_GRAD_REC_FLOATS 16
 // Option "deterministic_backward": the record is nine 64-bit FIXED-POINT sums (same order) in a 128-byte slot instead
 // of nine floats in a 64-byte one.  Integer addition is associative, so the per-Gaussian totals no longer depend on the
@@ -101,7 +105,8 @@ struct GcrPreprocessBwdArgs {
 // for the three conic sums and one for the other six (a conic-sized range would cost the dL_dmean2D sums, which the
 // projection multiplies by focal / depth afterwards, their precision: 0.27 on a dL_dmean3D of 12 in the same case):
 //     B_conic = pixels of its tile rectangle * max(squared distance centre -> farthest rectangle corner, 8 max(W, H)) * 64
-//     B_other = pixels of its tile rectangle * 8 max(W, H) * 64
+//               (the five moments with a pixel offset in them: record slots 4..8)
+//     B_other = pixels of its tile rectangle * 8 max(W, H) * 64   (colour sums and S: slots 0..3)
 //     k = clamp(61 - (floor(log2 B) + 1), -16, 32)
 // (the sums are bounded by pixels * {d^2 | W, 1} * |dL_dG|: B leaves |dL_dG| up to 64 per pixel before a sum can wrap;
 // an addend beyond the range still saturates).  The blend gradient kernel computes both when it flushes and leaves

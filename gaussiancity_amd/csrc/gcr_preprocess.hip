@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
     const int ko = kslot != 0 ? (int)((kslot >> 8) & 0xff) - 64 : 32;
     float f[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) f[k] = (float)__builtin_ldexp((double)r64[k], k >= 6 ? -kc : -ko);
+    for (int k = 0; k < 9; k++) f[k] = (float)__builtin_ldexp((double)r64[k], k >= 4 ? -kc : -ko);
     g0 = make_float4(f[0], f[1], f[2], f[3]);
     g1 = make_float4(f[4], f[5], f[6], f[7]);
     g2 = make_float4(f[8], 0.0f, 0.0f, 0.0f);
@@ -849,9 +849,18 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
     g1 = g0;
     g2 = g0;
   }
-  const float dcx = g1.z, dcy = g1.w, dcz = g2.x;
-  a.dL_dmean2D[3 * (size_t)idx] = g1.x;
-  a.dL_dmean2D[3 * (size_t)idx + 1] = g1.y;
+  // The record holds MOMENTS of u = G * dL/dalpha over the Gaussian's pixels (gcr_blend.hip "MOMENTS", gcr_internal.h):
+  // g0.w = S, g1 = (Sx, Sy, Sxx, Sxy), g2.x = Syy.  The per-Gaussian factors of cr/backward.cu:540-575 -- opacity (dL_dG =
+  // o dL/dalpha), the conic in dG/d(delta), -0.5, the pixel scale W/2, H/2 -- are applied here, once per Gaussian.
+  const float4 pr0 = a.rec[(size_t)idx * GCR_REC_QUADS], pr1 = a.rec[(size_t)idx * GCR_REC_QUADS + 1];
+  const float con_x = pr0.z, con_y = pr0.w, con_z = pr1.x, opac = pr1.y;
+  const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
+  const float hop = -0.5f * opac;
+  const float dcx = hop * g1.z, dcy = hop * g1.w, dcz = hop * g2.x;
+  const float dm2x = -(opac * ddelx_dx) * (con_x * g1.x + con_y * g1.y);
+  const float dm2y = -(opac * ddely_dy) * (con_z * g1.y + con_y * g1.x);
+  a.dL_dmean2D[3 * (size_t)idx] = dm2x;
+  a.dL_dmean2D[3 * (size_t)idx + 1] = dm2y;
   a.dL_dcolor[(size_t)idx * a.g_col] = g0.x;
   a.dL_dcolor[(size_t)idx * a.g_col + 1] = g0.y;
   a.dL_dcolor[(size_t)idx * a.g_col + 2] = g0.z;
@@ -922,7 +931,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
     const float m_w = 1.0f / (mhw + 0.0000001f);
     const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
     const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-    const float d2x = g1.x, d2y = g1.y;
+    const float d2x = dm2x, d2y = dm2y;
     const float ax = (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
     const float ay = (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
     const float az = (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
