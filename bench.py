@@ -1132,6 +1132,46 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
         barrier()
         leg_blocks.append(time.perf_counter() - t1)
     leg_s, leg_host_s = float(np.median(leg_blocks)), leg_host_s / 5
+
+    # ---- the same leg as an UNCHANGED caller would run it: utils/helpers.py:250-270 knows no `crop`
+    # keyword -- it renders the full 960x540 frame through rasterizator(points, pos, quat), slices the crop out of the
+    # image in Python and stacks the batch.  Same wrapper object, same autograd node underneath; what differs is that the
+    # tiles outside the crop are blended and walked, and torch runs the slice / stack (and their backward) kernels.
+    def unchanged_caller(gs_points, rasterizator, cam_pos, cam_quat, crop_bboxes):
+        frames_out = []
+        for b in range(gs_points.size(0)):
+            full = rasterizator(gs_points[b], cam_pos[b], cam_quat[b])
+            c = crop_bboxes[b]
+            frames_out.append(full[:, c["y"]:c["y"] + c["h"], c["x"]:c["x"] + c["w"]])
+        return torch.stack(frames_out, dim=0)
+
+    def leg_unchanged(i):
+        pos, quat = poses[(rank + i * world) % len(poses)]
+        leaf.grad = None
+        img = unchanged_caller(leaf[None], wr, [pos], [quat], box)[0]
+        (img - target).abs().mean().backward()
+
+    def blocks_of(fn, nblocks, nsteps):
+        out = []
+        for i in range(12):
+            fn(i)
+        for _ in range(nblocks):
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(nsteps):
+                fn(i)
+            barrier()
+            out.append(1e3 * (time.perf_counter() - t1) / nsteps)
+        return out
+
+    def spread(v):
+        v = sorted(v)
+        return {"median": round(float(np.median(v)), 4), "min": round(v[0], 4), "p10": round(v[len(v) // 10], 4),
+                "p90": round(v[(9 * len(v)) // 10], 4), "max": round(v[-1], 4), "blocks": len(v)}
+
+    nsteps_leg = max(16, min(args.steps, 64))
+    leg_windowed_blocks = blocks_of(leg, 30, nsteps_leg)
+    leg_unchanged_blocks = blocks_of(leg_unchanged, 30, nsteps_leg)
     N.set_option("timing", 1)
     N.stage_ms()
     for i in range(48):
@@ -1169,7 +1209,13 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
                 "what": "helpers.get_gaussian_rasterization -> wrapper -> autograd + crop + L1 + backward to the [N,14] leaf",
                 "ms_per_frame": round(1e3 * leg_s / args.steps, 4), "host_ms": round(1e3 * leg_host_s / args.steps, 4),
                 "ms_per_frame_fastest_block": round(1e3 * min(leg_blocks) / args.steps, 4),
-                "raster_ms": round(raster_ms, 4), "stages_ms": {k: round(v, 4) for k, v in st.items() if v > 0}},
+                "raster_ms": round(raster_ms, 4), "stages_ms": {k: round(v, 4) for k, v in st.items() if v > 0},
+                "ms_per_frame_over_30_blocks": spread(leg_windowed_blocks)},
+            "rasterizer_leg_unchanged_caller": {
+                "what": "the loop of utils/helpers.py:250-270 as an unchanged GaussianCity would run it: full 960x540 render "
+                        "through rasterizator(points, pos, quat), Python slice of the crop, torch.stack -- then the same L1 "
+                        "and backward (no `crop` keyword: every tile is blended and walked, torch runs the slice / stack kernels)",
+                "ms_per_frame_over_30_blocks": spread(leg_unchanged_blocks), "frames_per_block": nsteps_leg},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (gcity-synth-v1 %s, seed %d)" % (cfg["scene"], cfg["seed"]),
             "config": {"workload": "C4: %d points, precomputed colours, %dx%d render, %dx%d crop, %d fp32 stand-in "

@@ -30,7 +30,7 @@ std::atomic<int> g_bwd_wave_units{0};  // 1: the backward blend as one wave per 
 std::atomic<int> g_rescue_hold{0};  // test hook ("rescue_hold"): 1 = the rescue thread answers no call for help
 std::atomic<int> g_gate_polls{400000};  // polls before a frame gate gives up waiting for a rescue to START: about two seconds
                                         // (~5 us per poll: a PCIe round trip + two s_sleep 127); tests shorten it
-std::atomic<int> g_bwd_piece{128};  // entries per backward piece of frames rendered for a backward (gcr_camera.backward)
+std::atomic<int> g_bwd_piece{160};  // entries per backward piece of frames rendered for a backward (gcr_camera.backward)
 #ifdef GCR_EXPERIMENTS  // make EXTRA=-DGCR_EXPERIMENTS: timing experiments, never in the shipping library
 std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results are wrong when set
 std::atomic<int> g_k6_debug{0};  // forward blend knock-outs (gcr_blend.hip GCR_K6_*)
@@ -434,10 +434,15 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
 static void set_piece_args(const Opts& op, GcrBlendArgs& b, bool want_state, const gcr_layout& L, void* binning,
                            void* geom) {
   char* bb = want_state ? (char*)binning : nullptr;  // no state: the blend runs its instantiation without it
-  // Measured (tools/piece_probe.py): the backward blend balances best with 128-entry pieces (C2: 111 -> 95 us), which
-  // cost the forward blend ~10 % (more staging rounds, more sentinel steps) -- so only frames announced as training
-  // frames pay for them.
+  // Measured (tools/k7_ab.py, round 5: one workgroup per item): 160-entry pieces, C2 backward blend 60 us against 63 at
+  // 128 and 67 at 223, the forward blend 31.4 against 32.5 / 31.0 (profiles/r05_k7_ab.jsonl).  Pieces cost the
+  // forward blend a few per cent (more staging rounds, more sentinel steps, the checkpoint stores), so only frames
+  // announced as training frames pay for them.
   b.piece = want_state ? op.bwd_piece : GCR_PIECE_MAX;
+#ifdef GCR_EXPERIMENTS
+  if (!want_state)  // A/B: the chunk of inference frames (a saturating tile stages a whole chunk and consumes part of it)
+    if (const char* e = getenv("GCR_INFER_PIECE")) b.piece = atoi(e) < GCR_PIECE_MIN ? GCR_PIECE_MIN : (atoi(e) > GCR_PIECE_MAX ? GCR_PIECE_MAX : atoi(e));
+#endif
   b.ckpt = bb ? (float4*)(bb + L.bin_ckpt) : nullptr;
   b.work = bb ? (uint4*)(bb + L.bin_work) : nullptr;
   b.mask_out = bb ? (uint16_t*)(bb + L.bin_mask) : nullptr;

@@ -1054,11 +1054,19 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
 //   4. barrier; the nine sums of an entry leave as ONE record update per (entry, piece), nine adjacent lanes.
 // Two barriers in a workgroup's life, none in the walk.  The float sums of different waves meet in LDS in arrival order, so
 // the deterministic mode (whose promise is bit-identical reruns) stays on the kernel above.
-constexpr int IPASS = GCR_PIECE_MAX;                 // entries a workgroup stages: one whole piece
+#ifndef GCR_K7_IPASS  /* A/B builds: a smaller staging capacity (bwd_piece must not exceed it) */
+#define GCR_K7_IPASS GCR_PIECE_MAX
+#endif
+#ifdef GCR_K7_ITEM_WAVES  /* A/B builds: ask for that many waves per SIMD */
+#define GCR_K7_ITEM_OCC __attribute__((amdgpu_waves_per_eu(GCR_K7_ITEM_WAVES, GCR_K7_ITEM_WAVES)))
+#else
+#define GCR_K7_ITEM_OCC
+#endif
+constexpr int IPASS = GCR_K7_IPASS;                  // entries a workgroup stages: one whole piece
 constexpr int ILIST_STRIDE = IPASS + 9;              // byte slots per row list: entries + pipeline pads (232)
 static_assert(IPASS < 256, "one thread per piece entry, byte list slots (slot IPASS = the sentinel)");
 
-__global__ __launch_bounds__(256) void k_blend_bwd_item(const GcrBlendArgs a) {
+__global__ __launch_bounds__(256) GCR_K7_ITEM_OCC void k_blend_bwd_item(const GcrBlendArgs a) {
   __shared__ StagedEntry sE[IPASS + 1];
   __shared__ uint32_t sId[IPASS + 1];
   __shared__ uint16_t sMask[256];

@@ -350,7 +350,7 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *                     give bit-identical gradients whatever order the tiles' waves arrive in (a debug mode: fp32
  *                     atomics -- here and in the reference -- differ in the last bits from run to run).
  *                     gcr_grad_record_floats() then returns 32: size gcr_grads.dL_dconic AFTER setting the option.
- *   "bwd_piece"    entries per backward piece (64..223) of frames rendered with             default 128
+ *   "bwd_piece"    entries per backward piece (64..223) of frames rendered with             default 160
  *                     gcr_camera.backward != 0 (include/gcr.h; gcr_internal.h "backward pieces")
  *   "lazy_sort"    1: tile lists longer than 1024 entries are sorted segment by segment, only as far   default 1
  *                     as the forward blend walks them (saturating scenes never read most of a long list); the entries

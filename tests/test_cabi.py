@@ -138,8 +138,11 @@ def test_abi_v5_argument_checks_without_a_gpu():
     gr2 = N.Grads(p, p, p, p, p, p, None, p, p)
     rc = lib.gcr_backward(C.byref(cam), C.byref(g2), p, p, 1 << 30, None, 0, p, 1 << 30, 0, p, C.byref(gr2), None)
     assert rc == -1 and b"rotations must be 16-byte aligned" in lib.gcr_last_error()
-    assert lib.gcr_set_option(b"bwd_piece", 10) >= 0 and lib.gcr_set_option(b"bwd_piece", 128) == 64     # clamped to 64..223
-    assert lib.gcr_set_option(b"bwd_piece", 4096) == 128 and lib.gcr_set_option(b"bwd_piece", 128) == 223  # (upper clamp)
+    default_piece = lib.gcr_get_option(b"bwd_piece")
+    assert default_piece == 160 and lib.gcr_get_option(b"no_such_option") == -2 ** 31     # (ABI v7: a getter)
+    assert lib.gcr_set_option(b"bwd_piece", 10) == default_piece and lib.gcr_set_option(b"bwd_piece", 128) == 64     # clamped to 64..223
+    assert lib.gcr_set_option(b"bwd_piece", 4096) == 128 and lib.gcr_set_option(b"bwd_piece", default_piece) == 223  # (upper clamp)
+    assert lib.gcr_get_option(b"bwd_piece") == default_piece
     assert lib.gcr_set_option(b"deterministic_backward", 1) == 0 and lib.gcr_grad_record_floats() == 32
     assert lib.gcr_set_option(b"deterministic_backward", 0) == 1 and lib.gcr_grad_record_floats() == 16
 

@@ -226,7 +226,7 @@ def test_three_host_threads_with_different_per_call_options(oracle_mod, cuda_dev
     for _, g in res["det"][1:]:
         for n in ALL_GRADS:
             assert np.array_equal(g[n].view(np.uint32), d0[n].view(np.uint32)), n + " differs between deterministic runs"
-    assert N.lib().gcr_grad_record_floats() == 16 and N.get_option("bwd_wave_units") == 0 and N.get_option("bwd_piece") == 128
+    assert N.lib().gcr_grad_record_floats() == 16 and N.get_option("bwd_wave_units") == 0 and N.get_option("bwd_piece") == 160
 
 
 def test_global_radix_path_on_a_scene_with_empty_tiles(oracle_mod, cuda_device):

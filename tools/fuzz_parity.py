@@ -72,6 +72,13 @@ def draw_case(rng):
         deterministic=int(rng.random() < 0.15))
 
 
+def with_round5_options(c):
+    """Options added after the generator's draw order was fixed (the case sequence of a seed must not move): derived from
+    the case's own seed.  wave_units: the backward blend as one wave per (work item, quadrant) -- a quarter of the cases."""
+    c.setdefault("wave_units", int(c["seed"] % 4 == 0))
+    return c
+
+
 def run_case(c, O, G, scenes, N, dev):
     """Returns a list of failure strings (empty = the case agrees with the oracle)."""
     rs = scenes.camera(c["W"], c["H"], pose_index=c["pose"], radius=c["radius"], altitude=c["altitude"])
@@ -83,8 +90,10 @@ def run_case(c, O, G, scenes, N, dev):
     fr = O.Frame(**kw, means3D=sc["means3D"], opacities=sc["opacities"], scales=sc["scales"], rotations=sc["rotations"],
                  **extra)
     fails = []
+    with_round5_options(c)
     opts = dict(bwd_piece=c["piece"], lazy_sort=c["lazy"], sort_in_blend=c["sort_in_blend"],
-                split_preprocess=c["split_preprocess"], deterministic_backward=c["deterministic"])
+                split_preprocess=c["split_preprocess"], deterministic_backward=c["deterministic"],
+                bwd_wave_units=c["wave_units"])
     prev = {k: N.set_option(k, v) for k, v in opts.items()}
     try:
         args, out = G.run_forward(rs, sc, dev, use_sh=c["use_sh"], for_backward=c["train_frame"])

@@ -48,4 +48,4 @@ for wave_units, piece in configs:
                       "blend_fwd_ms": round(st["blend_fwd"], 4), "blend_bwd_ms": round(st["blend_bwd"], 4),
                       "preprocess_bwd_ms": round(st["preprocess_bwd"], 4), "fwd_bwd_wall_ms": round(float(np.median(walls)), 4),
                       "wall_min_ms": round(min(walls), 4), "worst_rel_diff_vs_first": worst}), flush=True)
-N.set_option("bwd_wave_units", 0); N.set_option("bwd_piece", 128)
+N.set_option("bwd_wave_units", 0); N.set_option("bwd_piece", 160)

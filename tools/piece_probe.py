@@ -118,4 +118,4 @@ if not args.no_c3:
         torch.cuda.synchronize()
         print(json.dumps({"config": "C3 forward announced as a training frame, one stream", "bwd_piece": P, "blend_fwd_ms": round(st["blend_fwd"], 4),
                           "frame_ms": round(1e3 * (time.perf_counter() - t0) / 96, 4)}), flush=True)
-N.set_option("bwd_piece", 128)
+N.set_option("bwd_piece", 160)
