@@ -6,7 +6,7 @@
 # Afterwards copy gpurun_out/<tag>_* into profiles/ and commit.
 #   usage: gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out
@@ -70,8 +70,9 @@ python $R/bench.py --train-step --steps 200 --host-camera closed-form > $O/${TAG
 python $R/bench.py --train-step --steps 200 --host-camera reference > $O/${TAG}_bench_c4_trainstep_host_camera_reference.json 2>/dev/null
 [ -n "${RASTER_ONLY:-}" ] && { python $R/bench.py > $O/${TAG}_bench_c3.json 2>/dev/null; echo collected $TAG raster only; ls $O | grep "^${TAG}_"; exit 0; }
 
-# ---- visibility and hash-grid encoder ------------------------------------------------------------------------
+# ---- visibility and hash-grid encoder (SKIP_F2F3=1: rows f2 / f3 unchanged this round, only their bench lines) ----------
 for P in visibility grid-encoder; do
+  [ -n "${SKIP_F2F3:-}" ] && continue
   N=${P/-/_}
   B="python $R/bench.py --path $P --no-cpu-baseline"
   timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_${N}_kt -o k -- $B --steps 24 --warmup 3 > /dev/null 2>&1 < /dev/null
@@ -94,5 +95,6 @@ for hc in "--host-camera device" "--host-camera reference" "--host-camera closed
   python $R/bench.py --inference-loop --steps 240 $hc 2>/dev/null
 done > $O/${TAG}_bench_inference_loop.jsonl
 python $R/bench.py --config C2 --backward --no-secondary --steps 200 > $O/${TAG}_bench_c2_fwd_bwd.json 2>/dev/null
+python $R/bench.py --config C2 --backward --no-secondary --no-cpu-baseline --steps 200 --bwd-wave-units > $O/${TAG}_bench_c2_fwd_bwd_wave_units.json 2>/dev/null   # round 4's backward blend kernel (A/B)
 python $R/bench.py --steps 20 --no-cpu-baseline --no-secondary > $O/${TAG}_bench_c3_k20.json 2>/dev/null
 echo collected $TAG; ls $O | grep "^${TAG}_"
