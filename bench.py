@@ -588,6 +588,14 @@ def main():
                                "in every frame, as the reference does)",
                 "value": round(total_frames / oel, 3), "unit": "frames/s", "ms_per_step": round(1e3 * oel / args.steps, 4),
                 "repeats": len(other_blocks)}
+            # which line is like for like with the reference.  Its binding returns num_rendered as an int
+            # (cr/rasterizer_impl.cu:236-238: a blocking read-back in every frame); a speed-up against a reference number
+            # is to be taken from the line whose entry point keeps that contract
+            out["like_for_like_with_the_reference"] = {
+                "line": "value" if args.native_int_api else "other_entry_point.value",
+                "why": "the positional rasterize_gaussians() of the native module returns num_rendered as an int, one host "
+                       "wait per frame, as the reference's binding does; the Python API line is faster because that API "
+                       "never hands the number out and this build does not wait for it"}
 
         # ---- CPU baseline: the oracle on a bounded sample of the same workload --------------
         if world == 1 and getattr(args, "full_cpu_mask", None):
