@@ -90,7 +90,7 @@ class Layout(C.Structure):
         ("img_total", C.c_size_t),
         ("bin_keys", C.c_size_t * 2), ("bin_vals", C.c_size_t * 2), ("bin_hist", C.c_size_t),
         ("bin_sorted", C.c_size_t), ("bin_work", C.c_size_t), ("bin_mask", C.c_size_t), ("bin_ckpt", C.c_size_t),
-        ("bin_total", C.c_size_t), ("bin_lean_total", C.c_size_t),
+        ("bin_total", C.c_size_t), ("bin_lean_total", C.c_size_t), ("bin_staged", C.c_size_t),
     ]
 
 

@@ -204,6 +204,7 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   L->bin_work = o;       o = align_up(o + slots * 16);
   L->bin_mask = o;       o = align_up(o + r * sizeof(uint16_t));
   L->bin_ckpt = o;       o = align_up(o + slots * (size_t)GCR_CKPT_BYTES);
+  L->bin_staged = o;     o = align_up(o + r * 48);
   L->bin_total = o;
 }
 
@@ -446,6 +447,8 @@ static void set_piece_args(const Opts& op, GcrBlendArgs& b, bool want_state, con
   b.ckpt = bb ? (float4*)(bb + L.bin_ckpt) : nullptr;
   b.work = bb ? (uint4*)(bb + L.bin_work) : nullptr;
   b.mask_out = bb ? (uint16_t*)(bb + L.bin_mask) : nullptr;
+  b.staged_out = bb ? (float4*)(bb + L.bin_staged) : nullptr;
+  b.staged_off = L.bin_staged;
   b.ckpt_off = L.bin_ckpt;
   b.work_off = L.bin_work;
   b.mask_off = L.bin_mask;
@@ -454,7 +457,7 @@ static void set_piece_args(const Opts& op, GcrBlendArgs& b, bool want_state, con
 #ifdef GCR_EXPERIMENTS
   if (const char* e = getenv("GCR_K6_NOEXTRAS")) {  // A/B only: what the backward's state costs the forward blend
     if (strchr(e, 'w')) { b.ckpt = nullptr; b.work = nullptr; }
-    if (strchr(e, 'm')) b.mask_out = nullptr;
+    if (strchr(e, 'm')) { b.mask_out = nullptr; b.staged_out = nullptr; }
   }
 #endif
 }

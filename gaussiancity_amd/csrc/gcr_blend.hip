@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         a.frame_out[GCR_FRAME_CKPT_OFF] = a.ckpt_off;
         a.frame_out[GCR_FRAME_WORK_OFF] = a.work_off;
         a.frame_out[GCR_FRAME_MASK_OFF] = a.mask_off;
+        a.frame_out[GCR_FRAME_STAGED_OFF] = a.staged_off;
         a.frame_out[GCR_FRAME_CARVE] = a.carve_bytes;
       }
     }
@@ -454,9 +455,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
       const float pmin = gcr_alpha_skip_bound(q1.y);
       my_mask = gcr_block_mask_2x4(q0.x, q0.y, q0.z, q0.w, q1.x, pmin, tile_x0, tile_y0);
-      sE[tid].a = make_float4(q0.x, q0.y, -0.5f * q0.z, -q0.w);
-      sE[tid].b = make_float4(-0.5f * q1.x, q1.y, q1.z, q1.w);
-      sE[tid].c = make_float4(q2.x, pmin, 0.0f, 0.0f);
+      const float4 sa = make_float4(q0.x, q0.y, -0.5f * q0.z, -q0.w), sb = make_float4(-0.5f * q1.x, q1.y, q1.z, q1.w);
+      const float4 sc = make_float4(q2.x, pmin, 0.0f, 0.0f);
+      sE[tid].a = sa;
+      sE[tid].b = sb;
+      sE[tid].c = sc;
+      if (STATE && a.staged_out != nullptr) {  // the backward's records, in list order: one coalesced block per piece there
+        float4* __restrict__ so = a.staged_out + (size_t)(r0 + (uint32_t)base + (uint32_t)tid) * 3;
+        so[0] = sa;
+        so[1] = sb;
+        so[2] = sc;
+      }
     }
     sMask[tid] = my_mask;
     if (STATE && tid < n && a.mask_out != nullptr)  // reused by the backward, whose rows are 4x4 blocks
@@ -584,6 +593,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     a.frame_out[GCR_FRAME_CKPT_OFF] = a.ckpt_off;
     a.frame_out[GCR_FRAME_WORK_OFF] = a.work_off;
     a.frame_out[GCR_FRAME_MASK_OFF] = a.mask_off;
+    a.frame_out[GCR_FRAME_STAGED_OFF] = a.staged_off;
     a.frame_out[GCR_FRAME_CARVE] = a.carve_bytes;
   }
 }
@@ -806,6 +816,7 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
   const float4* __restrict__ ckpt = reinterpret_cast<const float4*>(a.binning_base + a.frame_in[GCR_FRAME_CKPT_OFF]);
   const uint4* __restrict__ work = reinterpret_cast<const uint4*>(a.binning_base + a.frame_in[GCR_FRAME_WORK_OFF]);
   const uint16_t* __restrict__ masks = reinterpret_cast<const uint16_t*>(a.binning_base + a.frame_in[GCR_FRAME_MASK_OFF]);
+  const float4* __restrict__ staged = reinterpret_cast<const float4*>(a.binning_base + a.frame_in[GCR_FRAME_STAGED_OFF]);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const int acc_slot = GCR_K7_ROW_SLOT;  // which of the nine terms this lane adds to the accumulators
   const float bg0 = GCR_CAM(a, bg, a.bg, 0), bg1 = GCR_CAM(a, bg, a.bg, 1), bg2 = GCR_CAM(a, bg, a.bg, 2);
@@ -927,8 +938,8 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
 #undef GCR_K7_WINDOW
     bool rel_n = (wm0 & quad_bits) != 0u;  // reaches one of this quadrant's 4x4 blocks (entries below wave_max only)
     float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0, n2 = n0;
-    if (rel_n) {
-      const float4* __restrict__ rec = a.rec + (size_t)wi0 * GCR_REC_QUADS;
+    if (rel_n) {  // (the forward's staged copy, addressed by list position: no dependence on the id)
+      const float4* __restrict__ rec = staged + (size_t)(r0 + (uint32_t)(top - 1 - lane)) * 3;
       n0 = rec[0];
       n1 = rec[1];
       n2 = rec[2];
@@ -943,7 +954,7 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
       wi0 = wi1; wi1 = wi2; wi2 = wi3; wi3 = 0u;
       rel_n = k + 1 < npass && (wm0 & quad_bits) != 0u;
       if (rel_n) {
-        const float4* __restrict__ rec = a.rec + (size_t)wi0 * GCR_REC_QUADS;
+        const float4* __restrict__ rec = staged + (size_t)(r0 + (uint32_t)(top - 1 - (k + 1) * WPASS - lane)) * 3;
         n0 = rec[0];
         n1 = rec[1];
         n2 = rec[2];
@@ -951,10 +962,9 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
       const uint64_t rel_bal = __ballot(any_rel);
       if (rel_bal == 0ull) continue;  // wave-uniform: nothing of these 64 entries concerns the quadrant
       if (any_rel) {
-        sE[lane].a = make_float4(q0.x, q0.y, -0.5f * q0.z, -q0.w);  // (K6's pre-scaled conic)
-        sE[lane].b = make_float4(-0.5f * q1.x, q1.y, q1.z, q1.w);
-        sE[lane].c = make_float4(q2.x, gcr_alpha_skip_bound(q1.y), __uint_as_float((uint32_t)e_l),
-                                 __uint_as_float((uint32_t)lane * 72u));
+        sE[lane].a = q0;  // (as the forward staged it: K6's pre-scaled conic, its skip bound)
+        sE[lane].b = q1;
+        sE[lane].c = make_float4(q2.x, q2.y, __uint_as_float((uint32_t)e_l), __uint_as_float((uint32_t)lane * 72u));
         sId[lane] = id;
         sRel[__popcll(rel_bal & lt_mask)] = (uint16_t)lane;
       }
@@ -1044,10 +1054,11 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
 // Round 5.  The wave-per-(item, quadrant) kernel above gathers every list entry of a piece once per
 // quadrant that can see it and flushes it once per quadrant (counter traffic 6.9x the algorithmic bytes at C2, 2.5
 // record updates per consumed entry).  Here ONE 256-thread workgroup owns a (tile, piece) item:
-//   1. prologue, all loads of a thread independent of each other: the work item, the thread's pixel state (final T,
-//      n_contrib, dL/dpixel, the two checkpoints), and -- thread t < n -- block mask and Gaussian id of list entry
-//      hi - 1 - t (the piece back to front: a piece is <= 223 entries, one per thread);
-//   2. thread t gathers that entry's record ONCE (if its mask reaches any block of the tile) and stages it; barrier;
+//   1. prologue, all loads of a thread independent of each other: the work item, then the thread's pixel state (final T,
+//      n_contrib, dL/dpixel, the two checkpoints) and -- thread t < n -- block mask, Gaussian id and staged record of list
+//      entry hi - 1 - t (the piece back to front: a piece is <= 223 entries, one per thread): two round trips;
+//   2. thread t loads that entry's record ONCE -- from the forward's staged copy in list order (48 B per instance, one
+//      coalesced block per piece, no dependence on the id) -- and stages it if its mask reaches the tile; barrier;
 //   3. every wave builds the four row lists of its quadrant from the shared masks (its own rows' max n_contrib bounds
 //      them, no cross-wave value is needed) and walks them exactly as above -- no barrier inside the walk; the row
 //      sums of all four waves meet in ONE LDS accumulator column per entry (ds_add_f32 is atomic across waves);
@@ -1085,6 +1096,7 @@ __global__ __launch_bounds__(256) GCR_K7_ITEM_OCC void k_blend_bwd_item(const Gc
   const float4* __restrict__ ckpt = reinterpret_cast<const float4*>(a.binning_base + a.frame_in[GCR_FRAME_CKPT_OFF]);
   const uint4* __restrict__ work = reinterpret_cast<const uint4*>(a.binning_base + a.frame_in[GCR_FRAME_WORK_OFF]);
   const uint16_t* __restrict__ masks = reinterpret_cast<const uint16_t*>(a.binning_base + a.frame_in[GCR_FRAME_MASK_OFF]);
+  const float4* __restrict__ staged = reinterpret_cast<const float4*>(a.binning_base + a.frame_in[GCR_FRAME_STAGED_OFF]);
   const int lane = tid & 63;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's quadrant of the tile
   const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -1143,14 +1155,18 @@ __global__ __launch_bounds__(256) GCR_K7_ITEM_OCC void k_blend_bwd_item(const Gc
     // the accumulators of this item's entries start at zero (stores, no wait)
     for (int k = tid; k < n * 9; k += 256) sAcc[k] = 0.0;
 
-    // ---- the entry's record, gathered once for the whole tile
-    if (m16 != 0u) {
-      const float4* __restrict__ rec = a.rec + (size_t)id * GCR_REC_QUADS;
+    // ---- the entry's record, staged once for the whole tile: the forward's own staged copy (centre, pre-scaled conic,
+    // opacity, colour, skip bound), addressed by list position -- a piece is ONE coalesced block, and the load does not
+    // wait for the id (counter traffic without the zero fill 2.26x -> see DESIGN.md section 7)
+    if (hv) {
+      const float4* __restrict__ rec = staged + (size_t)(r0 + e_t) * 3;
       const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-      sE[tid].a = make_float4(q0.x, q0.y, -0.5f * q0.z, -q0.w);  // (K6's pre-scaled conic)
-      sE[tid].b = make_float4(-0.5f * q1.x, q1.y, q1.z, q1.w);
-      sE[tid].c = make_float4(q2.x, gcr_alpha_skip_bound(q1.y), __uint_as_float(e_t), __uint_as_float((uint32_t)tid * 72u));
-      sId[tid] = id;
+      if (m16 != 0u) {
+        sE[tid].a = q0;
+        sE[tid].b = q1;
+        sE[tid].c = make_float4(q2.x, q2.y, __uint_as_float(e_t), __uint_as_float((uint32_t)tid * 72u));
+        sId[tid] = id;
+      }
     }
     sMask[tid] = (uint16_t)m16;
 

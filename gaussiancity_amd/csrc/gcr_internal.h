@@ -180,6 +180,8 @@ static inline __host__ __device__ unsigned long long gcr_piece_slots(unsigned lo
 #define GCR_FRAME_MASK_OFF 7  // byte offset of the per-instance block masks (uint16, sorted-list order)
 #define GCR_FRAME_CARVE 6     // bytes of the binning buffer as the forward carved it (for ITS capacity): a backward
                               // that is handed a smaller buffer must not follow the offsets above
+#define GCR_FRAME_STAGED_OFF 8  // byte offset of the staged records (48 B per instance, sorted-list order; round 5): the
+                                // frame words' slot in the geometry buffer is 256 bytes, words 9..31 are free
 // Has the forward left the backward's state in a buffer of `binning_bytes`?  (frame word 3 is zeroed by the count
 // kernel of every frame and set by a forward blend that writes the state.)
 static inline __host__ __device__ bool gcr_frame_has_state(const unsigned long long* frame, unsigned long long binning_bytes) {
@@ -213,6 +215,8 @@ struct GcrBlendArgs {
   uint4* work;                     // fwd: [slots] work items {tile, list start, list length, piece}
   uint16_t* mask_out;              // fwd: [R] block mask of every staged list entry (the backward reuses them)
   unsigned long long mask_off;     // fwd: its byte offset in the binning buffer (published in the frame words)
+  float4* staged_out;              // fwd: [R][3] every list entry as staged (the backward's records, in list order)
+  unsigned long long staged_off;   // fwd: its byte offset in the binning buffer (published in the frame words)
   unsigned long long* frame_out;   // fwd: device frame words; [3..7] published by the first tile
   unsigned long long ckpt_off, work_off;  // fwd: what it publishes (byte offsets in the binning buffer)
   unsigned long long carve_bytes;         // fwd: ... and the size of the carve they belong to

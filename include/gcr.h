@@ -178,7 +178,8 @@ typedef struct gcr_layout {
   size_t geom_vis_list;      /* uint32 per Gaussian: K1 block b's survivors, packed at b*chunk */
   size_t geom_vis_count;     /* uint32 per K1 block */
   size_t geom_num_rendered;  /* uint64 {num_rendered, longest tile list, go flag, backward piece size,
-                                byte offsets of bin_ckpt / bin_work / bin_mask as the forward carved them} */
+                                byte offsets of bin_ckpt / bin_work, carve size, offsets of bin_mask / bin_staged as the
+                                forward carved them} (nine of the 32 words reserved here) */
   size_t geom_block_tiles;   /* uint64 per K1 block: its share of num_rendered */
   size_t geom_total;
   /* image buffer */
@@ -204,6 +205,9 @@ typedef struct gcr_layout {
                            blend crossed -- what lets the backward blend start in the middle of a tile list */
   size_t bin_total;
   size_t bin_lean_total; /* everything in front of bin_work: all a frame with gcr_camera.backward == 0 uses */
+  size_t bin_staged;    /* (ABI v7) 48 B per instance, sorted-list order: every entry as the forward blend staged it
+                           (centre, pre-scaled conic, opacity, colour, skip bound) -- the backward blend reads a piece's
+                           records as one coalesced block instead of gathering them by Gaussian index */
 } gcr_layout;
 
 /* Host-side summary of K1+K2, produced by gcr_forward_preprocess and consumed by

@@ -160,7 +160,7 @@ def test_abi_v6_per_call_options_async_arguments_and_ticket_protocol_without_a_g
         N.Options(no_such_option=1)
     # lean carve: everything in front of the backward's state
     L = N.get_layout(1000, 640, 448, 200000)
-    assert L.bin_lean_total == lib.gcr_binning_bytes_lean(200000, 640, 448) == L.bin_work < L.bin_mask < L.bin_ckpt < L.bin_total
+    assert L.bin_lean_total == lib.gcr_binning_bytes_lean(200000, 640, 448) == L.bin_work < L.bin_mask < L.bin_ckpt < L.bin_staged < L.bin_total and L.bin_total - L.bin_staged >= 48 * 200000
     assert 24 * 200000 <= L.bin_lean_total <= 40 * 200000
     buf = (C.c_float * 256)()
     p = (C.addressof(buf) + 63) // 64 * 64

@@ -20,7 +20,7 @@ def fb(i):
     a = (rs.bg, t["means3D"], E, t["opacities"], t["scales"], t["rotations"], 1.0, E, rs.view_matrix, rs.proj_matrix, rs.tanfovx, rs.tanfovy, H, W, t["shs"], 3, rs.campos, False, False)
     R, color, radii, geom, binning, img = ext.rasterize_gaussians(*a, _for_backward=True)
     ext.rasterize_gaussians_backward(rs.bg, t["means3D"], radii, E, t["scales"], t["rotations"], 1.0, E, rs.view_matrix, rs.proj_matrix, rs.tanfovx, rs.tanfovy, dpix, t["shs"], 3, rs.campos, geom, R, binning, img, False)
-for flag in (0, 1, 4, 5, 16, 21, 32, 0):
+for flag in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 1, 4, 5, 16, 21, 32, 0)):
     N.set_option("k7_skip_flush", flag)
     for i in range(5): fb(i)
     N.set_option("timing", 1); N.stage_ms(); torch.cuda.synchronize()
