@@ -185,7 +185,7 @@ GCR_DEV uint32_t slot_of_offset(uint32_t off) { return (off * 1366u) >> 16; }
 #define GCR_K6_WAVE_SKIP(x) true
 #endif
 // K7: a row standing on the sentinel entry (its list is shorter than the wave's longest) has nothing to add: without its
-// nine lanes in the ds_add_f32 the launch is 89.2 instead of 94.0 us at C2 (same A/B file).  1 = add anyway (A/B builds).
+// nine lanes in the LDS add the launch was 89.2 instead of 94.0 us at C2 (same A/B file).  1 = add anyway (A/B builds).
 #ifndef GCR_K7_ADD_SENTINEL
 #define GCR_K7_ADD_SENTINEL 0
 #endif
@@ -599,33 +599,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }
 
 // ------------------------------------------------------------------------------------- K7
-// cr/backward.cu:428-581.  Per pixel the reverse walk is the reference's.  What changes:
+// cr/backward.cu:428-581.  Per pixel the reverse walk is the reference's.  What changes, in both kernels below:
 //
 // (a) How the nine per-(pixel, Gaussian) gradient terms reach memory.  The reference issues nine global float
 //     atomics per pixel per Gaussian; here
 //   1. each 16-lane DPP row (= one 4x4 block, all lanes on the SAME Gaussian) reduce-scatters the nine terms
-//      (31 VALU ops, gcr_row_reduce_scatter9; no LDS traffic),
-//   2. lanes 0..8 of each row add the row sums into an LDS accumulator (one ds_add_f32 to nine consecutive floats of
-//      the entry's accumulator row),
-//   3. after a pass the nine sums of an entry are flushed by nine ADJACENT lanes into the Gaussian's 64-byte gradient
-//      record (gcr_internal.h): one wave instruction = 4 entries = 4 cache lines.
+//      (20 VALU instructions, gcr_row_reduce_scatter9_b; no LDS traffic),
+//   2. nine lanes of each row add the row sums into an LDS accumulator of DOUBLES (one ds_add_f64: "LDS FLOAT ATOMICS"
+//      below says why not floats),
+//   3. the nine sums of an entry are flushed by nine ADJACENT lanes into the Gaussian's 64-byte gradient record
+//      (gcr_internal.h): one wave instruction = 4 entries = 4 cache lines.
 //
 // (b) The unit of work is a (tile, PIECE) item of the list the forward left behind (gcr_internal.h "backward
-//     pieces"), not a tile: a pixel whose walk goes on behind the piece starts from the forward's checkpoint.
+//     pieces"), not a tile: a pixel whose walk goes on behind the piece starts from the forward's checkpoint.  An
+//     item's records come from the forward's staged copy in list order (gcr_layout.bin_staged), its block masks from the
+//     forward as well: no mask arithmetic (222 VALU per entry) and no gather by Gaussian index in the backward.
 //
-// (c) ONE WAVE PER (item, 8x8 QUADRANT), NO WORKGROUP BARRIERS.  Per-wave phase clocks (tools/k7_clocks.py, round 3)
-//     showed why one 256-thread workgroup per tile ran at a third of the VALU rate: a workgroup's life is a chain of
-//     dependent memory round trips (ranges -> pixel state -> list -> records), then the walk -- which is LATENCY-bound
-//     per wave (a ~50-deep dependent chain per step, ~1100 cycles; four walking waves per SIMD are needed to saturate
-//     the VALU) -- then the flush, with barriers in between; the four workgroups a CU holds start together and stay in
-//     step, so the SIMDs saw 1.7-2.3 walking waves on average.  Persistent workgroups with the next item's loads in
-//     flight shortened the gaps but not the launch (both measured 95-100 us at C2).  A wave that owns its quadrant's
-//     whole pipeline -- pixel state, list entries, staging, row lists, walk, flush, all in wave-private LDS -- never
-//     waits for another wave: sixteen independent pipelines per CU fill each other's gaps.  What makes it affordable
-//     is that the forward blend stores the block mask of every list entry it stages (uint16 per instance): the
-//     quadrant's wave reads 64 masks per pass, keeps the entries that reach its four 4x4 blocks below the quadrant's
-//     max n_contrib, and gathers only those records -- no mask arithmetic (222 VALU per entry) in the backward at all.
-//     The price: an entry that reaches several quadrants of a tile is flushed by each of them.
+// (c) k_blend_bwd (round 3): ONE WAVE PER (item, 8x8 QUADRANT), NO WORKGROUP BARRIERS -- sixteen independent pipelines per
+//     CU, all state in wave-private LDS; an entry that reaches several quadrants of a tile is staged and flushed by each
+//     of them.  Selected by option "bwd_wave_units" and always by the deterministic mode (its LDS sums have a fixed
+//     order).  k_blend_bwd_item (round 5, the default, further down): one workgroup per item.
 // Only entries below the row's max n_contrib are visited (skipped by every pixel upstream too,
 // contributor >= last_contributor, :511-512), and each row visits only the entries whose block mask includes its
 // 4x4 block (see K6).
@@ -736,7 +729,7 @@ constexpr uint32_t WSENT_OFF = WPASS * ENTRY_BYTES;  // byte offset of the wave'
       v[6] = ux * dy;                                                                          \
       v[7] = uy * dy;                                                                          \
       v[8] = u;                                                                                \
-      /* reduce-scatter over each 16-lane row, then ONE ds_add_f32: nine lanes of every row    */ \
+      /* reduce-scatter over each 16-lane row, then ONE ds_add_f64: nine lanes of every row    */ \
       /* add their row's sum of one term each into the column of the row's entry               */ \
       GCR_K7_ROW_SUMS                                                                          \
       if (acc_slot >= 0 && GCR_LDS_ADD_ON && (GCR_K7_ADD_SENTINEL || __float_as_uint(QC.z) != NO_ENTRY))                 \
@@ -919,9 +912,9 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
     // A unit's life is a chain of dependent memory round trips, and round 3's knock-outs showed that they ADD (a wave per
     // unit, 16 waves per CU: nothing covers another wave's wait).  Per pass the chain was masks -> list entry -> records;
     // here (round 4) the block masks and list entries of ALL the unit's passes are requested at once (a piece is <= 256
-    // entries = <= 4 passes) and the records of pass k + 1 are gathered while pass k is walked: work item -> pixel state ->
-    // masks + list -> records of the FIRST pass is the whole chain, whatever the number of passes.  (+20 VGPRs, still
-    // within the 128 of four waves per SIMD.)
+    // entries = <= 4 passes) and the records of pass k + 1 are loaded while pass k is walked (round 5: from the forward's
+    // staged copy in list order, so they do not wait for the ids either): work item -> pixel state -> masks + list +
+    // records of the FIRST pass is the whole chain, whatever the number of passes.
     const int npass = (top - (int)lo + WPASS - 1) / WPASS;
     uint32_t wm0, wm1, wm2, wm3, wi0, wi1, wi2, wi3;
 #define GCR_K7_WINDOW(K, M, I)                                         \
@@ -1061,7 +1054,7 @@ __global__ __launch_bounds__(64) GCR_K7_OCC void k_blend_bwd(const GcrBlendArgs 
 //      coalesced block per piece, no dependence on the id) -- and stages it if its mask reaches the tile; barrier;
 //   3. every wave builds the four row lists of its quadrant from the shared masks (its own rows' max n_contrib bounds
 //      them, no cross-wave value is needed) and walks them exactly as above -- no barrier inside the walk; the row
-//      sums of all four waves meet in ONE LDS accumulator column per entry (ds_add_f32 is atomic across waves);
+//      sums of all four waves meet in ONE LDS accumulator column per entry (ds_add_f64 is atomic across waves);
 //   4. barrier; the nine sums of an entry leave as ONE record update per (entry, piece), nine adjacent lanes.
 // Two barriers in a workgroup's life, none in the walk.  The float sums of different waves meet in LDS in arrival order, so
 // the deterministic mode (whose promise is bit-identical reruns) stays on the kernel above.
