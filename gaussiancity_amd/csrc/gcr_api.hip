@@ -167,7 +167,7 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   L->geom_block_sums = o;     o = align_up(o + (nblk + 1) * sizeof(uint32_t));
   L->geom_vis_list = o;       o = align_up(o + p * sizeof(uint32_t));
   L->geom_vis_count = o;      o = align_up(o + (nblk + 1) * sizeof(uint32_t));
-  L->geom_num_rendered = o;   o = align_up(o + 8 * sizeof(uint64_t));  // frame words (gcr_internal.h: GCR_FRAME_*)
+  L->geom_num_rendered = o;   o = align_up(o + 16 * sizeof(uint64_t));  // frame words (gcr_internal.h: GCR_FRAME_*, nine in use)
   L->geom_block_tiles = o;    o = align_up(o + GCR_K1_MAX_BLOCKS * sizeof(uint64_t));  // K1 blocks' shares of R
   L->geom_total = o;
 

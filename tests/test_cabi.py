@@ -211,6 +211,49 @@ def test_abi_v6_per_call_options_async_arguments_and_ticket_protocol_without_a_g
     assert lib.gcr_forward_render(C.byref(cam), C.byref(gb), p, big, p, big, p, big, C.byref(fi), None, None) == -1
     assert b"state-only" in lib.gcr_last_error()
     assert lib.gcr_rescue_count() == 0
+    # ABI v7 handshake: a gate that gave up (word 4) while a rescue had already started (word 7) is still waiting for
+    # it -- the ticket stays pending until the rescue's release (word 2), it does not report "not rescued in time"
+    words[0] = (9 << 32) | 700
+    words[5], words[2], words[4], words[7] = 0, 0, 9, 9
+    assert lib.gcr_ticket_poll(w, 9, 500, C.byref(info)) == 1
+    words[2] = 9
+    assert lib.gcr_ticket_poll(w, 9, 500, C.byref(info)) == 0 and info.num_rendered == 700
+    words[5] = 9   # ... and a rescue that saw the give-up word and touched nothing says so through the failure word
+    assert lib.gcr_ticket_poll(w, 9, 500, C.byref(info)) == -4
+    assert lib.gcr_rescue_dropped_count() == 0 and lib.gcr_get_option(b"gate_polls") == 400000
+
+
+def test_a_failed_frame_fails_its_own_ticket_and_nothing_else_without_a_gpu():
+    """ext.FrameTicket keeps a frame's error to itself.  Driven here on ordinary host memory: a ticket whose
+    words say "overflowed and not rescued in time" resolves (done() is True, the ring's harvest pops it, take() goes past
+    it), raises from its own wait() / int() -- every time --, leaves the capacity hints alone, and the next ticket on the
+    ring resolves normally."""
+    import collections
+
+    import pytest
+    from gaussiancity_amd import ext
+    lib = N.lib()
+    words = [(C.c_uint64 * N.TICKET_WORDS)() for _ in range(2)]
+    key = ("cpu-test", 1, 2, 3)
+    ext._capacity_hint.pop(key, None)
+    bad = ext.FrameTicket(lib, words[0], C.addressof(words[0]), 5, 100, None, key, True)
+    good = ext.FrameTicket(lib, words[1], C.addressof(words[1]), 6, 100, None, key, True)
+    assert not bad.done() and not good.done()                 # nothing published yet
+    words[0][0], words[0][4] = (5 << 32) | 4000, 5            # R = 4000 > capacity 100, the gate gave up
+    words[1][0], words[1][1] = (6 << 32) | 80, 17
+    ring = ext._TicketRing.__new__(ext._TicketRing)           # (no pinned block: only the bookkeeping is exercised)
+    ring.base, ring.pending, ring.tickets = None, collections.deque([bad, good]), [bad, good]
+    ring.harvest()
+    assert not ring.pending and bad.done() and good.done()
+    assert bad.failed is not None and good.failed is None and int(good) == 80
+    for _ in range(2):
+        with pytest.raises(RuntimeError, match="not rescued in time"):
+            int(bad)
+    with pytest.raises(RuntimeError, match="not rescued in time"):
+        bad.rescued
+    assert ext._capacity_hint[key] == (80, 17)                # the failed frame left no hint behind
+    ext._capacity_hint.pop(key, None)
+
 
 
 def _gcv_header_functions():
