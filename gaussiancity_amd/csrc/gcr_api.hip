@@ -72,6 +72,10 @@ int fail(gcr_status code, const std::string& msg) {
   g_err = msg;
   return (int)code;
 }
+// gcr_camera.prefiltered and a Gaussian behind the near plane (gcr_internal.h GCR_PREFILTER_MARK): the reference's words
+int fail_prefiltered() {
+  return fail(GCR_ERR_INVALID_ARGUMENT, "Point is filtered although prefiltered is set. This shouldn't happen!");
+}
 int fail_hip(hipError_t e, const char* where) {
   g_err = std::string(where) + ": " + hipGetErrorString(e);
   return (int)GCR_ERR_DEVICE;
@@ -383,6 +387,7 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
   a.s_col = stride_or(g->stride_colors, 3);
   a.s_scale = stride_or(g->stride_scales, 3);
   a.s_rot = stride_or(g->stride_rotations, 4);
+  a.prefiltered = cam->prefiltered != 0;
   fill_cam(a.cam, cam);
   a.radii = radii;
   a.rec = (float4*)(gb + L.geom_rec);
@@ -424,7 +429,8 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
     }
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
-    HIP_TRY(gcr_launch_scan_tiles(cursor, GCR_CURSOR_STRIDE, ranges, T, frame, cap_instances, cap_list, host_R, seq, s),
+    HIP_TRY(gcr_launch_scan_tiles(cursor, GCR_CURSOR_STRIDE, ranges, T, frame, cap_instances, cap_list, host_R, seq,
+                                  a.block_tiles, a.nblocks, s),
             "tile scan");
   }
   return 0;
@@ -627,6 +633,7 @@ int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* 
   unsigned long long r[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(r, frame, sizeof(r), hipMemcpyDeviceToHost, s), "num_rendered copy");
   HIP_TRY(hipStreamSynchronize(s), "num_rendered sync");  // cr/rasterizer_impl.cu:236-238
+  if (r[0] == GCR_PREFILTER_MARK) return fail_prefiltered();
   if (r[0] > 0x7fffffffull)
     return fail(GCR_ERR_OVERFLOW, "num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)");
   info_host->num_rendered = (int64_t)r[0];
@@ -689,6 +696,7 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
   const unsigned long long R = v & 0xffffffffull;
   // the same decision the scatter kernel takes on the device from the same number
   const bool go = R <= (unsigned long long)binning_capacity;
+  if (R == GCR_PREFILTER_MARK) return fail_prefiltered();
   if (R > 0x7fffffffull)
     return fail(GCR_ERR_OVERFLOW, "num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)");
   info_host->num_rendered = (int64_t)R;
@@ -983,6 +991,7 @@ static int ticket_state(const unsigned long long* words_host, uint32_t seq, int6
   const unsigned long long v = w[0];
   if ((unsigned int)(v >> 32) != seq) return 1;
   const unsigned long long R = v & 0xffffffffull;
+  if (R == GCR_PREFILTER_MARK) return fail_prefiltered();
   if (R > 0x7fffffffull)
     return fail(GCR_ERR_OVERFLOW, "num_rendered exceeds 2^31-1 (32-bit instance index, as in the reference)");
   if (R > (unsigned long long)capacity) {  // the frame needed the rescue: resolved when that is complete

@@ -102,17 +102,22 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
     // in ONE 8-byte store to pinned memory that the calling thread polls -- no copy, no event, and the host is
     // released while the tile tables, the scatter, the sort and the blend still run.
     if (blockIdx.x == 0) {
-      unsigned long long part = 0ull;
-      for (int b = tid; b < nblocks_k1; b += TT_THREADS) part += block_tiles[b];
+      unsigned long long part = 0ull, pf = 0ull;
+      for (int b = tid; b < nblocks_k1; b += TT_THREADS) {
+        const unsigned long long v = block_tiles[b];
+        part += v & ~GCR_PREFILTER_FLAG;
+        pf |= v & GCR_PREFILTER_FLAG;  // gcr_camera.prefiltered and a Gaussian behind the near plane (gcr_internal.h)
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
       __shared__ unsigned long long wpart[TT_THREADS / 64];
       if (lane == 0) wpart[w] = part;
-      __syncthreads();
+      const int prefilter_violation = __syncthreads_or(pf != 0ull ? 1 : 0);
       if (tid == 0) {
         unsigned long long total = 0ull;
 #pragma unroll
         for (int k = 0; k < TT_THREADS / 64; k++) total += wpart[k];
+        if (prefilter_violation) total = GCR_PREFILTER_MARK;  // (beyond every capacity: the rest of the frame is vetoed)
         frame[0] = total;
         frame[1] = 0ull;
         frame[2] = 0ull;

@@ -40,8 +40,17 @@ struct GcrPreprocessArgs {
   unsigned long long* block_tiles;  // [nblocks] every K1 block's share of num_rendered
   int nblocks, chunk;    // persistent grid: block b owns Gaussians [b*chunk, (b+1)*chunk)
   int s_mean, s_opac, s_col, s_scale, s_rot;  // row strides in floats (3 / 1 / 3 / 3 / 4 when dense)
+  int prefiltered;  // gcr_camera.prefiltered: a Gaussian behind the near plane is an error of the caller (GCR_PREFILTER_*)
   GcrCamVals cam;
 };
+
+// gcr_camera.prefiltered (cr/auxiliary.h:135-156: "Point is filtered although prefiltered is set. This shouldn't happen!" +
+// __trap() upstream).  Here a K1 block that meets such a Gaussian sets bit 63 of its share of num_rendered (block_tiles),
+// the kernel that sums the shares publishes GCR_PREFILTER_MARK instead of num_rendered -- which also vetoes every later
+// kernel of the frame, like any num_rendered beyond the capacity -- and the host turns it into GCR_ERR_INVALID_ARGUMENT
+// with the reference's text instead of a dead context.
+#define GCR_PREFILTER_FLAG (1ull << 63)
+#define GCR_PREFILTER_MARK 0xFFFFFFFEull
 
 // Persistent-grid geometry of K1 (also used by the kernels that walk its visible lists):
 // 8 workgroups per CU (a measured constant, see gcr_preprocess_resident_blocks), at most GCR_K1_MAX_BLOCKS.
@@ -253,7 +262,7 @@ hipError_t gcr_launch_emit(int P, const uint32_t* tiles_touched, const uint32_t*
 hipError_t gcr_launch_scan_tiles(uint32_t* tile_cursor, int stride, uint32_t* ranges, int T,
                                  unsigned long long* frame, unsigned long long cap_instances,
                                  unsigned long long cap_list, unsigned long long* host_R, unsigned int seq,
-                                 hipStream_t s);
+                                 const unsigned long long* block_tiles, int nblocks_k1, hipStream_t s);
 int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out);
 hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
                                  const uint32_t* vis_count, const float4* rec, uint32_t* table,

@@ -220,6 +220,12 @@ GCR_DEV bool phase_a0_certainly_culled(const GcrPreprocessArgs& a, const float (
          py - rb > 16.0f * (float)a.gy + slack;
 }
 
+// gcr_camera.prefiltered: does this Gaussian fail the near-plane test (the only test of in_frustum, cr/auxiliary.h:145)?
+GCR_DEV bool near_plane_violation(const float (&vm)[16], const PhaseAIn& in) {
+  const float tz = vm[2] * in.p.x + vm[6] * in.p.y + vm[10] * in.p.z + vm[14];  // exact, as transformPoint4x3
+  return tz <= 0.2f;
+}
+
 // Phase A1: the reference's exact per-Gaussian arithmetic.  Returns whether the Gaussian is
 // rendered; fills the projected state and the integer radius (0 if not rendered).
 struct Projected {
@@ -432,6 +438,7 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
   // two iterations of inputs in flight per wave: when the kernel shares the GPU with another frame's blend it
   // gets a fraction of the wave slots, and bytes in flight per wave are what keeps the stream at HBM speed
   PhaseAIn cur, nxt, nx2;
+  bool viol = false;  // gcr_camera.prefiltered and a Gaussian behind the near plane
   long long idx64 = chunk_begin + tid;
   const long long last = (long long)a.P - 1;
   phase_a_load<PRECOMP_COV>(a, idx64 < last ? idx64 : last, cur);
@@ -443,6 +450,7 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
     if (idx64 < chunk_end) {
       candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur);
       if (!candidate) a.radii[idx64] = 0;
+      if (a.prefiltered) viol |= near_plane_violation(vm, cur);
     }
     const uint64_t m = __ballot(candidate);
     if (m != 0ull) {
@@ -454,8 +462,8 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
     cur = nxt;
     nxt = nx2;
   }
-  __syncthreads();
-  if (tid == 0) a.cand_count[blockIdx.x] = list_tail;
+  const int any_viol = __syncthreads_or(viol ? 1 : 0);
+  if (tid == 0) a.cand_count[blockIdx.x] = list_tail | (any_viol ? 0x80000000u : 0u);  // (a block holds < 2^31 candidates)
 }
 
 // K1b: dense pass over the candidates of K1a block `blockIdx.x`, one candidate per thread: the
@@ -478,7 +486,8 @@ __global__ __launch_bounds__(256) void k_preprocess_project(const GcrPreprocessA
   const size_t chunk_begin = (size_t)blockIdx.x * a.chunk;
   const uint32_t* __restrict__ my_cand = a.cand_list + chunk_begin;
   uint32_t* __restrict__ my_list = a.vis_list + chunk_begin;
-  const uint32_t ncand = a.cand_count[blockIdx.x];
+  const uint32_t ncand_word = a.cand_count[blockIdx.x];
+  const uint32_t ncand = ncand_word & 0x7fffffffu;  // (bit 31: the cull kernel met a prefilter violation)
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   uint32_t my_tiles = 0;  // (Gaussian, tile) instances of this thread's survivors
   for (uint32_t it0 = 0; it0 < ncand; it0 += 256) {  // block-uniform trip count
@@ -517,7 +526,7 @@ __global__ __launch_bounds__(256) void k_preprocess_project(const GcrPreprocessA
     a.vis_count[blockIdx.x] = list_tail;
     // this block's share of num_rendered; the first workgroup of the kernel that follows sums the blocks' shares
     // and publishes the total to the host (no atomics, nothing to zero beforehand)
-    a.block_tiles[blockIdx.x] = blk_tiles;
+    a.block_tiles[blockIdx.x] = blk_tiles | ((ncand_word & 0x80000000u) ? GCR_PREFILTER_FLAG : 0ull);
   }
 }
 
@@ -579,6 +588,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
   uint32_t parity = 0;
 
   PhaseAIn cur, nxt, nx2;
+  bool viol = false;  // gcr_camera.prefiltered and a Gaussian behind the near plane
   long long idx64 = chunk_begin + tid;
   const long long last = (long long)a.P - 1;
   phase_a_load<PRECOMP_COV>(a, idx64 < last ? idx64 : last, cur);
@@ -590,6 +600,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
     if (idx64 < chunk_end) {
       candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur);
       if (!candidate) a.radii[idx64] = 0;
+      if (a.prefiltered) viol |= near_plane_violation(vm, cur);
     }
     const uint64_t m = __ballot(candidate);
     if (lane == 0) wave_new[parity][tid >> 6] = (uint32_t)__popcll(m);
@@ -665,10 +676,11 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
   }
   const uint32_t wsum = gcr_wave_sum_u32(my_tiles);
   if (lane == 0 && wsum) atomicAdd(&blk_tiles, (unsigned long long)wsum);
-  __syncthreads();
+  const int any_viol = __syncthreads_or(viol ? 1 : 0);
   if (tid == 0) {
     a.vis_count[blockIdx.x] = vis_tail;
-    a.block_tiles[blockIdx.x] = blk_tiles;  // summed (= num_rendered) by the first workgroup of the next kernel
+    // summed (= num_rendered) by the first workgroup of the next kernel; bit 63: a prefilter violation
+    a.block_tiles[blockIdx.x] = blk_tiles | (any_viol ? GCR_PREFILTER_FLAG : 0ull);
   }
 }
 
@@ -713,10 +725,14 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ curs
                                                      unsigned long long* __restrict__ frame,
                                                      unsigned long long cap_instances,
                                                      unsigned long long cap_list,
-                                                     unsigned long long* __restrict__ host_R, unsigned int seq) {
+                                                     unsigned long long* __restrict__ host_R, unsigned int seq,
+                                                     const unsigned long long* __restrict__ block_tiles, int nblocks_k1) {
   __shared__ unsigned long long wsum[16];
   __shared__ uint32_t wmax[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  unsigned long long pf = 0ull;  // a K1 block met a prefilter violation (GCR_PREFILTER_FLAG in its share)
+  for (int b = tid; b < nblocks_k1; b += 1024) pf |= block_tiles[b] & GCR_PREFILTER_FLAG;
+  const int prefilter_violation = __syncthreads_or(pf != 0ull ? 1 : 0);
   const int per = (T + 1023) / 1024;
   const int beg = min(T, tid * per), end = min(T, beg + per);
   unsigned long long s = 0;
@@ -758,6 +774,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ curs
     run = e64;
   }
   if (tid == 0) {
+    if (prefilter_violation) total = GCR_PREFILTER_MARK;  // (beyond every capacity: the rest of the frame is vetoed)
     if (host_R != nullptr)  // (frame tag << 32 | R) for the polling host thread, see k_tile_table<false>
       gcr_store_to_host(host_R, ((unsigned long long)seq << 32) | (total > 0xffffffffull ? 0xffffffffull : total));
     frame[0] = total;
@@ -1138,8 +1155,8 @@ hipError_t gcr_launch_scan_block_sums(uint32_t* block_sums, int n, unsigned long
 hipError_t gcr_launch_scan_tiles(uint32_t* tile_cursor, int stride, uint32_t* ranges, int T,
                                  unsigned long long* frame, unsigned long long cap_instances,
                                  unsigned long long cap_list, unsigned long long* host_R, unsigned int seq,
-                                 hipStream_t s) {
-  k_scan_tiles<<<1, 1024, 0, s>>>(tile_cursor, stride, ranges, T, frame, cap_instances, cap_list, host_R, seq);
+                                 const unsigned long long* block_tiles, int nblocks_k1, hipStream_t s) {
+  k_scan_tiles<<<1, 1024, 0, s>>>(tile_cursor, stride, ranges, T, frame, cap_instances, cap_list, host_R, seq, block_tiles, nblocks_k1);
   return hipGetLastError();
 }
 

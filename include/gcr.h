@@ -81,10 +81,13 @@ typedef struct gcr_camera {
   float tanfovx, tanfovy;
   float scale_modifier;
   int32_t sh_degree;   /* active degree D, 0..3 */
-  int32_t prefiltered; /* accepted and IGNORED.  Upstream it only arms a diagnostic (cr/auxiliary.h:148-152: a device
-                          printf + trap when a point the caller declared pre-culled fails the near-plane test); the
-                          result of a frame never depends on it, and GaussianCity always passes False
-                          (dgr/__init__.py:399).  Here culled points are skipped silently either way */
+  int32_t prefiltered; /* !=0: the caller declares that no Gaussian lies behind the near plane (view-space z <= 0.2).
+                          Upstream a Gaussian that does then hits a device printf + __trap() (cr/auxiliary.h:148-152: "Point
+                          is filtered although prefiltered is set. This shouldn't happen!").  Here (ABI v7) the frame is
+                          not rendered and the call -- gcr_forward, gcr_forward_preprocess, gcr_rasterize_forward, or the
+                          ticket of gcr_forward_async -- fails with GCR_ERR_INVALID_ARGUMENT and that text; the device and
+                          the stream stay usable.  0 (what GaussianCity always passes, dgr/__init__.py:399): such
+                          Gaussians are culled silently, as upstream */
   int32_t debug;       /* !=0: synchronise + check after every stage (cr/auxiliary.h:158) */
   const float *bg;          /* [3] */
   const float *view_matrix; /* [16] */

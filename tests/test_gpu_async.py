@@ -508,3 +508,55 @@ def test_the_ticket_ring_is_given_back_when_its_thread_ends(cuda_device):
     ring.close()
     ext._tls.ring = None
     assert int(ext.rasterize_gaussians_ticket(*a)[0]) == R
+
+
+def test_prefiltered_with_a_gaussian_behind_the_near_plane_fails_the_frame_not_the_device(oracle_mod, cuda_device):
+    """gcr_camera.prefiltered (cr/auxiliary.h:135-156): upstream a point that fails the near-plane test although the caller
+    declared the cloud pre-filtered hits a device printf + __trap().  Here the frame fails with the reference's text -- the
+    synchronous entry point at once, an asynchronous frame through ITS ticket --, nothing is rendered, and the device, the
+    stream and the thread's next frames are fine.  With every Gaussian in front of the camera the flag changes nothing;
+    fused and two-kernel K1, LDS tables and the global-cursor path."""
+    from gaussiancity_amd import ext
+    P, W, H = 3000, 128, 96
+    rs = scenes.camera(W, H)._replace(sh_degree=1)
+    sc = scenes.blob_scene(P, 17, 1)
+    fr = _frame(oracle_mod, rs, sc)
+    a = list(_args(rs, sc, cuda_device))
+    ok = ext.rasterize_gaussians(*a)
+    assert ok[0] == fr.R
+    a_pre = list(a)
+    a_pre[17] = True   # prefiltered
+    view = rs.view_matrix.numpy().reshape(4, 4)
+    tz = np.concatenate([sc["means3D"], np.ones((P, 1), np.float32)], 1) @ view[:, 2]
+    if (tz > 0.2).all():   # this cloud is in front of the camera: the flag must change nothing
+        out = ext.rasterize_gaussians(*a_pre)
+        assert out[0] == fr.R and np.array_equal(out[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32))
+    # one Gaussian moved behind the camera (its view-space z is negated through the camera's position)
+    campos = rs.campos.numpy()
+    means = sc["means3D"].copy()
+    means[7] = campos - 3.0 * (means[7] - campos)   # mirrored through the camera centre: behind it
+    tz7 = float(np.append(means[7], 1.0) @ view[:, 2])
+    assert tz7 <= 0.2
+    a_bad = list(a_pre)
+    a_bad[1] = G.to_dev(means, cuda_device)
+    a_fine = list(a_bad)
+    a_fine[17] = False
+    fr_bad = _frame(oracle_mod, rs, dict(sc, means3D=means))
+    for opts in ({}, dict(split_preprocess=1), dict(force_global_cursor=1)):
+        with ext.options(**opts):
+            with pytest.raises(RuntimeError, match="Point is filtered although prefiltered is set"):
+                ext.rasterize_gaussians(*a_bad)
+            out = ext.rasterize_gaussians(*a_fine)    # the same cloud without the declaration: culled silently, as upstream
+            assert out[0] == fr_bad.R
+            assert np.array_equal(out[1].cpu().numpy().view(np.uint32), fr_bad.out_color.view(np.uint32)), opts
+    # asynchronous frames: the error is the frame's own ticket's
+    first = ext.rasterize_gaussians_ticket(*a_fine)
+    assert int(first[0]) == fr_bad.R
+    t_bad = ext.rasterize_gaussians_ticket(*a_bad)[0]
+    t_ok = ext.rasterize_gaussians_ticket(*a_fine)
+    assert t_bad.seq != 0 and t_ok[0].seq != 0
+    with pytest.raises(RuntimeError, match="Point is filtered although prefiltered is set"):
+        int(t_bad)
+    assert int(t_ok[0]) == fr_bad.R
+    torch.cuda.synchronize()
+    assert np.array_equal(t_ok[1].cpu().numpy().view(np.uint32), fr_bad.out_color.view(np.uint32))
