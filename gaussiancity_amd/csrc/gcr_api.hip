@@ -551,10 +551,31 @@ static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_g
   b.debug_flags = g_k6_debug.load();
   b.clock_buf = g_clock_buf.load();  // K6: [tile][8] = {hw id | xcc id << 32, clock at entry, at exit, list length, staged, lists built, walk done, steps}
 #endif
+#ifdef GCR_EXPERIMENTS  // GCR_CHAIN_BLEND=1: the blends of consecutive frames (whatever their streams) run one after the other --
+  // they are VALU-bound and gain nothing from sharing the chip -- so that another frame's K1 / binning kernels fall beside
+  // a blend instead of beside their own kind (tools/r05_chain.sh; with GCR_K6_LDS_PAD=2048 there is room for them)
+  static const bool chain = getenv("GCR_CHAIN_BLEND") != nullptr && atoi(getenv("GCR_CHAIN_BLEND")) != 0;
+  static std::mutex chain_mu;
+  static hipEvent_t chain_ev[64] = {};
+  static unsigned chain_n = 0;
+  if (chain) {
+    std::lock_guard<std::mutex> lk(chain_mu);
+    if (chain_n > 0) (void)hipStreamWaitEvent(s, chain_ev[(chain_n - 1) % 64], 0);
+  }
+#endif
   {
     StageTimer t(s, ST_BLEND_FWD);
     HIP_TRY(gcr_launch_blend_fwd(b, sort_in_blend, s), "blend forward");
   }
+#ifdef GCR_EXPERIMENTS
+  if (chain) {
+    std::lock_guard<std::mutex> lk(chain_mu);
+    hipEvent_t& e = chain_ev[chain_n % 64];
+    if (!e) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    (void)hipEventRecord(e, s);
+    chain_n++;
+  }
+#endif
   return debug_sync(cam, s, "blend forward");
 }
 
