@@ -6,9 +6,10 @@ import os
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libgce_hip.so")
 EXPORTED_SYMBOLS = ("gce_abi_version", "gce_last_error", "gce_level_scales", "gce_forward", "gce_backward",
-                    "gce_set_option", "gce_get_stage_ms")
+                    "gce_set_option", "gce_get_stage_ms", "gce_forward_t", "gce_backward_t")
+DTYPE_F32, DTYPE_F16, DTYPE_F64 = 0, 1, 2  # enum gce_dtype
 STAGE_NAMES = ("forward", "backward_embeddings", "backward_inputs")
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 
@@ -29,6 +30,10 @@ def lib():
     L.gce_forward.argtypes = [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, i32, vp, u32, i32, vp]
     L.gce_backward.restype = i32
     L.gce_backward.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, i32, vp, vp, u32, i32, vp]
+    L.gce_forward_t.restype = i32
+    L.gce_forward_t.argtypes = [i32, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, i32, vp, u32, i32, vp]
+    L.gce_backward_t.restype = i32
+    L.gce_backward_t.argtypes = [i32, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, i32, vp, vp, u32, i32, vp]
     L.gce_set_option.restype = i32
     L.gce_set_option.argtypes = [C.c_char_p, i32]
     L.gce_get_stage_ms.restype = i32

@@ -325,6 +325,179 @@ __global__ __launch_bounds__(256) void k_input_bwd(const float* __restrict__ gra
   grad_inputs[t] = r;
 }
 
+// ------------------------------------------------------------------------------ K9t / K10t / K11t: half and double
+// Upstream dispatches its three kernels over the embeddings' dtype (AT_DISPATCH_FLOATING_TYPES_AND_HALF, ge/:555,597):
+// inputs and the interpolation weights stay float, embeddings / outputs / dy_dx / grad / grad_embeddings / grad_inputs are
+// scalar_t, and every accumulator is a scalar_t -- for at::Half that means a rounding to binary16 after every product and
+// every sum (c10::Half: float * Half -> float, Half += float converts the float first, Half + Half rounds once).  GaussianCity
+// itself never leaves float32, so these are plain one-thread-per-(point, level) kernels, not the register-resident float
+// version above; what they keep is the reference's arithmetic, operation for operation (gce-f16-v1 / gce-f64-v1,
+// oracle/grid_oracle_typed.py), so outputs and dy_dx are bit-comparable here too.
+template <typename T>
+struct GceOps;
+template <>
+struct GceOps<double> {
+  static __device__ __forceinline__ double mulw(float w, double g) { return (double)w * g; }  // float * double -> double
+  static __device__ __forceinline__ double add(double a, double b) { return a + b; }
+  static __device__ __forceinline__ double sub(double a, double b) { return a - b; }
+  static __device__ __forceinline__ double mul(double a, double b) { return a * b; }
+  static __device__ __forceinline__ void atomic_add(double* base, size_t i, double v) { atomicAdd(base + i, v); }
+};
+template <>
+struct GceOps<_Float16> {
+  // float * Half -> float (rounded to binary32), THEN Half(float): two roundings, as c10 does it.  The opaque barrier keeps
+  // the compiler from folding the pair into one v_fma_mixlo_f16 (exact product, one rounding to binary16): 1 result in 7 000
+  // differs by an ulp, found by the bit-exact test.  (Half +/- Half and Half * Half are exact in binary32: no such case.)
+  static __device__ __forceinline__ _Float16 mulw(float w, _Float16 g) {
+    float p = w * (float)g;
+    asm volatile("" : "+v"(p));
+    return (_Float16)p;
+  }
+  static __device__ __forceinline__ _Float16 add(_Float16 a, _Float16 b) { return (_Float16)((float)a + (float)b); }
+  static __device__ __forceinline__ _Float16 sub(_Float16 a, _Float16 b) { return (_Float16)((float)a - (float)b); }
+  static __device__ __forceinline__ _Float16 mul(_Float16 a, _Float16 b) { return (_Float16)((float)a * (float)b); }
+  // one binary16 add through the packed atomic (global_atomic_pk_add_f16): the element's pair partner gets +0
+  static __device__ __forceinline__ void atomic_add(_Float16* base, size_t i, _Float16 v) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 pv;
+    pv[0] = (i & 1) ? (_Float16)0.0f : v;
+    pv[1] = (i & 1) ? v : (_Float16)0.0f;
+    __builtin_amdgcn_global_atomic_fadd_v2f16(reinterpret_cast<h2*>(base + (i & ~(size_t)1)), pv);
+  }
+};
+
+template <typename T, int D, int C>
+__global__ __launch_bounds__(256) void k_grid_fwd_t(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                    const int32_t* __restrict__ offsets, T* __restrict__ outputs, uint32_t B,
+                                                    uint32_t L, const LevelScales scales, bool calc_grad_inputs,
+                                                    T* __restrict__ dy_dx, uint32_t gridtype, bool align_corners) {
+  using O = GceOps<T>;
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t level = blockIdx.y;
+  const uint32_t off0 = (uint32_t)offsets[level], off1 = (uint32_t)offsets[level + 1];
+  const T* __restrict__ g = grid + (size_t)off0 * C;
+  T* __restrict__ out = outputs + ((size_t)level * B + b) * C;
+  T* __restrict__ dd = dy_dx + ((size_t)b * L + level) * D * C;
+  const float scale = scales.v[level];
+  float pos[D];
+  uint32_t pos_grid[D];
+  if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, pos, pos_grid)) {
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) out[ch] = (T)0.0f;
+    if (calc_grad_inputs) {
+#pragma unroll
+      for (int i = 0; i < D * C; i++) dd[i] = (T)0.0f;
+    }
+    return;
+  }
+  const uint32_t hashmap_size = off1 - off0;
+  const uint32_t resolution = (uint32_t)ceil(scale) + 1;
+  T results[C];
+#pragma unroll
+  for (int ch = 0; ch < C; ch++) results[ch] = (T)0.0f;
+#pragma unroll
+  for (uint32_t idx = 0; idx < (1u << D); idx++) {  // ge/:152-180
+    float w = 1;
+    uint32_t pl[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      w *= ((idx & (1u << d)) == 0) ? 1 - pos[d] : pos[d];
+      pl[d] = pos_grid[d] + ((idx >> d) & 1u);
+    }
+    const uint32_t index = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pl);
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) results[ch] = O::add(results[ch], O::mulw(w, g[index + ch]));
+  }
+#pragma unroll
+  for (int ch = 0; ch < C; ch++) out[ch] = results[ch];
+  if (calc_grad_inputs) {  // ge/:192-254
+#pragma unroll
+    for (int gd = 0; gd < D; gd++) {
+      T rg[C];
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) rg[ch] = (T)0.0f;
+#pragma unroll
+      for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+        float w = scale;
+        uint32_t pl[D];
+#pragma unroll
+        for (int nd = 0; nd < D - 1; nd++) {
+          const int d = (nd >= gd) ? (nd + 1) : nd;
+          if ((idx & (1u << nd)) == 0) {
+            w *= 1 - pos[d];
+            pl[d] = pos_grid[d];
+          } else {
+            w *= pos[d];
+            pl[d] = pos_grid[d] + 1;
+          }
+        }
+        pl[gd] = pos_grid[gd];
+        const uint32_t il = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pl);
+        pl[gd] = pos_grid[gd] + 1;
+        const uint32_t ir = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pl);
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) rg[ch] = O::add(rg[ch], O::mulw(w, O::sub(g[ir + ch], g[il + ch])));
+      }
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) dd[gd * C + ch] = rg[ch];
+    }
+  }
+}
+
+template <typename T, int D, int C>
+__global__ __launch_bounds__(256) void k_grid_bwd_t(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                    const int32_t* __restrict__ offsets, T* __restrict__ grad_grid, uint32_t B,
+                                                    uint32_t L, const LevelScales scales, uint32_t gridtype,
+                                                    bool align_corners) {
+  using O = GceOps<T>;
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t b = (uint32_t)(t / C), ch = (uint32_t)(t % C);
+  if (b >= B) return;
+  const uint32_t level = blockIdx.y;
+  const uint32_t off0 = (uint32_t)offsets[level], off1 = (uint32_t)offsets[level + 1];
+  const float scale = scales.v[level];
+  float pos[D];
+  uint32_t pos_grid[D];
+  if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, pos, pos_grid)) return;  // grad stays 0
+  const uint32_t hashmap_size = off1 - off0;
+  const uint32_t resolution = (uint32_t)ceil(scale) + 1;
+  const T gc = grad[((size_t)level * B + b) * C + ch];
+#pragma unroll
+  for (uint32_t idx = 0; idx < (1u << D); idx++) {
+    float w = 1;
+    uint32_t pl[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      if ((idx & (1u << d)) == 0) {
+        w *= 1 - pos[d];
+        pl[d] = pos_grid[d];
+      } else {
+        w *= pos[d];
+        pl[d] = pos_grid[d] + 1;
+      }
+    }
+    const size_t i = (size_t)off0 * C + grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pl) + ch;
+    O::atomic_add(grad_grid, i, O::mulw(w, gc));  // ge/:313-335: w * grad rounded to scalar_t, then one scalar_t add
+  }
+}
+
+template <typename T, int D, int C>
+__global__ __launch_bounds__(256) void k_input_bwd_t(const T* __restrict__ grad, const T* __restrict__ dy_dx,
+                                                     T* __restrict__ grad_inputs, uint32_t B, uint32_t L) {
+  using O = GceOps<T>;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * D) return;
+  const uint32_t b = t / D, d = t - b * D;
+  const T* __restrict__ dd = dy_dx + (size_t)b * L * D * C;
+  T r = (T)0.0f;
+  for (uint32_t l = 0; l < L; l++) {
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) r = O::add(r, O::mul(grad[((size_t)l * B + b) * C + ch], dd[(l * D + d) * C + ch]));
+  }
+  grad_inputs[t] = r;
+}
+
 int check_dims(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
   (void)B;
   if (D < 2 || D > 5) return fail(GCE_ERR_UNSUPPORTED, "GridEncoding: D must be 2, 3, 4, or 5.");  // ge/:441-456
@@ -355,6 +528,35 @@ int check_dims(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
   }
 
 }  // namespace
+
+// ---- typed entry points (ABI v2): dtype of embeddings / outputs / dy_dx / grad / grad_embeddings / grad_inputs
+template <typename T>
+static int forward_typed(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B,
+                         uint32_t D, uint32_t C, uint32_t L, const LevelScales& sc, int calc_grad_inputs, void* dy_dx,
+                         uint32_t gridtype, int align_corners, hipStream_t s) {
+  const dim3 grid((B + 255) / 256, L, 1);
+  StageTimer t(s, ST_FWD);
+  GCE_DISPATCH_DC(D, C, (k_grid_fwd_t<T, D, C><<<grid, 256, 0, s>>>(inputs, (const T*)embeddings, offsets, (T*)outputs, B, L, sc,
+                                                                  calc_grad_inputs != 0, (T*)dy_dx, gridtype, align_corners != 0)))
+  return 0;
+}
+template <typename T>
+static int backward_typed(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                          uint32_t D, uint32_t C, uint32_t L, const LevelScales& sc, int calc_grad_inputs, const void* dy_dx,
+                          void* grad_inputs, uint32_t gridtype, int align_corners, hipStream_t s) {
+  const dim3 grid((unsigned)(((uint64_t)B * C + 255) / 256), L, 1);
+  {
+    StageTimer t(s, ST_BWD_EMB);
+    GCE_DISPATCH_DC(D, C, (k_grid_bwd_t<T, D, C><<<grid, 256, 0, s>>>((const T*)grad, inputs, offsets, (T*)grad_embeddings, B, L, sc,
+                                                                    gridtype, align_corners != 0)))
+  }
+  if (calc_grad_inputs) {
+    StageTimer t(s, ST_BWD_IN);
+    GCE_DISPATCH_DC(D, C, (k_input_bwd_t<T, D, C><<<(B * D + 255) / 256, 256, 0, s>>>((const T*)grad, (const T*)dy_dx,
+                                                                                    (T*)grad_inputs, B, L)))
+  }
+  return 0;
+}
 
 extern "C" {
 
@@ -429,6 +631,55 @@ int gce_backward(const float* grad, const float* inputs, const float* embeddings
     GCE_DISPATCH_DC(D, C, (k_input_bwd<D, C><<<(B * D + 255) / 256, 256, 0, s>>>(grad, dy_dx, grad_inputs, B, L)))
     HIP_TRY(hipGetLastError(), "input backward launch");
   }
+  return 0;
+}
+
+
+int gce_forward_t(int dtype, const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B,
+                  uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx,
+                  uint32_t gridtype, int align_corners, void* hip_stream) {
+  if (dtype == GCE_F32)
+    return gce_forward(inputs, (const float*)embeddings, offsets, (float*)outputs, B, D, C, L, S, H, calc_grad_inputs,
+                       (float*)dy_dx, gridtype, align_corners, hip_stream);
+  if (dtype != GCE_F16 && dtype != GCE_F64) return fail(GCE_ERR_UNSUPPORTED, "gce_forward_t: dtype must be GCE_F32, GCE_F16 or GCE_F64");
+  if (int rc = check_dims(B, D, C, L)) return rc;
+  if (B == 0) return 0;
+  if (!inputs || !embeddings || !offsets || !outputs) return fail(GCE_ERR_INVALID_ARGUMENT, "gce_forward_t: null tensor");
+  if (calc_grad_inputs && !dy_dx) return fail(GCE_ERR_INVALID_ARGUMENT, "gce_forward_t: calc_grad_inputs needs dy_dx");
+  LevelScales sc;
+  gce_level_scales(L, S, H, sc.v);
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int rc = dtype == GCE_F16
+                     ? forward_typed<_Float16>(inputs, embeddings, offsets, outputs, B, D, C, L, sc, calc_grad_inputs, dy_dx, gridtype, align_corners, s)
+                     : forward_typed<double>(inputs, embeddings, offsets, outputs, B, D, C, L, sc, calc_grad_inputs, dy_dx, gridtype, align_corners, s);
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError(), "grid forward launch");
+  return 0;
+}
+
+int gce_backward_t(int dtype, const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                   void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                   int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                   void* hip_stream) {
+  if (dtype == GCE_F32)
+    return gce_backward((const float*)grad, inputs, (const float*)embeddings, offsets, (float*)grad_embeddings, B, D, C, L, S, H,
+                        calc_grad_inputs, (const float*)dy_dx, (float*)grad_inputs, gridtype, align_corners, hip_stream);
+  if (dtype != GCE_F16 && dtype != GCE_F64) return fail(GCE_ERR_UNSUPPORTED, "gce_backward_t: dtype must be GCE_F32, GCE_F16 or GCE_F64");
+  if (int rc = check_dims(B, D, C, L)) return rc;
+  if (B == 0) return 0;
+  if (!grad || !inputs || !offsets || !grad_embeddings) return fail(GCE_ERR_INVALID_ARGUMENT, "gce_backward_t: null tensor");
+  if (calc_grad_inputs && (!dy_dx || !grad_inputs))
+    return fail(GCE_ERR_INVALID_ARGUMENT, "gce_backward_t: calc_grad_inputs needs dy_dx and grad_inputs");
+  if (dtype == GCE_F16 && ((uintptr_t)grad_embeddings & 3u))
+    return fail(GCE_ERR_INVALID_ARGUMENT, "gce_backward_t: half grad_embeddings must be 4-byte aligned (packed atomics)");
+  LevelScales sc;
+  gce_level_scales(L, S, H, sc.v);
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int rc = dtype == GCE_F16
+                     ? backward_typed<_Float16>(grad, inputs, offsets, grad_embeddings, B, D, C, L, sc, calc_grad_inputs, dy_dx, grad_inputs, gridtype, align_corners, s)
+                     : backward_typed<double>(grad, inputs, offsets, grad_embeddings, B, D, C, L, sc, calc_grad_inputs, dy_dx, grad_inputs, gridtype, align_corners, s);
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError(), "grid backward launch");
   return 0;
 }
 

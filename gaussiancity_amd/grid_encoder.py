@@ -7,7 +7,8 @@
                                parameter name `embeddings`, init range, output layout)
 
 torch supplies device memory, autograd plumbing and the current stream; the computation is in the HIP
-library.  float32 only (upstream also dispatches half/double; GaussianCity keeps float32 embeddings).
+library.  The embeddings' dtype selects the kernels as upstream's AT_DISPATCH_FLOATING_TYPES_AND_HALF does
+(grid_encoder_ext.cu:555,597): float32 (GaussianCity's own; the tuned kernels), float16, float64.  `inputs` are float32.
 """
 import ctypes as C
 import math
@@ -21,43 +22,57 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_DTYPES = {torch.float32: E.DTYPE_F32, torch.float16: E.DTYPE_F16, torch.float64: E.DTYPE_F64}
+
+
 def _chk(t, name, dtype=None):
     if not t.is_cuda:
         raise RuntimeError("%s must be a CUDA tensor" % name)             # CHECK_CUDA, grid_encoder_ext.cu:466-470
     if not t.is_contiguous():
         raise RuntimeError("%s must be a contiguous tensor" % name)       # CHECK_CONTIGUOUS, :472-476
     if dtype is not None and t.dtype != dtype:
-        raise RuntimeError("%s must be %s (this build is float32 only)" % (name, dtype))
+        raise RuntimeError("%s must be %s" % (name, dtype))
+
+
+def _scalar_type(embeddings):
+    """gce_dtype of the call: the embeddings' dtype, as upstream dispatches (grid_encoder_ext.cu:555)."""
+    code = _DTYPES.get(embeddings.dtype)
+    if code is None:
+        raise RuntimeError("embeddings must be float32, float16 or float64 (got %s)" % embeddings.dtype)
+    return code
 
 
 def ext_forward(inputs, embeddings, offsets, outputs, B, D, C_, L, S, H, calc_grad_inputs, dy_dx, gridtype, align_corners):
     """grid_encoder_ext.forward (bindings.cpp:19-24): fills outputs [L,B,C] (and dy_dx [B, L*D*C])."""
     _chk(inputs, "inputs", torch.float32)
-    _chk(embeddings, "embeddings", torch.float32)
+    code = _scalar_type(embeddings)
+    _chk(embeddings, "embeddings")
     _chk(offsets, "offsets")
     if offsets.dtype != torch.int32:
         raise RuntimeError("offsets must be an int tensor")               # CHECK_IS_INT, :480
-    _chk(outputs, "outputs", torch.float32)
-    _chk(dy_dx, "dy_dx", torch.float32)
+    _chk(outputs, "outputs", embeddings.dtype)
+    _chk(dy_dx, "dy_dx", embeddings.dtype)
     with torch.cuda.device(inputs.device):
-        E.check(E.lib().gce_forward(inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(), outputs.data_ptr(),
-                                    int(B), int(D), int(C_), int(L), float(S), int(H), int(bool(calc_grad_inputs)),
-                                    dy_dx.data_ptr(), int(gridtype), int(bool(align_corners)), _stream()),
+        E.check(E.lib().gce_forward_t(code, inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(), outputs.data_ptr(),
+                                      int(B), int(D), int(C_), int(L), float(S), int(H), int(bool(calc_grad_inputs)),
+                                      dy_dx.data_ptr(), int(gridtype), int(bool(align_corners)), _stream()),
                 "gce_forward")
 
 
 def ext_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C_, L, S, H, calc_grad_inputs, dy_dx,
                  grad_inputs, gridtype, align_corners):
     """grid_encoder_ext.backward (bindings.cpp:25-33): accumulates into grad_embeddings, fills grad_inputs."""
-    for t, n in ((grad, "grad"), (inputs, "inputs"), (embeddings, "embeddings"), (grad_embeddings, "grad_embeddings"),
-                 (dy_dx, "dy_dx"), (grad_inputs, "grad_inputs")):
-        _chk(t, n, torch.float32)
+    code = _scalar_type(embeddings)
+    _chk(inputs, "inputs", torch.float32)
+    for t, n in ((grad, "grad"), (embeddings, "embeddings"), (grad_embeddings, "grad_embeddings"), (dy_dx, "dy_dx"),
+                 (grad_inputs, "grad_inputs")):
+        _chk(t, n, embeddings.dtype)
     _chk(offsets, "offsets")
     with torch.cuda.device(inputs.device):
-        E.check(E.lib().gce_backward(grad.data_ptr(), inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(),
-                                     grad_embeddings.data_ptr(), int(B), int(D), int(C_), int(L), float(S), int(H),
-                                     int(bool(calc_grad_inputs)), dy_dx.data_ptr(), grad_inputs.data_ptr(),
-                                     int(gridtype), int(bool(align_corners)), _stream()), "gce_backward")
+        E.check(E.lib().gce_backward_t(code, grad.data_ptr(), inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(),
+                                       grad_embeddings.data_ptr(), int(B), int(D), int(C_), int(L), float(S), int(H),
+                                       int(bool(calc_grad_inputs)), dy_dx.data_ptr(), grad_inputs.data_ptr(),
+                                       int(gridtype), int(bool(align_corners)), _stream()), "gce_backward")
 
 
 class _Geometry:

@@ -19,7 +19,11 @@
  *               upstream's torch.zeros_like); grad_inputs float [B][D]
  *   B points, D in 2..5 input dims, C in {1,2,4,8} channels per level, L <= 32 levels,
  *   S = log2(per_level_scale), H = base resolution, gridtype 0 = hash / 1 = tiled.
- * float32 only (GaussianCity's embeddings are float32; upstream also dispatches half/double).
+ * gce_forward / gce_backward are the float32 entry points (GaussianCity's embeddings are float32).  gce_forward_t /
+ * gce_backward_t (ABI v2) take the dtype upstream dispatches over (AT_DISPATCH_FLOATING_TYPES_AND_HALF, grid_encoder_ext.cu:
+ * 555,597): `inputs` stay float; embeddings, outputs, dy_dx, grad, grad_embeddings and grad_inputs are GCE_F32 float,
+ * GCE_F16 IEEE binary16 or GCE_F64 double, every accumulator in that type with upstream's roundings (c10::Half rounds
+ * after every product and every sum).
  * The per-level scale exp2f(level*S)*H - 1 is evaluated on the host (gce_level_scales) -- see
  * oracle/gce_oracle.c "gce-fp32-v1".  Returns 0 or a negative gce_status; gce_last_error() has the text.
  */
@@ -32,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GCE_ABI_VERSION 1
+#define GCE_ABI_VERSION 2
 #define GCE_MAX_LEVELS 32
 
 enum gce_status { GCE_OK = 0, GCE_ERR_INVALID_ARGUMENT = -1, GCE_ERR_HIP = -2, GCE_ERR_UNSUPPORTED = -3 };
@@ -51,6 +55,15 @@ int gce_backward(const float* grad, const float* inputs, const float* embeddings
                  float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                  int calc_grad_inputs, const float* dy_dx, float* grad_inputs, uint32_t gridtype, int align_corners,
                  void* hip_stream);
+
+enum gce_dtype { GCE_F32 = 0, GCE_F16 = 1, GCE_F64 = 2 };
+int gce_forward_t(int dtype, const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B,
+                  uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx,
+                  uint32_t gridtype, int align_corners, void* hip_stream);
+int gce_backward_t(int dtype, const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                   void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                   int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                   void* hip_stream);
 
 /* avg device ms per stage since the last call (option "timing"): 0 forward, 1 backward_embeddings, 2 backward_inputs */
 int gce_set_option(const char* name, int value);

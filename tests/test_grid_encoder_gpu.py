@@ -118,5 +118,53 @@ def test_argument_errors(cuda_device):
                        1.0, 4, False, dd, 0, False)
     with pytest.raises(RuntimeError, match="D must be"):  # :455
         GE.ext_forward(torch.rand(8, 6, device=cuda_device), emb, off, out, 8, 6, 2, 2, 1.0, 4, False, dd, 0, False)
-    with pytest.raises(RuntimeError, match="float32"):
-        GE.ext_forward(x, emb.half(), off, out.half(), 8, 3, 2, 2, 1.0, 4, False, dd.half(), 0, False)
+    with pytest.raises(RuntimeError, match="outputs must be torch.float16"):   # one dtype per call: the embeddings'
+        GE.ext_forward(x, emb.half(), off, out, 8, 3, 2, 2, 1.0, 4, False, dd.half(), 0, False)
+    with pytest.raises(RuntimeError, match="float32, float16 or float64"):
+        GE.ext_forward(x, emb.bfloat16(), off, out.bfloat16(), 8, 3, 2, 2, 1.0, 4, False, dd.bfloat16(), 0, False)
+    with pytest.raises(RuntimeError, match="inputs must be torch.float32"):      # inputs stay float (ge/:97)
+        GE.ext_forward(x.double(), emb.double(), off, out.double(), 8, 3, 2, 2, 1.0, 4, False, dd.double(), 0, False)
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float64], ids=["half", "double"])
+@pytest.mark.parametrize("D,C,gridtype,align,lh", [(2, 1, 0, False, 8), (3, 2, 0, False, 9), (3, 4, 1, True, 13), (4, 8, 0, True, 10),
+                                                    (5, 8, 0, False, 11), (5, 1, 1, False, 9)])
+def test_half_and_double_dispatch_matches_the_typed_oracle(cuda_device, dtype, D, C, gridtype, align, lh):
+    """Upstream dispatches the three kernels over the embeddings' dtype (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+    grid_encoder_ext.cu:555,597); GaussianCity itself stays in float32, the drop-in does not have to.  Against
+    oracle/grid_oracle_typed.py (the reference's arithmetic with scalar_t accumulators: c10::Half rounds after every product
+    and every sum): outputs, dy_dx and grad_inputs BIT-EXACT in both dtypes; grad_embeddings is a sum of scalar_t atomics
+    (order-dependent roundings): 1e-12 * max in double, and in half within the rounding a sum of that many binary16 addends
+    can carry."""
+    from oracle import grid_oracle_typed as GT
+    rng = np.random.default_rng(7 * D + C)
+    L, B = 4, 1777
+    x, emb32, offsets, S, H = GU.make_case(rng, B, D, C, L, base=3, desired=40, log2_hashmap=lh, align_corners=align)
+    emb = emb32.astype(dtype)
+    grad = rng.normal(size=(L, B, C)).astype(dtype)
+    out_o, dd_o = GT.forward(x, emb, offsets, S, H, True, gridtype, align)
+    ge_o, gi_o = GT.backward(grad, x, emb.shape, offsets, S, H, dd_o, gridtype, align)
+    tdt = torch.float16 if dtype == np.float16 else torch.float64
+    dev = cuda_device
+    xt, et, ot = torch.from_numpy(x).to(dev), torch.from_numpy(emb).to(dev), torch.from_numpy(offsets).to(dev)
+    out = torch.empty(L, B, C, device=dev, dtype=tdt)
+    dd = torch.empty(B, L * D * C, device=dev, dtype=tdt)
+    GE.ext_forward(xt, et, ot, out, B, D, C, L, S, H, True, dd, gridtype, align)
+    ge = torch.zeros_like(et)
+    gi = torch.zeros(B, D, device=dev, dtype=tdt)
+    GE.ext_backward(torch.from_numpy(grad).to(dev), xt, et, ot, ge, B, D, C, L, S, H, True, dd, gi, gridtype, align)
+    bits = np.uint16 if dtype == np.float16 else np.uint64
+    assert np.array_equal(out.cpu().numpy().view(bits), out_o.view(bits)), "outputs not bit-exact"
+    assert np.array_equal(dd.cpu().numpy().reshape(B, L, D, C).view(bits), dd_o.view(bits)), "dy_dx not bit-exact"
+    assert np.array_equal(gi.cpu().numpy().view(bits), gi_o.view(bits)), "grad_inputs not bit-exact"
+    err = float(np.abs(ge.cpu().numpy().astype(np.float64) - ge_o.astype(np.float64)).max())
+    scale = max(1.0, float(np.abs(ge_o.astype(np.float64)).max()))
+    assert err <= (1e-12 if dtype == np.float64 else 2e-2) * scale, (err, scale)
+    # the module: a half / double table runs through the same autograd node and returns the table's dtype
+    enc = GE.GridEncoder(in_channels=D, n_levels=3, lvl_channels=C, desired_resolution=32, base_resolution=4,
+                         log2_hashmap_size=9).to(dev).to(tdt)
+    xin = (torch.rand(257, D, device=dev) * 2 - 1).requires_grad_(True)
+    y = enc(xin)
+    assert y.dtype == tdt and tuple(y.shape) == (257, 3 * C)
+    y.float().sum().backward()
+    assert enc.embeddings.grad.dtype == tdt and xin.grad.dtype == torch.float32 and bool(torch.isfinite(xin.grad).all())

@@ -112,3 +112,28 @@ def test_level_scales_and_hash_constants(go):
     out, _ = go.forward(x, emb, offsets, 0.0, 4, False, 1, False)  # scale = 3, res = 4
     # pos = (2.0, 1.25): cell (2,1), frac (0, .25) -> rows 7 (w .75) and 12 (w .25)
     assert abs(float(out[0, 0, 0]) - (0.75 * 7 + 0.25 * 12)) < 1e-6
+
+
+@pytest.mark.parametrize("D,C,L,gridtype,align,lh", CASES)
+def test_typed_oracle_agrees_with_the_float32_oracle(go, D, C, L, gridtype, align, lh):
+    """oracle/grid_oracle_typed.py (numpy; scalar_t = double / at::Half, what upstream's dtype dispatch instantiates) is
+    pinned through the C oracle it restates: in double it agrees with the float32 oracle to float32 rounding (outputs 1e-6,
+    dy_dx 1e-4 * max, gradients likewise), in half to binary16 rounding; rows outside [0, 1] encode to exact zeros."""
+    from oracle import grid_oracle_typed as GT
+    rng = np.random.default_rng(100 * D + C)
+    B = 200
+    x, emb, offsets, S, H = GU.make_case(rng, B, D, C, L, base=3, desired=40, log2_hashmap=lh, align_corners=align)
+    assert np.array_equal(GT.level_scales(L, S, H), go.level_scales(L, S, H))
+    o32, d32 = go.forward(x, emb, offsets, S, H, True, gridtype, align)
+    g = rng.normal(size=(L, B, C)).astype(np.float32)
+    ge32, gi32 = go.backward(g, x, emb.shape, offsets, S, H, d32, gridtype, align)
+    inside = ((x >= 0) & (x <= 1)).all(axis=1)
+    for T, t_out, t_dd in ((np.float64, 1e-6, 1e-4), (np.float16, 4e-3, 2e-2)):
+        o, d = GT.forward(x, emb.astype(T), offsets, S, H, True, gridtype, align)
+        assert o.dtype == T and d.dtype == T
+        assert float(np.abs(o.astype(np.float64) - o32).max()) <= t_out * max(1.0, float(np.abs(o32).max()))
+        assert float(np.abs(d.astype(np.float64) - d32).max()) <= t_dd * max(1.0, float(np.abs(d32).max()))
+        assert np.all(o[:, ~inside] == 0) and np.all(d[~inside] == 0)
+        ge, gi = GT.backward(g.astype(T), x, emb.shape, offsets, S, H, d, gridtype, align)
+        assert float(np.abs(ge.astype(np.float64) - ge32).max()) <= 10 * t_out * max(1.0, float(np.abs(ge32).max()))
+        assert float(np.abs(gi.astype(np.float64) - gi32).max()) <= (1e-4 if T == np.float64 else 5e-2) * max(1.0, float(np.abs(gi32).max()))
