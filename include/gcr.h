@@ -148,8 +148,11 @@ typedef struct gcr_grads {
   float *dL_dconic;     /* [P, gcr_grad_record_floats()] (16 floats; 32 in the deterministic mode) scratch (contents undefined on return), 64-byte
                            aligned: the role of the
                            reference's dL_dconic [P,2,2] (dgr/rasterize_points.cu:121), widened to one
-                           64-byte accumulation record per Gaussian (colour 3, opacity 1, mean2D 2,
-                           conic 3, pad) so that K7's nine atomics per (tile, Gaussian) share a cache line */
+                           64-byte accumulation record per Gaussian so that K7's nine atomics per (tile piece,
+                           Gaussian) share a cache line.  Since ABI v7 the nine sums are the colour gradient and six
+                           MOMENTS of G * dL/dalpha over the pixel offset (S, Sx, Sy, Sxx, Sxy, Syy); the preprocess
+                           gradient kernel turns them into dL_dopacity / dL_dmeans2D / the conic gradient with the
+                           Gaussian's opacity and conic -- the record itself is no longer the reference's dL_dconic */
   float *dL_dopacity;   /* [P] */
   float *dL_dcolors;    /* [P,3] */
   float *dL_dmeans3D;   /* [P,3] */
