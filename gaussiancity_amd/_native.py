@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("GCR_LIB_PATH") or os.path.join(_CSRC, "libgcr_hip.so"
 EXPORTED_SYMBOLS = (
     "gcr_abi_version", "gcr_last_error", "gcr_geometry_bytes", "gcr_image_bytes",
     "gcr_binning_bytes", "gcr_get_layout", "gcr_forward", "gcr_forward_preprocess", "gcr_forward_render",
-    "gcr_backward", "gcr_mark_visible", "gcr_rasterize_forward", "gcr_set_option",
+    "gcr_backward", "gcr_build_cull_cache", "gcr_cull_cache_bytes", "gcr_mark_visible", "gcr_rasterize_forward", "gcr_set_option",
     "gcr_get_stage_ms", "gcr_grad_record_floats", "gcr_grad_record_floats_opt", "gcr_binning_bytes_lean",
     "gcr_forward_async", "gcr_ticket_poll", "gcr_ticket_wait", "gcr_host_words_alloc", "gcr_host_words_free", "gcr_rescue_count",
     "gcr_get_option", "gcr_rescue_dropped_count",
@@ -67,6 +67,7 @@ class Gaussians(C.Structure):
         ("cov3D_precomp", C.c_void_p),
         ("stride_means3D", C.c_int32), ("stride_opacities", C.c_int32), ("stride_colors", C.c_int32),
         ("stride_scales", C.c_int32), ("stride_rotations", C.c_int32),
+        ("cull_cache", C.c_void_p),  # ABI v8: gcr_cull_cache_bytes(P) bytes of gcr_build_cull_cache, or NULL
     ]
 
 
@@ -98,7 +99,7 @@ class FrameInfo(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("max_tile_instances", C.c_int64)]
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 TICKET_WORDS = 8  # 64-bit pinned host words per asynchronous frame (include/gcr.h, gcr_forward_async)
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -168,6 +169,10 @@ def lib():
     L.gcr_backward.argtypes = [C.POINTER(Camera), C.POINTER(Gaussians), C.c_void_p, C.c_void_p,
                                C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                C.c_int64, C.c_void_p, C.POINTER(Grads), C.c_void_p]
+    L.gcr_cull_cache_bytes.restype = C.c_size_t
+    L.gcr_cull_cache_bytes.argtypes = [C.c_int32]
+    L.gcr_build_cull_cache.restype = C.c_int
+    L.gcr_build_cull_cache.argtypes = [C.POINTER(Gaussians), C.c_float, C.c_void_p, C.c_void_p]
     L.gcr_mark_visible.restype = C.c_int
     L.gcr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]

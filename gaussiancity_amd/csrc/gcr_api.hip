@@ -238,6 +238,8 @@ int check_inputs(const gcr_camera* cam, const gcr_gaussians* g, bool need_opacit
   if (has_sr == (g->cov3D_precomp != nullptr) || ((g->scales != nullptr) != (g->rotations != nullptr)))
     return fail(GCR_ERR_INVALID_ARGUMENT,
                 "provide exactly one of scale/rotation pair or precomputed 3D covariance");
+  if (g->cull_cache && ((uintptr_t)g->cull_cache & 127u))
+    return fail(GCR_ERR_INVALID_ARGUMENT, "cull_cache must be 128-byte aligned (gcr_cull_cache_bytes(P) bytes filled by gcr_build_cull_cache)");
   if (g->shs) {
     if (cam->sh_degree < 0 || cam->sh_degree > 3) return fail(GCR_ERR_INVALID_ARGUMENT, "sh_degree must be 0..3");
     if (g->M < (cam->sh_degree + 1) * (cam->sh_degree + 1))
@@ -388,6 +390,11 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
   a.s_scale = stride_or(g->stride_scales, 3);
   a.s_rot = stride_or(g->stride_rotations, 4);
   a.prefiltered = cam->prefiltered != 0;
+#ifdef GCR_EXPERIMENTS
+  a.exp_flags = 0;
+#endif
+  a.cull_cache = op.split_preprocess ? nullptr : reinterpret_cast<const float4*>(g->cull_cache);
+  a.cull_shape = a.cull_cache ? reinterpret_cast<const float4*>((const char*)g->cull_cache + gcr_cull_cache_offset_b(g->P)) : nullptr;
   fill_cam(a.cam, cam);
   a.radii = radii;
   a.rec = (float4*)(gb + L.geom_rec);
@@ -1296,6 +1303,36 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
     HIP_TRY(gcr_launch_preprocess_bwd(a, s), "preprocess backward");
   }
   return debug_sync(cam, s, "preprocess backward");
+}
+
+size_t gcr_cull_cache_bytes(int32_t P) { return P > 0 ? gcr_cull_cache_offset_b(P) + (size_t)P * 32 : 0; }
+
+int gcr_build_cull_cache(const gcr_gaussians* g, float scale_modifier, void* cull_cache_out, void* hip_stream) {
+  if (!g) return fail(GCR_ERR_INVALID_ARGUMENT, "null gaussians record");
+  if (g->P < 0 || g->P > 700000000) return fail(GCR_ERR_INVALID_ARGUMENT, "P must be 0 .. 700 000 000");
+  if (g->P == 0) return 0;
+  if (!g->means3D) return fail(GCR_ERR_INVALID_ARGUMENT, "means3D must have dimensions (num_points, 3)");
+  if (!g->opacities) return fail(GCR_ERR_INVALID_ARGUMENT, "opacities must be non-null");
+  const bool has_sr = g->scales != nullptr && g->rotations != nullptr;
+  if (has_sr == (g->cov3D_precomp != nullptr) || ((g->scales != nullptr) != (g->rotations != nullptr)))
+    return fail(GCR_ERR_INVALID_ARGUMENT, "provide exactly one of scale/rotation pair or precomputed 3D covariance");
+  if (!cull_cache_out || ((uintptr_t)cull_cache_out & 127u))
+    return fail(GCR_ERR_INVALID_ARGUMENT, "cull_cache_out must be a 128-byte aligned buffer of gcr_cull_cache_bytes(P) bytes");
+  GcrPreprocessArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = g->P;
+  a.scale_modifier = scale_modifier;
+  a.means3D = g->means3D; a.scales = g->scales; a.rotations = g->rotations; a.cov3D_precomp = g->cov3D_precomp;
+  a.opacities = g->opacities;
+  a.s_mean = stride_or(g->stride_means3D, 3);
+  a.s_scale = stride_or(g->stride_scales, 3);
+  a.s_rot = stride_or(g->stride_rotations, 4);
+  a.s_opac = stride_or(g->stride_opacities, 1);
+  HIP_TRY(gcr_launch_build_cull_cache(a, reinterpret_cast<float4*>(cull_cache_out),
+                                      reinterpret_cast<float4*>((char*)cull_cache_out + gcr_cull_cache_offset_b(g->P)),
+                                      (hipStream_t)hip_stream),
+          "build cull cache");
+  return 0;
 }
 
 int gcr_mark_visible(int32_t P, const float* means3D, const float* view_matrix,

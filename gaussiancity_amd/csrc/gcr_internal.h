@@ -41,6 +41,11 @@ struct GcrPreprocessArgs {
   int nblocks, chunk;    // persistent grid: block b owns Gaussians [b*chunk, (b+1)*chunk)
   int s_mean, s_opac, s_col, s_scale, s_rot;  // row strides in floats (3 / 1 / 3 / 3 / 4 when dense)
   int prefiltered;  // gcr_camera.prefiltered: a Gaussian behind the near plane is an error of the caller (GCR_PREFILTER_*)
+  const float4* cull_cache;  // gcr_gaussians.cull_cache, part A: [P] (mean, rho) records of gcr_build_cull_cache, or null (stateless)
+#ifdef GCR_EXPERIMENTS
+  int exp_flags;  // bit 0: GCR_K1_SH_TOUCH
+#endif
+  const float4* cull_shape;  // ... part B: [P] x 32 bytes (scales, opacity, rotation) or (covariance, opacity, 0)
   GcrCamVals cam;
 };
 
@@ -245,6 +250,9 @@ struct GcrBlendArgs {
 hipError_t gcr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present,
                                    hipStream_t s);
 hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, bool split, hipStream_t s);
+hipError_t gcr_launch_build_cull_cache(const GcrPreprocessArgs& a, float4* outA, float4* outB, hipStream_t s);
+// the cache buffer: part A at offset 0, part B at gcr_cull_cache_offset_b(P) (128-byte aligned)
+static inline size_t gcr_cull_cache_offset_b(int P) { return (((size_t)P * 16) + 127) & ~(size_t)127; }
 // zero the K7 accumulation records of K1's survivors / stream zeros over the backward's outputs (R == 0 frames)
 hipError_t gcr_launch_zero_grad_records(int nblocks, int chunk, const uint32_t* vis_list, const uint32_t* vis_count,
                                         float4* grad_rec, int rec_quads, hipStream_t s);

@@ -160,6 +160,43 @@ GCR_DEV void phase_a_load(const GcrPreprocessArgs& a, long long idx, PhaseAIn& i
   }
 }
 
+// The covariance inputs only (a cached cull's candidate: its mean comes from the cache, bit for bit the caller's)
+template <bool PRECOMP_COV>
+GCR_DEV void phase_a_load_shape(const GcrPreprocessArgs& a, long long idx, PhaseAIn& in) {
+  if (PRECOMP_COV) {
+    const float* __restrict__ c = a.cov3D_precomp + 6 * (size_t)idx;
+    in.c0 = c[0]; in.c1 = c[1]; in.c2 = c[2]; in.c3 = c[3]; in.c4 = c[4]; in.c5 = c[5];
+    in.c6 = 0.0f;
+  } else {
+    const float* __restrict__ sp = a.scales + (size_t)idx * a.s_scale;
+    in.c0 = sp[0];
+    in.c1 = sp[1];
+    in.c2 = sp[2];
+    const float* __restrict__ rp = a.rotations + (size_t)idx * a.s_rot;
+    if (a.s_rot == 4) {
+      const float4 rot = *reinterpret_cast<const float4*>(rp);
+      in.c3 = rot.x; in.c4 = rot.y; in.c5 = rot.z; in.c6 = rot.w;
+    } else {
+      in.c3 = rp[0]; in.c4 = rp[1]; in.c5 = rp[2]; in.c6 = rp[3];
+    }
+  }
+}
+
+// What the streaming cull reads per Gaussian.  CACHED (gcr_gaussians.cull_cache): ONE 16-byte load -- the mean and the
+// camera-independent half of the screen bound (cull_rho below), as k_build_cull_cache left them -- instead of 40 bytes
+// from three arrays (56 when the caller's rows are [N,14]); c0 carries rho, the other fields are constants the compiler drops.
+template <bool PRECOMP_COV, bool CACHED>
+GCR_DEV void stream_load(const GcrPreprocessArgs& a, long long idx, PhaseAIn& in) {
+  if (CACHED) {
+    const float4 c = a.cull_cache[idx];
+    in.p = {c.x, c.y, c.z};
+    in.c0 = c.w;
+    in.c1 = in.c2 = in.c3 = in.c4 = in.c5 = in.c6 = 0.0f;
+  } else {
+    phase_a_load<PRECOMP_COV>(a, idx, in);
+  }
+}
+
 // Wave-uniform float forced into an SGPR.  The camera matrices are read once per kernel this way:
 // left to itself the compiler re-fetched them with VECTOR loads in every loop iteration (it
 // cannot prove them invariant next to the kernel's stores, so no s_load).
@@ -179,9 +216,26 @@ GCR_DEV float gcr_uniform(float v) { return __int_as_float(__builtin_amdgcn_read
 //    times over by the 2 % + 2 px inflation.  NaN anywhere makes the comparisons false -> candidate.
 //    The radius bound is about 2x the true radius for unit quaternions and a rigid camera, so the
 //    extra candidates are the Gaussians within a couple of radii of the screen border.
+// rho >= spectral radius of the Gaussian's world-space covariance, scale_modifier included: the one per-Gaussian
+// quantity of the bound above that does not depend on the camera (what gcr_build_cull_cache stores beside the mean).
+template <bool PRECOMP_COV>
+GCR_DEV float cull_rho(float scale_modifier, const PhaseAIn& in) {
+  if (PRECOMP_COV) {
+    return __builtin_amdgcn_sqrtf(in.c0 * in.c0 + in.c3 * in.c3 + in.c5 * in.c5 +
+                                  2.0f * (in.c1 * in.c1 + in.c2 * in.c2 + in.c4 * in.c4)) * 1.001f;
+  } else {
+    const float q2 = __builtin_fmaf(in.c3, in.c3, __builtin_fmaf(in.c4, in.c4, __builtin_fmaf(in.c5, in.c5, in.c6 * in.c6)));
+    // diagonal 1 - 2(u^2+v^2) lies in [1 - 2|q|^2, 1]; off-diagonal 2(uv +- rw) <= |q|^2 (AM-GM)
+    const float rmax = __builtin_fmaxf(1.0f, __builtin_fmaf(2.0f, q2, -1.0f)) * 1.0001f;  // >= every |R_ij|
+    const float smax = scale_modifier * __builtin_fmaxf(__builtin_fabsf(in.c0),
+                                                        __builtin_fmaxf(__builtin_fabsf(in.c1), __builtin_fabsf(in.c2)));
+    return 9.0f * (smax * smax) * (rmax * rmax);
+  }
+}
+
 template <bool PRECOMP_COV>
 GCR_DEV bool phase_a0_certainly_culled(const GcrPreprocessArgs& a, const float (&vm)[16], const float (&pm)[16],
-                                       float wf2, const PhaseAIn& in) {
+                                       float wf2, const PhaseAIn& in, float rho) {
   const float tz = vm[2] * in.p.x + vm[6] * in.p.y + vm[10] * in.p.z + vm[14];  // exact, as transformPoint4x3
   if (tz <= 0.2f) return true;  // in_frustum, cr/auxiliary.h:145
   const float tx = __builtin_fmaf(vm[0], in.p.x, __builtin_fmaf(vm[4], in.p.y, __builtin_fmaf(vm[8], in.p.z, vm[12])));
@@ -193,18 +247,6 @@ GCR_DEV bool phase_a0_certainly_culled(const GcrPreprocessArgs& a, const float (
   const float half_w = 0.5f * (float)a.W, half_h = 0.5f * (float)a.H;
   const float px = __builtin_fmaf(hx * pw, half_w, half_w - 0.5f);  // ((ndc+1)*W-1)/2
   const float py = __builtin_fmaf(hy * pw, half_h, half_h - 0.5f);
-  float rho;  // >= spectral radius of Sigma
-  if (PRECOMP_COV) {
-    rho = __builtin_amdgcn_sqrtf(in.c0 * in.c0 + in.c3 * in.c3 + in.c5 * in.c5 +
-                                 2.0f * (in.c1 * in.c1 + in.c2 * in.c2 + in.c4 * in.c4)) * 1.001f;
-  } else {
-    const float q2 = __builtin_fmaf(in.c3, in.c3, __builtin_fmaf(in.c4, in.c4, __builtin_fmaf(in.c5, in.c5, in.c6 * in.c6)));
-    // diagonal 1 - 2(u^2+v^2) lies in [1 - 2|q|^2, 1]; off-diagonal 2(uv +- rw) <= |q|^2 (AM-GM)
-    const float rmax = __builtin_fmaxf(1.0f, __builtin_fmaf(2.0f, q2, -1.0f)) * 1.0001f;  // >= every |R_ij|
-    const float smax = a.scale_modifier * __builtin_fmaxf(__builtin_fabsf(in.c0),
-                                                          __builtin_fmaxf(__builtin_fabsf(in.c1), __builtin_fabsf(in.c2)));
-    rho = 9.0f * (smax * smax) * (rmax * rmax);
-  }
   const float rtz = __builtin_amdgcn_rcpf(tz);
   const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
   const float cx = __builtin_fminf(limx, __builtin_fmaxf(-limx, tx * rtz));
@@ -338,9 +380,18 @@ GCR_DEV float sh_accumulate(int i, int deg, const ShDir& d, float result, float 
   return deg > 2 ? result + sh_term(i, d, s) : result;
 }
 
+#ifdef GCR_EXPERIMENTS  /* experiment builds toggle it per launch (GCR_K1_SH_TOUCH in the environment) */
+#define GCR_K1_SH_TOUCH_ON(a) (((a).exp_flags & 1) != 0)
+#elif defined(GCR_K1_SH_TOUCH)
+#define GCR_K1_SH_TOUCH_ON(a) true
+#else
+#define GCR_K1_SH_TOUCH_ON(a) false
+#endif
+
+template <bool HAVE_OPACITY = false>
 GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 mean, const Projected& pr,
-                                uint32_t list_pos, uint32_t* __restrict__ vis_list) {
-  const float opacity = a.opacities[(size_t)idx * a.s_opac];
+                                uint32_t list_pos, uint32_t* __restrict__ vis_list, float cached_opacity = 0.0f) {
+  const float opacity = HAVE_OPACITY ? cached_opacity : a.opacities[(size_t)idx * a.s_opac];
   float cr, cg, cb;
   if (a.colors_precomp == nullptr) {
     const float ox = mean.x - GCR_CAM(a, campos, a.campos, 0), oy = mean.y - GCR_CAM(a, campos, a.campos, 1),
@@ -355,9 +406,19 @@ GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 me
     float res[3] = {0.0f, 0.0f, 0.0f};
     if (a.M == 16) {
       const float4* __restrict__ sh4 = reinterpret_cast<const float4*>(shp);
+      // The 192-byte row lies in two 128-byte lines and the four groups below are four round trips in a row (each
+      // group's registers are reused by the next): the row's LAST float is asked for first, so the second line's miss
+      // runs beside the first one's instead of starting two round trips later.
+      float sh_last = 0.0f;
+      if (GCR_K1_SH_TOUCH_ON(a)) {
+        sh_last = shp[47];
+        asm volatile("" ::: "memory");
+      }
 #pragma unroll
       for (int grp = 0; grp < 4; grp++) {  // coefficients 4*grp .. 4*grp+3
-        const float4 v0 = sh4[3 * grp], v1 = sh4[3 * grp + 1], v2 = sh4[3 * grp + 2];
+        const float4 v0 = sh4[3 * grp], v1 = sh4[3 * grp + 1];
+        float4 v2 = sh4[3 * grp + 2];
+        if (grp == 3 && GCR_K1_SH_TOUCH_ON(a)) v2.w = sh_last;  // (the same bits)
         const float f[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -401,6 +462,14 @@ GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 me
   }
 }
 
+#ifdef GCR_EXPERIMENTS  /* GCR_K1_NOCLAMP=1 in the environment, per launch */
+#define GCR_K1_PREFETCH_LIMIT ((a.exp_flags & 2) ? (long long)a.P - 1 : chunk_end - 1)
+#elif defined(GCR_K1_NO_CHUNK_CLAMP)  /* A/B builds: the prefetch as it was before round 5 (runs on into the next block's chunk) */
+#define GCR_K1_PREFETCH_LIMIT ((long long)a.P - 1)
+#else
+#define GCR_K1_PREFETCH_LIMIT (chunk_end - 1)
+#endif
+
 // K1a: streaming cull.  Persistent grid, inputs prefetched one iteration ahead; writes radii = 0
 // for everything phase A0 rules out and appends the rest to the block's candidate list
 // (wave-level ballot compaction, one LDS atomic per wave and iteration).
@@ -440,7 +509,7 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
   PhaseAIn cur, nxt, nx2;
   bool viol = false;  // gcr_camera.prefiltered and a Gaussian behind the near plane
   long long idx64 = chunk_begin + tid;
-  const long long last = (long long)a.P - 1;
+  const long long last = GCR_K1_PREFETCH_LIMIT;  // (see k_preprocess_fused)
   phase_a_load<PRECOMP_COV>(a, idx64 < last ? idx64 : last, cur);
   phase_a_load<PRECOMP_COV>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);
   for (long long base = chunk_begin; base < chunk_end; base += 256) {
@@ -448,7 +517,7 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
     phase_a_load<PRECOMP_COV>(a, idx64 + 512 < last ? idx64 + 512 : last, nx2);  // prefetch, two iterations ahead
     bool candidate = false;
     if (idx64 < chunk_end) {
-      candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur);
+      candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur, cull_rho<PRECOMP_COV>(a.scale_modifier, cur));
       if (!candidate) a.radii[idx64] = 0;
       if (a.prefiltered) viol |= near_plane_violation(vm, cur);
     }
@@ -532,17 +601,199 @@ __global__ __launch_bounds__(256) void k_preprocess_project(const GcrPreprocessA
 
 // K1 fused (default): ONE kernel whose workgroups alternate between STREAMING their chunk through the cull
 // (K1a's loop) and PROCESSING the candidates they have collected -- exact projection, colour, record (K1b's body).
-// The candidates' inputs (index + 10 floats) wait in LDS, so they never go back to HBM and K1b's re-gather of three
-// 128-byte lines per candidate disappears; and while one workgroup is in its latency-bound processing pass the
-// other workgroups of the CU keep the HBM stream going, so the pass is hidden instead of being a second kernel
-// that starts only when the slowest streaming block has finished.  A processing pass runs whenever 256 candidates
-// are waiting (all lanes busy) and once more at the end of the chunk.
-constexpr int FUSED_CAP = 512;  // <= 255 left over + <= 256 new candidates per iteration
+// While one workgroup is in its latency-bound processing pass the other workgroups of the CU keep the HBM stream
+// going, so the pass is hidden instead of being a second kernel that starts only when the slowest streaming block has
+// finished.
+//
+// Round 5, the streaming loop in GROUPS of NS iterations with one register set per iteration of the group:
+//   * stage k's registers are loaded for the NEXT group right after their last use in this one, so NS - 1 iterations of
+//     inputs are in flight per wave and no register is ever copied.  The loop before (k_preprocess_fused_r4 below, kept
+//     for A/B builds) rotated cur <- nxt <- nx2: the copies read the loads' destination registers, so every iteration
+//     waited for all but the newest loads (s_waitcnt vmcnt(2) in its ISA) -- one iteration in flight, not the two its
+//     comments promised;
+//   * a prefetch never leaves the block's own chunk: lanes that would read past it re-read the chunk's last record (one
+//     L2-hot line).  Before, every block read the next block's first two iterations as well: 20 KB x 2 048 blocks = 42 MB
+//     of the 313 MB the kernel fetched at C3 (profiles/r05_traffic.json);
+//   * one barrier pair per group instead of one barrier per iteration; a processing pass runs at the end of a group when
+//     256 candidates are waiting (all lanes busy) and at the end of the chunk;
+//   * a waiting candidate keeps its index and mean in LDS (16 B; the queue holds a whole group's worth, 255 + 256 NS)
+//     and fetches its scales / rotation (or covariance) at the start of its pass -- lines this CU streamed a moment ago.
+//
+// CACHED (gcr_gaussians.cull_cache, a static scene's second line -- never the headline): the stream is the 16-byte cache
+// record instead of 40 B from three arrays (56 B when the rows are [N,14]).  The cull's decisions are those of the
+// stateless kernel (the same mean, the same rho, the same test), and A0 only ever skips Gaussians whose exact result is
+// radius 0, so radii / lists / image are the same bits either way.
+#ifndef GCR_K1_STAGES  /* A/B builds: iterations per group of the stateless stream (40 B per lane and iteration) */
+#define GCR_K1_STAGES 3
+#endif
+#ifndef GCR_K1_STAGES_CACHED  /* ... of the cached stream (16 B per lane and iteration) */
+#define GCR_K1_STAGES_CACHED 5
+#endif
 
-template <bool PRECOMP_COV>
+template <bool PRECOMP_COV, bool CACHED>
 __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArgs a) {
-  __shared__ uint32_t sIdx[FUSED_CAP];
-  __shared__ float sIn[10][FUSED_CAP];
+  constexpr int NS = CACHED ? GCR_K1_STAGES_CACHED : GCR_K1_STAGES;
+  constexpr int CAP = 256 * (NS + 1);  // <= 255 left over + <= 256 NS new candidates per group
+  __shared__ uint32_t sIdx[CAP];
+  __shared__ float sP[3][CAP];
+  __shared__ uint32_t cand_tail, vis_tail;
+  __shared__ unsigned long long blk_tiles;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) {
+    cand_tail = 0;
+    vis_tail = 0;
+    blk_tiles = 0ull;
+  }
+  __syncthreads();
+  float vm[16], pm[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    vm[i] = gcr_uniform(GCR_CAM(a, view, a.view, i));
+    pm[i] = gcr_uniform(GCR_CAM(a, proj, a.proj, i));
+  }
+  float wf2 = 0.0f;
+  {
+    const float wc[3][3] = {{vm[0], vm[1], vm[2]}, {vm[4], vm[5], vm[6]}, {vm[8], vm[9], vm[10]}};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      float row = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        row += __builtin_fabsf(wc[0][i] * wc[0][j] + wc[1][i] * wc[1][j] + wc[2][i] * wc[2][j]);
+      wf2 = __builtin_fmaxf(wf2, row);
+    }
+    wf2 *= 1.001f;
+  }
+  const long long chunk_begin = (long long)blockIdx.x * a.chunk;
+  const long long chunk_end = chunk_begin + a.chunk < a.P ? chunk_begin + a.chunk : a.P;
+  const long long clast = chunk_end - 1;  // (every block owns at least one Gaussian: gcr_preprocess_grid)
+  uint32_t* __restrict__ my_list = a.vis_list + chunk_begin;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  uint32_t my_tiles = 0;
+  bool viol = false;  // gcr_camera.prefiltered and a Gaussian behind the near plane
+
+  PhaseAIn q[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const long long i = chunk_begin + 256 * k + tid;
+    stream_load<PRECOMP_COV, CACHED>(a, i < clast ? i : clast, q[k]);
+  }
+  for (long long gbase = chunk_begin; gbase < chunk_end; gbase += 256 * NS) {
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      const long long idx64 = gbase + 256 * k + tid;
+      bool candidate = false;
+      if (idx64 < chunk_end) {
+        candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, q[k],
+                                                            CACHED ? q[k].c0 : cull_rho<PRECOMP_COV>(a.scale_modifier, q[k]));
+        if (!candidate) a.radii[idx64] = 0;
+        if (a.prefiltered) viol |= near_plane_violation(vm, q[k]);
+      }
+      const uint64_t m = __ballot(candidate);
+      if (m != 0ull) {
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&cand_tail, (uint32_t)__popcll(m));
+        wbase = __shfl(wbase, 0, 64);
+        if (candidate) {
+          const uint32_t slot = wbase + (uint32_t)__popcll(m & lt_mask);
+          sIdx[slot] = (uint32_t)idx64;
+          sP[0][slot] = q[k].p.x; sP[1][slot] = q[k].p.y; sP[2][slot] = q[k].p.z;
+        }
+      }
+      // stage k's registers are free now: the same iteration of the NEXT group goes into them (the compiler must not
+      // hoist the load above the uses -- it would need a second register set and copy it at the back-edge)
+      asm volatile("" ::: "memory");
+      const long long inext = idx64 + 256 * NS;
+      stream_load<PRECOMP_COV, CACHED>(a, inext < clast ? inext : clast, q[k]);
+    }
+    __syncthreads();
+    const uint32_t waiting = cand_tail;  // block-uniform: nobody appends again before the barrier(s) below
+    const bool last_group = gbase + 256 * NS >= chunk_end;
+    if (waiting >= 256u || (last_group && waiting > 0u)) {
+      // ---- processing passes over the waiting candidates: full 256-lane passes, plus the remainder at the end
+      uint32_t done = 0;
+      while (done + 256u <= waiting || (last_group && done < waiting)) {
+        const uint32_t it = done + (uint32_t)tid;
+        bool keep = false;
+        int idx = 0, radius = 0;
+        float opac = 0.0f;
+        PhaseAIn in;
+        Projected pr;
+        if (it < waiting) {
+          idx = (int)sIdx[it];
+          in.p = {sP[0][it], sP[1][it], sP[2][it]};
+          if constexpr (CACHED) {  // ONE 32-byte record: scales (or covariance), opacity, rotation
+            const float4 b0 = a.cull_shape[2 * (size_t)idx], b1 = a.cull_shape[2 * (size_t)idx + 1];
+            if (PRECOMP_COV) {
+              in.c0 = b0.x; in.c1 = b0.y; in.c2 = b0.z; in.c3 = b0.w; in.c4 = b1.x; in.c5 = b1.y; in.c6 = 0.0f;
+              opac = b1.z;
+            } else {
+              in.c0 = b0.x; in.c1 = b0.y; in.c2 = b0.z; opac = b0.w;
+              in.c3 = b1.x; in.c4 = b1.y; in.c5 = b1.z; in.c6 = b1.w;
+            }
+          } else {
+            phase_a_load_shape<PRECOMP_COV>(a, idx, in);
+          }
+          keep = phase_a1_exact<PRECOMP_COV>(a, vm, pm, idx, in, pr, radius);
+          a.radii[idx] = radius;
+        }
+        const uint64_t mk = __ballot(keep);
+        if (mk != 0ull) {
+          uint32_t lbase = 0;
+          if (lane == 0) lbase = atomicAdd(&vis_tail, (uint32_t)__popcll(mk));
+          lbase = __shfl(lbase, 0, 64);
+          if (keep) {
+            my_tiles += ((pr.rect_x >> 16) - (pr.rect_x & 0xffffu)) * ((pr.rect_y >> 16) - (pr.rect_y & 0xffffu));
+            preprocess_phase_b<CACHED>(a, idx, in.p, pr, lbase + (uint32_t)__popcll(mk & lt_mask), my_list, opac);
+          }
+        }
+        done += 256u;
+      }
+      if (done > waiting) done = waiting;
+      // the (< 256) candidates that did not fill a pass move to the front and wait for the next one
+      const uint32_t left = waiting - done;
+      __syncthreads();  // every lane has read its candidate
+      uint32_t mv_idx = 0;
+      float mv[3];
+      if ((uint32_t)tid < left) {
+        mv_idx = sIdx[done + tid];
+#pragma unroll
+        for (int k = 0; k < 3; k++) mv[k] = sP[k][done + tid];
+      }
+      __syncthreads();
+      if ((uint32_t)tid < left) {
+        sIdx[tid] = mv_idx;
+#pragma unroll
+        for (int k = 0; k < 3; k++) sP[k][tid] = mv[k];
+      }
+      if (tid == 0) cand_tail = left;
+    }
+    __syncthreads();  // everybody has read cand_tail (and sees the compacted queue) before the next group appends
+  }
+  const uint32_t wsum = gcr_wave_sum_u32(my_tiles);
+  if (lane == 0 && wsum) atomicAdd(&blk_tiles, (unsigned long long)wsum);
+  const int any_viol = __syncthreads_or(viol ? 1 : 0);
+  if (tid == 0) {
+    a.vis_count[blockIdx.x] = vis_tail;
+    // summed (= num_rendered) by the first workgroup of the next kernel; bit 63: a prefilter violation
+    a.block_tiles[blockIdx.x] = blk_tiles | (any_viol ? GCR_PREFILTER_FLAG : 0ull);
+  }
+}
+
+#if defined(GCR_K1_OLD_FUSED) || defined(GCR_EXPERIMENTS)  /* A/B builds only: the fused kernel as it was until round 5 */
+constexpr int FUSED_R4_CAP = 512;  // <= 255 left over + <= 256 new candidates per iteration
+
+//
+// CACHED (gcr_gaussians.cull_cache, a static scene's second line -- never the headline): the stream is the 16-byte cache
+// record instead of 40 B from three arrays; a candidate waits in LDS with its mean only and fetches its scales / rotation
+// (or covariance) at the start of its processing pass -- two line gathers for the few per cent that get that far.  The
+// cull's decisions are those of the stateless kernel (the same mean, the same rho, the same test), and A0 only ever
+// skips Gaussians whose exact result is radius 0, so radii / lists / image are the same bits either way.
+template <bool PRECOMP_COV, bool CACHED>
+__global__ __launch_bounds__(256) void k_preprocess_fused_r4(const GcrPreprocessArgs a) {
+  constexpr int QF = CACHED ? 3 : 10;  // floats a waiting candidate keeps in LDS
+  __shared__ uint32_t sIdx[FUSED_R4_CAP];
+  __shared__ float sIn[QF][FUSED_R4_CAP];
   __shared__ uint32_t cand_tail, vis_tail;
   __shared__ uint32_t wave_new[2][4];  // candidates each wave found in this iteration, double-buffered by parity
   __shared__ unsigned long long blk_tiles;
@@ -587,18 +838,32 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
   uint32_t waiting = 0;
   uint32_t parity = 0;
 
-  PhaseAIn cur, nxt, nx2;
+  // AHEAD iterations of inputs in flight per wave besides the current one (bytes in flight per wave are what keeps the
+  // stream at HBM speed: 40 B x 2 stateless; the cached stream is 16 B per Gaussian and needs more of them).  The
+  // prefetch never leaves the block's own chunk: lanes that would read past it re-read the chunk's last record (one
+  // L2-hot line) -- until round 5 they read the NEXT block's first two iterations, 20 KB x 2 048 blocks = 42 MB of the
+  // 313 MB the kernel fetched at C3 (profiles/r05_traffic.json).
+  constexpr int AHEAD = 2;
+  PhaseAIn q[AHEAD + 1];
   bool viol = false;  // gcr_camera.prefiltered and a Gaussian behind the near plane
   long long idx64 = chunk_begin + tid;
-  const long long last = (long long)a.P - 1;
-  phase_a_load<PRECOMP_COV>(a, idx64 < last ? idx64 : last, cur);
-  phase_a_load<PRECOMP_COV>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);
+  const long long last = GCR_K1_PREFETCH_LIMIT;
+#pragma unroll
+  for (int k = 0; k < AHEAD; k++) {
+    const long long i = idx64 + 256 * k;
+    stream_load<PRECOMP_COV, CACHED>(a, i < last ? i : last, q[k]);
+  }
   for (long long base = chunk_begin; base < chunk_end; base += 256, parity ^= 1u) {
     idx64 = base + tid;
-    phase_a_load<PRECOMP_COV>(a, idx64 + 512 < last ? idx64 + 512 : last, nx2);  // prefetch, two iterations ahead
+    {
+      const long long i = idx64 + 256 * AHEAD;
+      stream_load<PRECOMP_COV, CACHED>(a, i < last ? i : last, q[AHEAD]);  // prefetch, AHEAD iterations ahead
+    }
+    const PhaseAIn cur = q[0];
     bool candidate = false;
     if (idx64 < chunk_end) {
-      candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur);
+      candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur,
+                                                          CACHED ? cur.c0 : cull_rho<PRECOMP_COV>(a.scale_modifier, cur));
       if (!candidate) a.radii[idx64] = 0;
       if (a.prefiltered) viol |= near_plane_violation(vm, cur);
     }
@@ -612,13 +877,15 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
         const uint32_t slot = wbase + (uint32_t)__popcll(m & lt_mask);
         sIdx[slot] = (uint32_t)idx64;
         sIn[0][slot] = cur.p.x; sIn[1][slot] = cur.p.y; sIn[2][slot] = cur.p.z;
-        sIn[3][slot] = cur.c0; sIn[4][slot] = cur.c1; sIn[5][slot] = cur.c2;
-        sIn[6][slot] = cur.c3; sIn[7][slot] = cur.c4; sIn[8][slot] = cur.c5;
-        sIn[9][slot] = cur.c6;
+        if constexpr (!CACHED) {
+          sIn[3][slot] = cur.c0; sIn[4][slot] = cur.c1; sIn[5][slot] = cur.c2;
+          sIn[6][slot] = cur.c3; sIn[7][slot] = cur.c4; sIn[8][slot] = cur.c5;
+          sIn[9][slot] = cur.c6;
+        }
       }
     }
-    cur = nxt;
-    nxt = nx2;
+#pragma unroll
+    for (int k = 0; k < AHEAD; k++) q[k] = q[k + 1];
     __syncthreads();
     waiting += wave_new[parity][0] + wave_new[parity][1] + wave_new[parity][2] + wave_new[parity][3];
     const bool last_iter = base + 256 >= chunk_end;
@@ -634,9 +901,13 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
         if (it < waiting) {
           idx = (int)sIdx[it];
           in.p = {sIn[0][it], sIn[1][it], sIn[2][it]};
-          in.c0 = sIn[3][it]; in.c1 = sIn[4][it]; in.c2 = sIn[5][it];
-          in.c3 = sIn[6][it]; in.c4 = sIn[7][it]; in.c5 = sIn[8][it];
-          in.c6 = sIn[9][it];
+          if constexpr (CACHED) {
+            phase_a_load_shape<PRECOMP_COV>(a, idx, in);
+          } else {
+            in.c0 = sIn[3][it]; in.c1 = sIn[4][it]; in.c2 = sIn[5][it];
+            in.c3 = sIn[6][it]; in.c4 = sIn[7][it]; in.c5 = sIn[8][it];
+            in.c6 = sIn[9][it];
+          }
           keep = phase_a1_exact<PRECOMP_COV>(a, vm, pm, idx, in, pr, radius);
           a.radii[idx] = radius;
         }
@@ -657,17 +928,17 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
       const uint32_t left = waiting - done;
       __syncthreads();  // every lane has read its candidate
       uint32_t mv_idx = 0;
-      float mv[10];
+      float mv[QF];
       if ((uint32_t)tid < left) {
         mv_idx = sIdx[done + tid];
 #pragma unroll
-        for (int k = 0; k < 10; k++) mv[k] = sIn[k][done + tid];
+        for (int k = 0; k < QF; k++) mv[k] = sIn[k][done + tid];
       }
       __syncthreads();
       if ((uint32_t)tid < left) {
         sIdx[tid] = mv_idx;
 #pragma unroll
-        for (int k = 0; k < 10; k++) sIn[k][tid] = mv[k];
+        for (int k = 0; k < QF; k++) sIn[k][tid] = mv[k];
       }
       if (tid == 0) cand_tail = left;
       waiting = left;
@@ -683,6 +954,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
     a.block_tiles[blockIdx.x] = blk_tiles | (any_viol ? GCR_PREFILTER_FLAG : 0ull);
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------- K2
 // Exclusive scan (in place) of the n per-block tile counts; *total = num_rendered
@@ -1127,13 +1399,80 @@ int gcr_preprocess_resident_blocks(bool split) {
   return cached;
 }
 
+// gcr_build_cull_cache.  Two arrays: A[i] = (mean, rho) -- everything the streaming cull needs of Gaussian i, 16 bytes; B[i] =
+// (scales, opacity, rotation) or (covariance, opacity, 0) -- everything a candidate needs besides, ONE 32-byte record instead
+// of a 128-byte line each of scales, rotations and opacities.  Only the inputs, their strides, P and scale_modifier of `a`
+// are read.
+template <bool PRECOMP_COV>
+__global__ __launch_bounds__(256) void k_build_cull_cache(const GcrPreprocessArgs a, float4* __restrict__ outA,
+                                                          float4* __restrict__ outB) {
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < (long long)a.P; idx += (long long)gridDim.x * 256) {
+    PhaseAIn in;
+    phase_a_load<PRECOMP_COV>(a, idx, in);
+    const float opacity = a.opacities[(size_t)idx * a.s_opac];
+    outA[idx] = make_float4(in.p.x, in.p.y, in.p.z, cull_rho<PRECOMP_COV>(a.scale_modifier, in));
+    if (PRECOMP_COV) {
+      outB[2 * idx] = make_float4(in.c0, in.c1, in.c2, in.c3);
+      outB[2 * idx + 1] = make_float4(in.c4, in.c5, opacity, 0.0f);
+    } else {
+      outB[2 * idx] = make_float4(in.c0, in.c1, in.c2, opacity);
+      outB[2 * idx + 1] = make_float4(in.c3, in.c4, in.c5, in.c6);
+    }
+  }
+}
+
+hipError_t gcr_launch_build_cull_cache(const GcrPreprocessArgs& a, float4* outA, float4* outB, hipStream_t s) {
+  if (a.P <= 0) return hipSuccess;
+  long long nb = ((long long)a.P + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  if (a.cov3D_precomp != nullptr)
+    k_build_cull_cache<true><<<(unsigned int)nb, 256, 0, s>>>(a, outA, outB);
+  else
+    k_build_cull_cache<false><<<(unsigned int)nb, 256, 0, s>>>(a, outA, outB);
+  return hipGetLastError();
+}
+
 hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, bool split, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
   if (!split) {  // default: streaming cull and exact pass in one kernel
-    if (a.cov3D_precomp != nullptr)
-      k_preprocess_fused<true><<<a.nblocks, 256, 0, s>>>(a);
-    else
-      k_preprocess_fused<false><<<a.nblocks, 256, 0, s>>>(a);
+#ifdef GCR_EXPERIMENTS  // GCR_K1_R4=1 / GCR_K1_SH_TOUCH=1 in the environment, read per launch: A/B in one process
+    if (const char* e = getenv("GCR_K1_R4"))
+      if (atoi(e) != 0) {
+        GcrPreprocessArgs b = a;
+        if (const char* t = getenv("GCR_K1_SH_TOUCH")) b.exp_flags = atoi(t) != 0 ? 1 : 0;
+        if (const char* t = getenv("GCR_K1_NOCLAMP")) b.exp_flags |= atoi(t) != 0 ? 2 : 0;
+        if (b.cull_cache != nullptr) {
+          if (b.cov3D_precomp != nullptr) k_preprocess_fused_r4<true, true><<<b.nblocks, 256, 0, s>>>(b);
+          else k_preprocess_fused_r4<false, true><<<b.nblocks, 256, 0, s>>>(b);
+        } else if (b.cov3D_precomp != nullptr) {
+          k_preprocess_fused_r4<true, false><<<b.nblocks, 256, 0, s>>>(b);
+        } else {
+          k_preprocess_fused_r4<false, false><<<b.nblocks, 256, 0, s>>>(b);
+        }
+        return hipGetLastError();
+      }
+    GcrPreprocessArgs b = a;
+    if (const char* t = getenv("GCR_K1_SH_TOUCH")) b.exp_flags = atoi(t) != 0 ? 1 : 0;
+#define a b
+#endif
+#ifdef GCR_K1_OLD_FUSED
+#define GCR_K1_FUSED k_preprocess_fused_r4
+#else
+#define GCR_K1_FUSED k_preprocess_fused
+#endif
+    if (a.cull_cache != nullptr) {  // a static scene's cull cache (gcr_gaussians.cull_cache): same results, fewer bytes
+      if (a.cov3D_precomp != nullptr)
+        GCR_K1_FUSED<true, true><<<a.nblocks, 256, 0, s>>>(a);
+      else
+        GCR_K1_FUSED<false, true><<<a.nblocks, 256, 0, s>>>(a);
+    } else if (a.cov3D_precomp != nullptr) {
+      GCR_K1_FUSED<true, false><<<a.nblocks, 256, 0, s>>>(a);
+    } else {
+      GCR_K1_FUSED<false, false><<<a.nblocks, 256, 0, s>>>(a);
+    }
+#ifdef GCR_EXPERIMENTS
+#undef a
+#endif
     return hipGetLastError();
   }
   if (a.cov3D_precomp != nullptr) {

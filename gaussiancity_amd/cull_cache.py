@@ -1,0 +1,140 @@
+"""A static scene's cull cache (gcr_gaussians.cull_cache, include/gcr.h ABI v8) kept current for the Python API.
+
+GaussianCity's inference loop flies a camera through ONE generated city (scripts/inference.py:640-667: the point tensor
+is made once, the poses change): every frame's streaming cull reads the mean, the scales and the rotation of all of its
+Gaussians to reject the 95 % that are off screen.  With a cache -- (mean, rho) as one 16-byte record per Gaussian, rho =
+the camera-independent factor of the cull's screen bound, plus (scales, opacity, rotation) as one 32-byte record -- the
+cull streams 16 bytes per Gaussian instead of 40 (56 when the rows are [N,14]) and the few per cent that survive it fetch
+one 32-byte record instead of a 128-byte line of each of three arrays.  Every output is the same bits
+(tests/test_gpu_cull_cache.py); what changes is K1's time.
+
+OFF by default -- the reference's API has no notion of a static scene, and the headline numbers are the stateless
+path's.  On: `gaussiancity_amd.cull_cache.enable(True)` (or GCR_STATIC_SCENE=1 in the environment, or
+InferenceLoop(static_scene=True)).  Only frames that are rendered WITHOUT the backward's state use it (no_grad /
+inference frames): a training step changes its Gaussians every iteration, the cache would be rebuilt each time.
+
+Validity.  An entry is keyed on (data_ptr, _version, shape, strides) of every tensor it was built from plus
+scale_modifier, and it keeps those tensors alive -- so the address cannot be handed to another allocation while the entry
+exists, and any in-place edit through torch (which bumps `_version`) misses the key and rebuilds.  Writes torch cannot
+see (a raw kernel scribbling into the storage) are not detected: call invalidate() after such a write.  Tensors without a
+version counter (inference-mode tensors) are never cached.
+"""
+import collections
+import ctypes as C
+import os
+import threading
+
+import torch
+
+from . import _native as N
+
+_enabled = os.environ.get("GCR_STATIC_SCENE", "0") not in ("", "0")
+_MAX_ENTRIES = 2  # scenes per process that stay cached (a second one: A/B renders of two cities)
+_entries = collections.OrderedDict()  # key -> (cache buffer, uint8 [gcr_cull_cache_bytes(P)], tensors kept alive)
+_CACHE_BYTES_HOOK = None  # tests without the library: fn(P) -> bytes
+_lock = threading.Lock()
+stats = {"hits": 0, "builds": 0, "uncacheable": 0, "thrashing": 0}
+_THRASH_LIMIT = 8  # that many builds in a row without a hit: the caller's scene is not static; stop until invalidate()
+_builds_in_a_row = 0
+
+# tests replace this to count / fake builds without a GPU: fn(g: N.Gaussians, scale_modifier, out_ptr, stream) -> None
+_build_hook = None
+
+
+def enable(on=True):
+    """Process-wide switch; returns the previous value."""
+    global _enabled
+    prev, _enabled = _enabled, bool(on)
+    if not on:
+        invalidate()
+    return prev
+
+
+def enabled():
+    return _enabled
+
+
+class scoped:
+    """`with cull_cache.scoped(True): ...` -- the switch for a block of frames; entries stay cached afterwards (a later
+    block on the same scene hits them)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _enabled
+        self.prev, _enabled = _enabled, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _enabled
+        _enabled = self.prev
+        return False
+
+
+def invalidate():
+    """Drop every entry (e.g. after a write into a cached tensor's storage that torch's version counter cannot see)."""
+    with _lock:
+        _drop_all()
+
+
+def _drop_all():
+    global _builds_in_a_row
+    _builds_in_a_row = 0
+    if _entries and torch.cuda.is_available():
+        torch.cuda.synchronize()  # frames on other streams may still be reading a cache (allocated on the build stream)
+    _entries.clear()
+
+
+def _key_of(tensors, scale_modifier):
+    key = [float(scale_modifier)]
+    for t in tensors:
+        if t is None or t.numel() == 0:
+            key.append(None)
+            continue
+        try:
+            ver = t._version
+        except RuntimeError:  # inference tensors do not track versions: cannot tell whether they were edited
+            return None
+        key.append((t.data_ptr(), ver, tuple(t.shape), tuple(t.stride()), t.device.index))
+    return tuple(key)
+
+
+def attach(g, scale_modifier, tensors, device, stream):
+    """Point g.cull_cache (N.Gaussians, already filled for this frame) at the current cache of `tensors` = the tensors g's
+    means3D / scales / rotations / cov3D_precomp / opacities pointers came from, building it on `stream` if there is
+    none.  Returns the cache buffer (keep it alive until the frame is enqueued) or None when the tensors cannot be keyed."""
+    global _builds_in_a_row
+    key = _key_of(tensors, scale_modifier)
+    if key is None:
+        stats["uncacheable"] += 1
+        return None
+    with _lock:
+        hit = _entries.get(key)
+        if hit is not None:
+            _entries.move_to_end(key)
+            stats["hits"] += 1
+            _builds_in_a_row = 0
+            g.cull_cache = hit[0].data_ptr()
+            return hit[0]
+        if _builds_in_a_row >= _THRASH_LIMIT:  # every frame brings new tensors: a build per frame costs more than it saves
+            stats["thrashing"] += 1
+            return None
+        _builds_in_a_row += 1
+        nbytes = _CACHE_BYTES_HOOK(int(g.P)) if _CACHE_BYTES_HOOK is not None else N.lib().gcr_cull_cache_bytes(int(g.P))
+        cache = torch.empty((int(nbytes),), dtype=torch.uint8, device=device)  # (torch's blocks are 512-byte aligned)
+        if _build_hook is not None:
+            _build_hook(g, float(scale_modifier), cache.data_ptr(), stream)
+        else:
+            N.check(N.lib().gcr_build_cull_cache(C.byref(g), float(scale_modifier), cache.data_ptr(), stream),
+                    "gcr_build_cull_cache")
+            # frames on OTHER streams will read it (InferenceLoop rotates three): the build is a one-off, wait for it
+            torch.cuda.current_stream(device).synchronize()
+        stats["builds"] += 1
+        while len(_entries) >= _MAX_ENTRIES:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()  # (see _drop_all)
+            _entries.popitem(last=False)
+        _entries[key] = (cache, tuple(t for t in tensors if t is not None))
+        g.cull_cache = cache.data_ptr()
+        return cache

@@ -230,10 +230,14 @@ class InferenceLoop:
     frames' renders.  `render_fn(points, cam_pos, cam_quat) -> [3,H,W]`
     is the rasterizer wrapper (or any stand-in on CPU, which degrades to a plain loop)."""
 
-    def __init__(self, render_fn, device=None, n_streams=3, render_uint8_fn=None):
+    def __init__(self, render_fn, device=None, n_streams=3, render_uint8_fn=None, static_scene=False):
         """`render_uint8_fn(points, cam_pos, cam_quat) -> uint8 [H,W,3]` (optional): a renderer that produces the video
         frame itself (GaussianRasterizerWrapper(..., as_uint8=True): the blend kernel stores the bytes to_uint8_hwc would
-        compute); used instead of render_fn + to_uint8_hwc when given."""
+        compute); used instead of render_fn + to_uint8_hwc when given.  `static_scene`: the frames of a run() share one
+        point tensor that nobody edits meanwhile (the reference's loop: one city, many poses) -- the rasterizer may keep
+        its cull cache for it (gaussiancity_amd/cull_cache.py: the same frames, the cull streams 16 instead of 56 bytes
+        per Gaussian).  Frames must be rendered under no_grad for it to apply."""
+        self.static_scene = bool(static_scene)
         self.render_fn = render_fn
         self.render_uint8_fn = render_uint8_fn
         self.device = torch.device(device) if device is not None else torch.device("cpu")
@@ -251,6 +255,13 @@ class InferenceLoop:
     def run(self, points, poses, consume=None):
         """Renders every (cam_pos, cam_quat) of `poses`; returns the list of uint8 [H,W,3] numpy frames, or
         calls `consume(index, frame)` per frame (the frame buffer is reused `n_streams` frames later)."""
+        if self.static_scene and self.cuda:
+            from . import cull_cache
+            with cull_cache.scoped(True):
+                return self._run(points, poses, consume)
+        return self._run(points, poses, consume)
+
+    def _run(self, points, poses, consume):
         out = []
         pending = [None] * self.n  # (index, event) per slot
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GCR_ABI_VERSION 7
+#define GCR_ABI_VERSION 8
 #define GCR_BLOCK_X 16 /* cr/config.h:16 */
 #define GCR_BLOCK_Y 16 /* cr/config.h:17 */
 #define GCR_NUM_CHANNELS 3 /* cr/config.h:15 */
@@ -136,7 +136,27 @@ typedef struct gcr_gaussians {
    * 11 the kernels read it in place, where the reference's binding copies every slice (.contiguous(),
    * dgr/rasterize_points.cu:37-93 through torch).  shs and cov3D_precomp are always dense. */
   int32_t stride_means3D, stride_opacities, stride_colors, stride_scales, stride_rotations;
+  /* ABI v8, optional (NULL = none; forward calls only, the backward never reads it): the buffer gcr_build_cull_cache
+   * filled from THESE means3D / scales / rotations (or cov3D_precomp) / opacities at the camera's scale_modifier;
+   * gcr_cull_cache_bytes(P) bytes, 128-byte aligned.  A scene that does not change between frames (a city that is only
+   * flown through, scripts/inference.py:640-667) is then culled from one 16-byte record per Gaussian instead of 40
+   * bytes out of three arrays (56 when the rows are [N,14]), and the few per cent that survive the cull fetch their
+   * scales, rotation and opacity as one 32-byte record instead of a 128-byte line of each array.  Every output is the
+   * same bits as without it: the cull takes the same decisions from the same numbers, it only ever skips Gaussians
+   * whose exact projection has radius 0 (cr/forward.cu:147-233 decides everything else), and the records are copies.
+   * The library cannot see whether the arrays still hold what the cache was built from -- a stale cache renders the
+   * OLD positions, sizes and opacities of the culled / surviving Gaussians; keeping it current is the caller's job (the
+   * Python layer keys it on the tensors' versions).  Ignored under option "split_preprocess". */
+  const void *cull_cache;
 } gcr_gaussians;
+
+/* The cull cache of gcr_gaussians.cull_cache for g's means3D / scales / rotations (or cov3D_precomp) / opacities (strides
+ * as in g) at `scale_modifier`.  Part A, P x 16 bytes: (mean_i, rho_i), rho = a bound on the spectral radius of Gaussian
+ * i's world-space covariance (the camera-independent factor of the cull's screen bound, cr/forward.cu:126-144 in
+ * interval form).  Part B, P x 32 bytes at the next 128-byte boundary: (scales, opacity, rotation) or (covariance,
+ * opacity, 0).  One streaming kernel on `hip_stream` (44 -> 48 bytes per Gaussian); g->cull_cache itself is not read. */
+size_t gcr_cull_cache_bytes(int32_t P);
+int gcr_build_cull_cache(const gcr_gaussians *g, float scale_modifier, void *cull_cache_out, void *hip_stream);
 
 /* Gradient outputs (cr/rasterizer.h:39-48).  The arrays may be UNINITIALISED memory: gcr_backward writes every
  * element of every output (zeros for Gaussians that were not rendered), where the reference asks its caller for

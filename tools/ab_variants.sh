@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=$R/gpurun_out; mkdir -p $O
 : > $O/${TAG}_ab.jsonl
-for rep in 1 2 3; do
+for rep in $(seq 1 ${REPS:-3}); do
   for v in "$@"; do
     echo "{\"variant\": \"$v\"}" >> $O/${TAG}_ab.jsonl
     if [ $v = ship ]; then env -u GCR_LIB_PATH timeout 600 $CMD 2>/dev/null >> $O/${TAG}_ab.jsonl
