@@ -390,9 +390,6 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
   a.s_scale = stride_or(g->stride_scales, 3);
   a.s_rot = stride_or(g->stride_rotations, 4);
   a.prefiltered = cam->prefiltered != 0;
-#ifdef GCR_EXPERIMENTS
-  a.exp_flags = 0;
-#endif
   a.cull_cache = op.split_preprocess ? nullptr : reinterpret_cast<const float4*>(g->cull_cache);
   a.cull_shape = a.cull_cache ? reinterpret_cast<const float4*>((const char*)g->cull_cache + gcr_cull_cache_offset_b(g->P)) : nullptr;
   fill_cam(a.cam, cam);

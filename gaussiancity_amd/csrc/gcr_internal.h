@@ -42,9 +42,6 @@ struct GcrPreprocessArgs {
   int s_mean, s_opac, s_col, s_scale, s_rot;  // row strides in floats (3 / 1 / 3 / 3 / 4 when dense)
   int prefiltered;  // gcr_camera.prefiltered: a Gaussian behind the near plane is an error of the caller (GCR_PREFILTER_*)
   const float4* cull_cache;  // gcr_gaussians.cull_cache, part A: [P] (mean, rho) records of gcr_build_cull_cache, or null (stateless)
-#ifdef GCR_EXPERIMENTS
-  int exp_flags;  // bit 0: GCR_K1_SH_TOUCH
-#endif
   const float4* cull_shape;  // ... part B: [P] x 32 bytes (scales, opacity, rotation) or (covariance, opacity, 0)
   GcrCamVals cam;
 };

@@ -160,43 +160,6 @@ GCR_DEV void phase_a_load(const GcrPreprocessArgs& a, long long idx, PhaseAIn& i
   }
 }
 
-// The covariance inputs only (a cached cull's candidate: its mean comes from the cache, bit for bit the caller's)
-template <bool PRECOMP_COV>
-GCR_DEV void phase_a_load_shape(const GcrPreprocessArgs& a, long long idx, PhaseAIn& in) {
-  if (PRECOMP_COV) {
-    const float* __restrict__ c = a.cov3D_precomp + 6 * (size_t)idx;
-    in.c0 = c[0]; in.c1 = c[1]; in.c2 = c[2]; in.c3 = c[3]; in.c4 = c[4]; in.c5 = c[5];
-    in.c6 = 0.0f;
-  } else {
-    const float* __restrict__ sp = a.scales + (size_t)idx * a.s_scale;
-    in.c0 = sp[0];
-    in.c1 = sp[1];
-    in.c2 = sp[2];
-    const float* __restrict__ rp = a.rotations + (size_t)idx * a.s_rot;
-    if (a.s_rot == 4) {
-      const float4 rot = *reinterpret_cast<const float4*>(rp);
-      in.c3 = rot.x; in.c4 = rot.y; in.c5 = rot.z; in.c6 = rot.w;
-    } else {
-      in.c3 = rp[0]; in.c4 = rp[1]; in.c5 = rp[2]; in.c6 = rp[3];
-    }
-  }
-}
-
-// What the streaming cull reads per Gaussian.  CACHED (gcr_gaussians.cull_cache): ONE 16-byte load -- the mean and the
-// camera-independent half of the screen bound (cull_rho below), as k_build_cull_cache left them -- instead of 40 bytes
-// from three arrays (56 when the caller's rows are [N,14]); c0 carries rho, the other fields are constants the compiler drops.
-template <bool PRECOMP_COV, bool CACHED>
-GCR_DEV void stream_load(const GcrPreprocessArgs& a, long long idx, PhaseAIn& in) {
-  if (CACHED) {
-    const float4 c = a.cull_cache[idx];
-    in.p = {c.x, c.y, c.z};
-    in.c0 = c.w;
-    in.c1 = in.c2 = in.c3 = in.c4 = in.c5 = in.c6 = 0.0f;
-  } else {
-    phase_a_load<PRECOMP_COV>(a, idx, in);
-  }
-}
-
 // Wave-uniform float forced into an SGPR.  The camera matrices are read once per kernel this way:
 // left to itself the compiler re-fetched them with VECTOR loads in every loop iteration (it
 // cannot prove them invariant next to the kernel's stores, so no s_load).
@@ -380,14 +343,6 @@ GCR_DEV float sh_accumulate(int i, int deg, const ShDir& d, float result, float 
   return deg > 2 ? result + sh_term(i, d, s) : result;
 }
 
-#ifdef GCR_EXPERIMENTS  /* experiment builds toggle it per launch (GCR_K1_SH_TOUCH in the environment) */
-#define GCR_K1_SH_TOUCH_ON(a) (((a).exp_flags & 1) != 0)
-#elif defined(GCR_K1_SH_TOUCH)
-#define GCR_K1_SH_TOUCH_ON(a) true
-#else
-#define GCR_K1_SH_TOUCH_ON(a) false
-#endif
-
 template <bool HAVE_OPACITY = false>
 GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 mean, const Projected& pr,
                                 uint32_t list_pos, uint32_t* __restrict__ vis_list, float cached_opacity = 0.0f) {
@@ -409,16 +364,14 @@ GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 me
       // The 192-byte row lies in two 128-byte lines and the four groups below are four round trips in a row (each
       // group's registers are reused by the next): the row's LAST float is asked for first, so the second line's miss
       // runs beside the first one's instead of starting two round trips later.
-      float sh_last = 0.0f;
-      if (GCR_K1_SH_TOUCH_ON(a)) {
-        sh_last = shp[47];
-        asm volatile("" ::: "memory");
-      }
+      // (round 5; K1 -0.7 us stateless / -2.3 us cached at C3, -4 us cached at C5: profiles/r05_k1_ab_*.jsonl)
+      const float sh_last = shp[47];
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int grp = 0; grp < 4; grp++) {  // coefficients 4*grp .. 4*grp+3
         const float4 v0 = sh4[3 * grp], v1 = sh4[3 * grp + 1];
         float4 v2 = sh4[3 * grp + 2];
-        if (grp == 3 && GCR_K1_SH_TOUCH_ON(a)) v2.w = sh_last;  // (the same bits)
+        if (grp == 3) v2.w = sh_last;  // (the same bits)
         const float f[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -462,14 +415,6 @@ GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 me
   }
 }
 
-#ifdef GCR_EXPERIMENTS  /* GCR_K1_NOCLAMP=1 in the environment, per launch */
-#define GCR_K1_PREFETCH_LIMIT ((a.exp_flags & 2) ? (long long)a.P - 1 : chunk_end - 1)
-#elif defined(GCR_K1_NO_CHUNK_CLAMP)  /* A/B builds: the prefetch as it was before round 5 (runs on into the next block's chunk) */
-#define GCR_K1_PREFETCH_LIMIT ((long long)a.P - 1)
-#else
-#define GCR_K1_PREFETCH_LIMIT (chunk_end - 1)
-#endif
-
 // K1a: streaming cull.  Persistent grid, inputs prefetched one iteration ahead; writes radii = 0
 // for everything phase A0 rules out and appends the rest to the block's candidate list
 // (wave-level ballot compaction, one LDS atomic per wave and iteration).
@@ -509,7 +454,7 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
   PhaseAIn cur, nxt, nx2;
   bool viol = false;  // gcr_camera.prefiltered and a Gaussian behind the near plane
   long long idx64 = chunk_begin + tid;
-  const long long last = GCR_K1_PREFETCH_LIMIT;  // (see k_preprocess_fused)
+  const long long last = chunk_end - 1;  // the prefetch stays inside the block's own chunk (see k_preprocess_fused)
   phase_a_load<PRECOMP_COV>(a, idx64 < last ? idx64 : last, cur);
   phase_a_load<PRECOMP_COV>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);
   for (long long base = chunk_begin; base < chunk_end; base += 256) {
@@ -601,199 +546,17 @@ __global__ __launch_bounds__(256) void k_preprocess_project(const GcrPreprocessA
 
 // K1 fused (default): ONE kernel whose workgroups alternate between STREAMING their chunk through the cull
 // (K1a's loop) and PROCESSING the candidates they have collected -- exact projection, colour, record (K1b's body).
-// While one workgroup is in its latency-bound processing pass the other workgroups of the CU keep the HBM stream
-// going, so the pass is hidden instead of being a second kernel that starts only when the slowest streaming block has
-// finished.
-//
-// Round 5, the streaming loop in GROUPS of NS iterations with one register set per iteration of the group:
-//   * stage k's registers are loaded for the NEXT group right after their last use in this one, so NS - 1 iterations of
-//     inputs are in flight per wave and no register is ever copied.  The loop before (k_preprocess_fused_r4 below, kept
-//     for A/B builds) rotated cur <- nxt <- nx2: the copies read the loads' destination registers, so every iteration
-//     waited for all but the newest loads (s_waitcnt vmcnt(2) in its ISA) -- one iteration in flight, not the two its
-//     comments promised;
-//   * a prefetch never leaves the block's own chunk: lanes that would read past it re-read the chunk's last record (one
-//     L2-hot line).  Before, every block read the next block's first two iterations as well: 20 KB x 2 048 blocks = 42 MB
-//     of the 313 MB the kernel fetched at C3 (profiles/r05_traffic.json);
-//   * one barrier pair per group instead of one barrier per iteration; a processing pass runs at the end of a group when
-//     256 candidates are waiting (all lanes busy) and at the end of the chunk;
-//   * a waiting candidate keeps its index and mean in LDS (16 B; the queue holds a whole group's worth, 255 + 256 NS)
-//     and fetches its scales / rotation (or covariance) at the start of its pass -- lines this CU streamed a moment ago.
-//
-// CACHED (gcr_gaussians.cull_cache, a static scene's second line -- never the headline): the stream is the 16-byte cache
-// record instead of 40 B from three arrays (56 B when the rows are [N,14]).  The cull's decisions are those of the
-// stateless kernel (the same mean, the same rho, the same test), and A0 only ever skips Gaussians whose exact result is
-// radius 0, so radii / lists / image are the same bits either way.
-#ifndef GCR_K1_STAGES  /* A/B builds: iterations per group of the stateless stream (40 B per lane and iteration) */
-#define GCR_K1_STAGES 3
-#endif
-#ifndef GCR_K1_STAGES_CACHED  /* ... of the cached stream (16 B per lane and iteration) */
-#define GCR_K1_STAGES_CACHED 5
-#endif
+// The candidates' inputs (index + 10 floats) wait in LDS, so they never go back to HBM and K1b's re-gather of three
+// 128-byte lines per candidate disappears; and while one workgroup is in its latency-bound processing pass the
+// other workgroups of the CU keep the HBM stream going, so the pass is hidden instead of being a second kernel
+// that starts only when the slowest streaming block has finished.  A processing pass runs whenever 256 candidates
+// are waiting (all lanes busy) and once more at the end of the chunk.
+constexpr int FUSED_CAP = 512;  // <= 255 left over + <= 256 new candidates per iteration
 
-template <bool PRECOMP_COV, bool CACHED>
+template <bool PRECOMP_COV>
 __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArgs a) {
-  constexpr int NS = CACHED ? GCR_K1_STAGES_CACHED : GCR_K1_STAGES;
-  constexpr int CAP = 256 * (NS + 1);  // <= 255 left over + <= 256 NS new candidates per group
-  __shared__ uint32_t sIdx[CAP];
-  __shared__ float sP[3][CAP];
-  __shared__ uint32_t cand_tail, vis_tail;
-  __shared__ unsigned long long blk_tiles;
-  const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) {
-    cand_tail = 0;
-    vis_tail = 0;
-    blk_tiles = 0ull;
-  }
-  __syncthreads();
-  float vm[16], pm[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    vm[i] = gcr_uniform(GCR_CAM(a, view, a.view, i));
-    pm[i] = gcr_uniform(GCR_CAM(a, proj, a.proj, i));
-  }
-  float wf2 = 0.0f;
-  {
-    const float wc[3][3] = {{vm[0], vm[1], vm[2]}, {vm[4], vm[5], vm[6]}, {vm[8], vm[9], vm[10]}};
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      float row = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-        row += __builtin_fabsf(wc[0][i] * wc[0][j] + wc[1][i] * wc[1][j] + wc[2][i] * wc[2][j]);
-      wf2 = __builtin_fmaxf(wf2, row);
-    }
-    wf2 *= 1.001f;
-  }
-  const long long chunk_begin = (long long)blockIdx.x * a.chunk;
-  const long long chunk_end = chunk_begin + a.chunk < a.P ? chunk_begin + a.chunk : a.P;
-  const long long clast = chunk_end - 1;  // (every block owns at least one Gaussian: gcr_preprocess_grid)
-  uint32_t* __restrict__ my_list = a.vis_list + chunk_begin;
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
-  uint32_t my_tiles = 0;
-  bool viol = false;  // gcr_camera.prefiltered and a Gaussian behind the near plane
-
-  PhaseAIn q[NS];
-#pragma unroll
-  for (int k = 0; k < NS; k++) {
-    const long long i = chunk_begin + 256 * k + tid;
-    stream_load<PRECOMP_COV, CACHED>(a, i < clast ? i : clast, q[k]);
-  }
-  for (long long gbase = chunk_begin; gbase < chunk_end; gbase += 256 * NS) {
-#pragma unroll
-    for (int k = 0; k < NS; k++) {
-      const long long idx64 = gbase + 256 * k + tid;
-      bool candidate = false;
-      if (idx64 < chunk_end) {
-        candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, q[k],
-                                                            CACHED ? q[k].c0 : cull_rho<PRECOMP_COV>(a.scale_modifier, q[k]));
-        if (!candidate) a.radii[idx64] = 0;
-        if (a.prefiltered) viol |= near_plane_violation(vm, q[k]);
-      }
-      const uint64_t m = __ballot(candidate);
-      if (m != 0ull) {
-        uint32_t wbase = 0;
-        if (lane == 0) wbase = atomicAdd(&cand_tail, (uint32_t)__popcll(m));
-        wbase = __shfl(wbase, 0, 64);
-        if (candidate) {
-          const uint32_t slot = wbase + (uint32_t)__popcll(m & lt_mask);
-          sIdx[slot] = (uint32_t)idx64;
-          sP[0][slot] = q[k].p.x; sP[1][slot] = q[k].p.y; sP[2][slot] = q[k].p.z;
-        }
-      }
-      // stage k's registers are free now: the same iteration of the NEXT group goes into them (the compiler must not
-      // hoist the load above the uses -- it would need a second register set and copy it at the back-edge)
-      asm volatile("" ::: "memory");
-      const long long inext = idx64 + 256 * NS;
-      stream_load<PRECOMP_COV, CACHED>(a, inext < clast ? inext : clast, q[k]);
-    }
-    __syncthreads();
-    const uint32_t waiting = cand_tail;  // block-uniform: nobody appends again before the barrier(s) below
-    const bool last_group = gbase + 256 * NS >= chunk_end;
-    if (waiting >= 256u || (last_group && waiting > 0u)) {
-      // ---- processing passes over the waiting candidates: full 256-lane passes, plus the remainder at the end
-      uint32_t done = 0;
-      while (done + 256u <= waiting || (last_group && done < waiting)) {
-        const uint32_t it = done + (uint32_t)tid;
-        bool keep = false;
-        int idx = 0, radius = 0;
-        float opac = 0.0f;
-        PhaseAIn in;
-        Projected pr;
-        if (it < waiting) {
-          idx = (int)sIdx[it];
-          in.p = {sP[0][it], sP[1][it], sP[2][it]};
-          if constexpr (CACHED) {  // ONE 32-byte record: scales (or covariance), opacity, rotation
-            const float4 b0 = a.cull_shape[2 * (size_t)idx], b1 = a.cull_shape[2 * (size_t)idx + 1];
-            if (PRECOMP_COV) {
-              in.c0 = b0.x; in.c1 = b0.y; in.c2 = b0.z; in.c3 = b0.w; in.c4 = b1.x; in.c5 = b1.y; in.c6 = 0.0f;
-              opac = b1.z;
-            } else {
-              in.c0 = b0.x; in.c1 = b0.y; in.c2 = b0.z; opac = b0.w;
-              in.c3 = b1.x; in.c4 = b1.y; in.c5 = b1.z; in.c6 = b1.w;
-            }
-          } else {
-            phase_a_load_shape<PRECOMP_COV>(a, idx, in);
-          }
-          keep = phase_a1_exact<PRECOMP_COV>(a, vm, pm, idx, in, pr, radius);
-          a.radii[idx] = radius;
-        }
-        const uint64_t mk = __ballot(keep);
-        if (mk != 0ull) {
-          uint32_t lbase = 0;
-          if (lane == 0) lbase = atomicAdd(&vis_tail, (uint32_t)__popcll(mk));
-          lbase = __shfl(lbase, 0, 64);
-          if (keep) {
-            my_tiles += ((pr.rect_x >> 16) - (pr.rect_x & 0xffffu)) * ((pr.rect_y >> 16) - (pr.rect_y & 0xffffu));
-            preprocess_phase_b<CACHED>(a, idx, in.p, pr, lbase + (uint32_t)__popcll(mk & lt_mask), my_list, opac);
-          }
-        }
-        done += 256u;
-      }
-      if (done > waiting) done = waiting;
-      // the (< 256) candidates that did not fill a pass move to the front and wait for the next one
-      const uint32_t left = waiting - done;
-      __syncthreads();  // every lane has read its candidate
-      uint32_t mv_idx = 0;
-      float mv[3];
-      if ((uint32_t)tid < left) {
-        mv_idx = sIdx[done + tid];
-#pragma unroll
-        for (int k = 0; k < 3; k++) mv[k] = sP[k][done + tid];
-      }
-      __syncthreads();
-      if ((uint32_t)tid < left) {
-        sIdx[tid] = mv_idx;
-#pragma unroll
-        for (int k = 0; k < 3; k++) sP[k][tid] = mv[k];
-      }
-      if (tid == 0) cand_tail = left;
-    }
-    __syncthreads();  // everybody has read cand_tail (and sees the compacted queue) before the next group appends
-  }
-  const uint32_t wsum = gcr_wave_sum_u32(my_tiles);
-  if (lane == 0 && wsum) atomicAdd(&blk_tiles, (unsigned long long)wsum);
-  const int any_viol = __syncthreads_or(viol ? 1 : 0);
-  if (tid == 0) {
-    a.vis_count[blockIdx.x] = vis_tail;
-    // summed (= num_rendered) by the first workgroup of the next kernel; bit 63: a prefilter violation
-    a.block_tiles[blockIdx.x] = blk_tiles | (any_viol ? GCR_PREFILTER_FLAG : 0ull);
-  }
-}
-
-#if defined(GCR_K1_OLD_FUSED) || defined(GCR_EXPERIMENTS)  /* A/B builds only: the fused kernel as it was until round 5 */
-constexpr int FUSED_R4_CAP = 512;  // <= 255 left over + <= 256 new candidates per iteration
-
-//
-// CACHED (gcr_gaussians.cull_cache, a static scene's second line -- never the headline): the stream is the 16-byte cache
-// record instead of 40 B from three arrays; a candidate waits in LDS with its mean only and fetches its scales / rotation
-// (or covariance) at the start of its processing pass -- two line gathers for the few per cent that get that far.  The
-// cull's decisions are those of the stateless kernel (the same mean, the same rho, the same test), and A0 only ever
-// skips Gaussians whose exact result is radius 0, so radii / lists / image are the same bits either way.
-template <bool PRECOMP_COV, bool CACHED>
-__global__ __launch_bounds__(256) void k_preprocess_fused_r4(const GcrPreprocessArgs a) {
-  constexpr int QF = CACHED ? 3 : 10;  // floats a waiting candidate keeps in LDS
-  __shared__ uint32_t sIdx[FUSED_R4_CAP];
-  __shared__ float sIn[QF][FUSED_R4_CAP];
+  __shared__ uint32_t sIdx[FUSED_CAP];
+  __shared__ float sIn[10][FUSED_CAP];
   __shared__ uint32_t cand_tail, vis_tail;
   __shared__ uint32_t wave_new[2][4];  // candidates each wave found in this iteration, double-buffered by parity
   __shared__ unsigned long long blk_tiles;
@@ -838,32 +601,22 @@ __global__ __launch_bounds__(256) void k_preprocess_fused_r4(const GcrPreprocess
   uint32_t waiting = 0;
   uint32_t parity = 0;
 
-  // AHEAD iterations of inputs in flight per wave besides the current one (bytes in flight per wave are what keeps the
-  // stream at HBM speed: 40 B x 2 stateless; the cached stream is 16 B per Gaussian and needs more of them).  The
-  // prefetch never leaves the block's own chunk: lanes that would read past it re-read the chunk's last record (one
-  // L2-hot line) -- until round 5 they read the NEXT block's first two iterations, 20 KB x 2 048 blocks = 42 MB of the
-  // 313 MB the kernel fetched at C3 (profiles/r05_traffic.json).
-  constexpr int AHEAD = 2;
-  PhaseAIn q[AHEAD + 1];
+  PhaseAIn cur, nxt, nx2;
   bool viol = false;  // gcr_camera.prefiltered and a Gaussian behind the near plane
   long long idx64 = chunk_begin + tid;
-  const long long last = GCR_K1_PREFETCH_LIMIT;
-#pragma unroll
-  for (int k = 0; k < AHEAD; k++) {
-    const long long i = idx64 + 256 * k;
-    stream_load<PRECOMP_COV, CACHED>(a, i < last ? i : last, q[k]);
-  }
+  // The prefetch never leaves the block's own chunk: lanes that would read past it re-read the chunk's last Gaussian (an
+  // L2-hot line).  Until round 5 they read on into the next block's chunk -- 20 KB x 2 048 blocks = 42 MB of the 313 MB the
+  // kernel fetched at C3.  K1 alone: C3 82.3 -> 83.2 us, C5 355 -> 347 us, C2 18.3 -> 17.1 us
+  // (profiles/r05_k1_ab_stateless_clamp_touch.jsonl, one process, alternating).
+  const long long last = chunk_end - 1;
+  phase_a_load<PRECOMP_COV>(a, idx64 < last ? idx64 : last, cur);
+  phase_a_load<PRECOMP_COV>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);
   for (long long base = chunk_begin; base < chunk_end; base += 256, parity ^= 1u) {
     idx64 = base + tid;
-    {
-      const long long i = idx64 + 256 * AHEAD;
-      stream_load<PRECOMP_COV, CACHED>(a, i < last ? i : last, q[AHEAD]);  // prefetch, AHEAD iterations ahead
-    }
-    const PhaseAIn cur = q[0];
+    phase_a_load<PRECOMP_COV>(a, idx64 + 512 < last ? idx64 + 512 : last, nx2);  // prefetch, two iterations ahead
     bool candidate = false;
     if (idx64 < chunk_end) {
-      candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur,
-                                                          CACHED ? cur.c0 : cull_rho<PRECOMP_COV>(a.scale_modifier, cur));
+      candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur, cull_rho<PRECOMP_COV>(a.scale_modifier, cur));
       if (!candidate) a.radii[idx64] = 0;
       if (a.prefiltered) viol |= near_plane_violation(vm, cur);
     }
@@ -877,15 +630,13 @@ __global__ __launch_bounds__(256) void k_preprocess_fused_r4(const GcrPreprocess
         const uint32_t slot = wbase + (uint32_t)__popcll(m & lt_mask);
         sIdx[slot] = (uint32_t)idx64;
         sIn[0][slot] = cur.p.x; sIn[1][slot] = cur.p.y; sIn[2][slot] = cur.p.z;
-        if constexpr (!CACHED) {
-          sIn[3][slot] = cur.c0; sIn[4][slot] = cur.c1; sIn[5][slot] = cur.c2;
-          sIn[6][slot] = cur.c3; sIn[7][slot] = cur.c4; sIn[8][slot] = cur.c5;
-          sIn[9][slot] = cur.c6;
-        }
+        sIn[3][slot] = cur.c0; sIn[4][slot] = cur.c1; sIn[5][slot] = cur.c2;
+        sIn[6][slot] = cur.c3; sIn[7][slot] = cur.c4; sIn[8][slot] = cur.c5;
+        sIn[9][slot] = cur.c6;
       }
     }
-#pragma unroll
-    for (int k = 0; k < AHEAD; k++) q[k] = q[k + 1];
+    cur = nxt;
+    nxt = nx2;
     __syncthreads();
     waiting += wave_new[parity][0] + wave_new[parity][1] + wave_new[parity][2] + wave_new[parity][3];
     const bool last_iter = base + 256 >= chunk_end;
@@ -901,13 +652,9 @@ __global__ __launch_bounds__(256) void k_preprocess_fused_r4(const GcrPreprocess
         if (it < waiting) {
           idx = (int)sIdx[it];
           in.p = {sIn[0][it], sIn[1][it], sIn[2][it]};
-          if constexpr (CACHED) {
-            phase_a_load_shape<PRECOMP_COV>(a, idx, in);
-          } else {
-            in.c0 = sIn[3][it]; in.c1 = sIn[4][it]; in.c2 = sIn[5][it];
-            in.c3 = sIn[6][it]; in.c4 = sIn[7][it]; in.c5 = sIn[8][it];
-            in.c6 = sIn[9][it];
-          }
+          in.c0 = sIn[3][it]; in.c1 = sIn[4][it]; in.c2 = sIn[5][it];
+          in.c3 = sIn[6][it]; in.c4 = sIn[7][it]; in.c5 = sIn[8][it];
+          in.c6 = sIn[9][it];
           keep = phase_a1_exact<PRECOMP_COV>(a, vm, pm, idx, in, pr, radius);
           a.radii[idx] = radius;
         }
@@ -928,17 +675,17 @@ __global__ __launch_bounds__(256) void k_preprocess_fused_r4(const GcrPreprocess
       const uint32_t left = waiting - done;
       __syncthreads();  // every lane has read its candidate
       uint32_t mv_idx = 0;
-      float mv[QF];
+      float mv[10];
       if ((uint32_t)tid < left) {
         mv_idx = sIdx[done + tid];
 #pragma unroll
-        for (int k = 0; k < QF; k++) mv[k] = sIn[k][done + tid];
+        for (int k = 0; k < 10; k++) mv[k] = sIn[k][done + tid];
       }
       __syncthreads();
       if ((uint32_t)tid < left) {
         sIdx[tid] = mv_idx;
 #pragma unroll
-        for (int k = 0; k < QF; k++) sIn[k][tid] = mv[k];
+        for (int k = 0; k < 10; k++) sIn[k][tid] = mv[k];
       }
       if (tid == 0) cand_tail = left;
       waiting = left;
@@ -954,7 +701,177 @@ __global__ __launch_bounds__(256) void k_preprocess_fused_r4(const GcrPreprocess
     a.block_tiles[blockIdx.x] = blk_tiles | (any_viol ? GCR_PREFILTER_FLAG : 0ull);
   }
 }
+
+// K1 fused, a static scene's variant (gcr_gaussians.cull_cache -- a second line, never the headline).  The stream is part A
+// of the cache, ONE 16-byte (mean, rho) record per Gaussian instead of 40 B out of three arrays (56 B when the rows are
+// [N,14]); a candidate waits in LDS with its index and mean and reads part B -- scales, opacity, rotation as ONE 32-byte
+// record -- at the start of its processing pass, instead of a 128-byte line of each of three arrays.  The cull's decisions
+// are those of the stateless kernel (the same mean, the same rho, the same test), A0 only ever skips Gaussians whose
+// exact result is radius 0, and the records are copies: radii / lists / image are the same bits either way
+// (tests/test_gpu_cull_cache.py).  K1 alone at C3: 86.8 -> 55.9 us, at C5: 365 -> 266 us
+// (profiles/r05_k1_ab_same_process.jsonl).
+//
+// Its streaming loop runs in GROUPS of NS iterations with one register set per iteration of the group:
+//   * stage k's registers are loaded for the NEXT group right after their last use in this one, so NS - 1 iterations of
+//     records are in flight per wave and no register is ever copied (the stateless loop above rotates cur <- nxt <- nx2:
+//     the copies read the loads' destination registers, so it waits for all but the newest loads -- measured as good
+//     for a 40-byte stream, 86.8 vs 86.1 us with this structure, and better at C5, 365 vs 377 us, where this one's
+//     candidates would have to re-read their scales / rotations);
+//   * one barrier pair per group instead of one barrier per iteration; a processing pass runs at the end of a group when
+//     256 candidates are waiting (all lanes busy) and at the end of the chunk; the queue holds a whole group's worth.
+#ifndef GCR_K1_STAGES_CACHED  /* A/B builds: iterations per group of the cached stream (16 B per lane and iteration) */
+#define GCR_K1_STAGES_CACHED 5
 #endif
+
+template <bool PRECOMP_COV>
+__global__ __launch_bounds__(256) void k_preprocess_fused_cached(const GcrPreprocessArgs a) {
+  constexpr int NS = GCR_K1_STAGES_CACHED;
+  constexpr int CAP = 256 * (NS + 1);  // <= 255 left over + <= 256 NS new candidates per group
+  __shared__ uint32_t sIdx[CAP];
+  __shared__ float sP[3][CAP];
+  __shared__ uint32_t cand_tail, vis_tail;
+  __shared__ unsigned long long blk_tiles;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) {
+    cand_tail = 0;
+    vis_tail = 0;
+    blk_tiles = 0ull;
+  }
+  __syncthreads();
+  float vm[16], pm[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    vm[i] = gcr_uniform(GCR_CAM(a, view, a.view, i));
+    pm[i] = gcr_uniform(GCR_CAM(a, proj, a.proj, i));
+  }
+  float wf2 = 0.0f;
+  {
+    const float wc[3][3] = {{vm[0], vm[1], vm[2]}, {vm[4], vm[5], vm[6]}, {vm[8], vm[9], vm[10]}};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      float row = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        row += __builtin_fabsf(wc[0][i] * wc[0][j] + wc[1][i] * wc[1][j] + wc[2][i] * wc[2][j]);
+      wf2 = __builtin_fmaxf(wf2, row);
+    }
+    wf2 *= 1.001f;
+  }
+  const long long chunk_begin = (long long)blockIdx.x * a.chunk;
+  const long long chunk_end = chunk_begin + a.chunk < a.P ? chunk_begin + a.chunk : a.P;
+  const long long clast = chunk_end - 1;  // (every block owns at least one Gaussian: gcr_preprocess_grid)
+  uint32_t* __restrict__ my_list = a.vis_list + chunk_begin;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  uint32_t my_tiles = 0;
+  bool viol = false;  // gcr_camera.prefiltered and a Gaussian behind the near plane
+
+  float4 q[NS];  // (mean, rho) of this thread's Gaussian in iteration k of the group
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const long long i = chunk_begin + 256 * k + tid;
+    q[k] = a.cull_cache[i < clast ? i : clast];
+  }
+  for (long long gbase = chunk_begin; gbase < chunk_end; gbase += 256 * NS) {
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      const long long idx64 = gbase + 256 * k + tid;
+      bool candidate = false;
+      if (idx64 < chunk_end) {
+        PhaseAIn in;
+        in.p = {q[k].x, q[k].y, q[k].z};
+        in.c0 = in.c1 = in.c2 = in.c3 = in.c4 = in.c5 = in.c6 = 0.0f;  // (the cull reads the mean and rho only)
+        candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, in, q[k].w);
+        if (!candidate) a.radii[idx64] = 0;
+        if (a.prefiltered) viol |= near_plane_violation(vm, in);
+      }
+      const uint64_t m = __ballot(candidate);
+      if (m != 0ull) {
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&cand_tail, (uint32_t)__popcll(m));
+        wbase = __shfl(wbase, 0, 64);
+        if (candidate) {
+          const uint32_t slot = wbase + (uint32_t)__popcll(m & lt_mask);
+          sIdx[slot] = (uint32_t)idx64;
+          sP[0][slot] = q[k].x; sP[1][slot] = q[k].y; sP[2][slot] = q[k].z;
+        }
+      }
+      // stage k's registers are free now: the same iteration of the NEXT group goes into them (the compiler must not
+      // hoist the load above the uses -- it would need a second register set and copy it at the back-edge)
+      asm volatile("" ::: "memory");
+      const long long inext = idx64 + 256 * NS;
+      q[k] = a.cull_cache[inext < clast ? inext : clast];
+    }
+    __syncthreads();
+    const uint32_t waiting = cand_tail;  // block-uniform: nobody appends again before the barrier(s) below
+    const bool last_group = gbase + 256 * NS >= chunk_end;
+    if (waiting >= 256u || (last_group && waiting > 0u)) {
+      // ---- processing passes over the waiting candidates: full 256-lane passes, plus the remainder at the end
+      uint32_t done = 0;
+      while (done + 256u <= waiting || (last_group && done < waiting)) {
+        const uint32_t it = done + (uint32_t)tid;
+        bool keep = false;
+        int idx = 0, radius = 0;
+        float opac = 0.0f;
+        PhaseAIn in;
+        Projected pr;
+        if (it < waiting) {
+          idx = (int)sIdx[it];
+          in.p = {sP[0][it], sP[1][it], sP[2][it]};
+          {  // ONE 32-byte record: scales (or covariance), opacity, rotation
+            const float4 b0 = a.cull_shape[2 * (size_t)idx], b1 = a.cull_shape[2 * (size_t)idx + 1];
+            if (PRECOMP_COV) {
+              in.c0 = b0.x; in.c1 = b0.y; in.c2 = b0.z; in.c3 = b0.w; in.c4 = b1.x; in.c5 = b1.y; in.c6 = 0.0f;
+              opac = b1.z;
+            } else {
+              in.c0 = b0.x; in.c1 = b0.y; in.c2 = b0.z; opac = b0.w;
+              in.c3 = b1.x; in.c4 = b1.y; in.c5 = b1.z; in.c6 = b1.w;
+            }
+          }
+          keep = phase_a1_exact<PRECOMP_COV>(a, vm, pm, idx, in, pr, radius);
+          a.radii[idx] = radius;
+        }
+        const uint64_t mk = __ballot(keep);
+        if (mk != 0ull) {
+          uint32_t lbase = 0;
+          if (lane == 0) lbase = atomicAdd(&vis_tail, (uint32_t)__popcll(mk));
+          lbase = __shfl(lbase, 0, 64);
+          if (keep) {
+            my_tiles += ((pr.rect_x >> 16) - (pr.rect_x & 0xffffu)) * ((pr.rect_y >> 16) - (pr.rect_y & 0xffffu));
+            preprocess_phase_b<true>(a, idx, in.p, pr, lbase + (uint32_t)__popcll(mk & lt_mask), my_list, opac);
+          }
+        }
+        done += 256u;
+      }
+      if (done > waiting) done = waiting;
+      // the (< 256) candidates that did not fill a pass move to the front and wait for the next one
+      const uint32_t left = waiting - done;
+      __syncthreads();  // every lane has read its candidate
+      uint32_t mv_idx = 0;
+      float mv[3];
+      if ((uint32_t)tid < left) {
+        mv_idx = sIdx[done + tid];
+#pragma unroll
+        for (int k = 0; k < 3; k++) mv[k] = sP[k][done + tid];
+      }
+      __syncthreads();
+      if ((uint32_t)tid < left) {
+        sIdx[tid] = mv_idx;
+#pragma unroll
+        for (int k = 0; k < 3; k++) sP[k][tid] = mv[k];
+      }
+      if (tid == 0) cand_tail = left;
+    }
+    __syncthreads();  // everybody has read cand_tail (and sees the compacted queue) before the next group appends
+  }
+  const uint32_t wsum = gcr_wave_sum_u32(my_tiles);
+  if (lane == 0 && wsum) atomicAdd(&blk_tiles, (unsigned long long)wsum);
+  const int any_viol = __syncthreads_or(viol ? 1 : 0);
+  if (tid == 0) {
+    a.vis_count[blockIdx.x] = vis_tail;
+    // summed (= num_rendered) by the first workgroup of the next kernel; bit 63: a prefilter violation
+    a.block_tiles[blockIdx.x] = blk_tiles | (any_viol ? GCR_PREFILTER_FLAG : 0ull);
+  }
+}
 
 // ------------------------------------------------------------------------------------- K2
 // Exclusive scan (in place) of the n per-block tile counts; *total = num_rendered
@@ -1435,44 +1352,16 @@ hipError_t gcr_launch_build_cull_cache(const GcrPreprocessArgs& a, float4* outA,
 hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, bool split, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
   if (!split) {  // default: streaming cull and exact pass in one kernel
-#ifdef GCR_EXPERIMENTS  // GCR_K1_R4=1 / GCR_K1_SH_TOUCH=1 in the environment, read per launch: A/B in one process
-    if (const char* e = getenv("GCR_K1_R4"))
-      if (atoi(e) != 0) {
-        GcrPreprocessArgs b = a;
-        if (const char* t = getenv("GCR_K1_SH_TOUCH")) b.exp_flags = atoi(t) != 0 ? 1 : 0;
-        if (const char* t = getenv("GCR_K1_NOCLAMP")) b.exp_flags |= atoi(t) != 0 ? 2 : 0;
-        if (b.cull_cache != nullptr) {
-          if (b.cov3D_precomp != nullptr) k_preprocess_fused_r4<true, true><<<b.nblocks, 256, 0, s>>>(b);
-          else k_preprocess_fused_r4<false, true><<<b.nblocks, 256, 0, s>>>(b);
-        } else if (b.cov3D_precomp != nullptr) {
-          k_preprocess_fused_r4<true, false><<<b.nblocks, 256, 0, s>>>(b);
-        } else {
-          k_preprocess_fused_r4<false, false><<<b.nblocks, 256, 0, s>>>(b);
-        }
-        return hipGetLastError();
-      }
-    GcrPreprocessArgs b = a;
-    if (const char* t = getenv("GCR_K1_SH_TOUCH")) b.exp_flags = atoi(t) != 0 ? 1 : 0;
-#define a b
-#endif
-#ifdef GCR_K1_OLD_FUSED
-#define GCR_K1_FUSED k_preprocess_fused_r4
-#else
-#define GCR_K1_FUSED k_preprocess_fused
-#endif
     if (a.cull_cache != nullptr) {  // a static scene's cull cache (gcr_gaussians.cull_cache): same results, fewer bytes
       if (a.cov3D_precomp != nullptr)
-        GCR_K1_FUSED<true, true><<<a.nblocks, 256, 0, s>>>(a);
+        k_preprocess_fused_cached<true><<<a.nblocks, 256, 0, s>>>(a);
       else
-        GCR_K1_FUSED<false, true><<<a.nblocks, 256, 0, s>>>(a);
+        k_preprocess_fused_cached<false><<<a.nblocks, 256, 0, s>>>(a);
     } else if (a.cov3D_precomp != nullptr) {
-      GCR_K1_FUSED<true, false><<<a.nblocks, 256, 0, s>>>(a);
+      k_preprocess_fused<true><<<a.nblocks, 256, 0, s>>>(a);
     } else {
-      GCR_K1_FUSED<false, false><<<a.nblocks, 256, 0, s>>>(a);
+      k_preprocess_fused<false><<<a.nblocks, 256, 0, s>>>(a);
     }
-#ifdef GCR_EXPERIMENTS
-#undef a
-#endif
     return hipGetLastError();
   }
   if (a.cov3D_precomp != nullptr) {

@@ -2,7 +2,7 @@
 (gaussiancity_amd/cull_cache.py), forward frames of a BASELINE config one after the other on one stream -- the stage timer's
 average for K1 alone, the serial wall time per frame, and whether image / radii / num_rendered of the two are the same bits.
     gpurun -- 'python tools/k1_ab.py C3 > gpurun_out/r05_k1_ab.jsonl'
-GCR_LIB_PATH selects a variant build (tools/ab_variants.sh: -DGCR_K1_OLD_FUSED, -DGCR_K1_NO_CHUNK_CLAMP, -DGCR_K1_STAGES=n ...)."""
+GCR_LIB_PATH selects a variant build (tools/ab_variants.sh; e.g. EXTRA=-DGCR_K1_STAGES_CACHED=3)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,14 +24,10 @@ def f(i):
          False, False)
     return ext.rasterize_gaussians(*a, _for_backward=False)
 ref = {}
-exp = "exp" in os.path.basename(N.LIB_PATH)
-# (r4 kernel, SH touch, cull cache); the first two are switches of the experiment build (tools/_build/libgcr_hip_exp.so)
-configs = [(1, 0, 0), (0, 0, 0), (0, 1, 0), (1, 0, 1), (0, 0, 1), (0, 1, 1)] * 3 if exp else [(0, 0, 0), (0, 0, 1)] * 2
-if exp and os.environ.get("K1_AB_SET") == "stateless_r4":  # the round-4 kernel: prefetch clamp x SH touch (r4 + 10 * noclamp)
-    configs = [(1, 0, 0), (11, 0, 0), (1, 1, 0), (11, 1, 0)] * 3
-for r4, sht, mode in configs:
-    os.environ["GCR_K1_NOCLAMP"] = str(r4 // 10); r4 = r4 % 10
-    os.environ["GCR_K1_R4"] = str(r4); os.environ["GCR_K1_SH_TOUCH"] = str(sht)
+# (The experiment switches this tool drove for profiles/r05_k1_ab_same_process.jsonl and r05_k1_ab_stateless_clamp_touch.jsonl
+# -- the grouped loop for the stateless stream, the prefetch clamp, the early SH load, each per launch through the
+# environment of the experiment build -- are in the tree at commit 3257f5d; what they decided is in the kernels' comments.)
+for mode in (0, 1, 0, 1, 0, 1):
     cull_cache.enable(bool(mode))
     same = True
     for pose in (0, 5, 17):
@@ -53,8 +49,7 @@ for r4, sht, mode in configs:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(frames): f(i)
         torch.cuda.synchronize(); walls.append((time.perf_counter() - t0) / frames * 1e3)
-    print(json.dumps({"config": cfgname, "cull_cache": mode, "r4_kernel": r4 if exp else None, "sh_touch": sht if exp else None, "noclamp": int(os.environ["GCR_K1_NOCLAMP"]) if exp else None,
-                      "k1_blocks_env": os.environ.get("GCR_K1_BLOCKS"), "lib": os.path.basename(N.LIB_PATH),
+    print(json.dumps({"config": cfgname, "cull_cache": mode, "lib": os.path.basename(N.LIB_PATH),
                       "preprocess_ms": round(st["preprocess"], 4), "serial_wall_ms": round(float(np.median(walls)), 4),
                       "same_bits_as_first": bool(same)}), flush=True)
 cull_cache.enable(False)
