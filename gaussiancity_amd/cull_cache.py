@@ -15,9 +15,14 @@ inference frames): a training step changes its Gaussians every iteration, the ca
 
 Validity.  An entry is keyed on (data_ptr, _version, shape, strides) of every tensor it was built from plus
 scale_modifier, and it keeps those tensors alive -- so the address cannot be handed to another allocation while the entry
-exists, and any in-place edit through torch (which bumps `_version`) misses the key and rebuilds.  Writes torch cannot
-see (a raw kernel scribbling into the storage) are not detected: call invalidate() after such a write.  Tensors without a
-version counter (inference-mode tensors) are never cached.
+exists, and any in-place edit through torch (which bumps `_version`) misses the key and rebuilds.  Writes torch's version
+counter does not see are not detected -- a raw kernel scribbling into the storage, an in-place operation on `tensor.data`
+(which carries a version counter of its own): call invalidate() after such a write.  Tensors without a version counter
+(inference-mode tensors) are never cached.  A scene whose tensors are new objects with new storage every frame is
+rebuilt every frame; after eight such frames in a row the cache steps aside until invalidate().
+
+Memory: 48 bytes per Gaussian per cached scene (240 MB at 5 M, 960 MB at 20 M), at most two scenes, plus the scene's own
+tensors, which an entry keeps alive.
 """
 import collections
 import ctypes as C
@@ -78,11 +83,18 @@ def invalidate():
         _drop_all()
 
 
+def _quiesce(cache):
+    """Frames on other streams may still be reading `cache` (which belongs to the stream it was built on): before it goes
+    back to the allocator, wait for its device."""
+    if cache.is_cuda:
+        torch.cuda.synchronize(cache.device)
+
+
 def _drop_all():
     global _builds_in_a_row
     _builds_in_a_row = 0
-    if _entries and torch.cuda.is_available():
-        torch.cuda.synchronize()  # frames on other streams may still be reading a cache (allocated on the build stream)
+    for cache, _ in _entries.values():
+        _quiesce(cache)
     _entries.clear()
 
 
@@ -132,8 +144,7 @@ def attach(g, scale_modifier, tensors, device, stream):
             torch.cuda.current_stream(device).synchronize()
         stats["builds"] += 1
         while len(_entries) >= _MAX_ENTRIES:
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()  # (see _drop_all)
+            _quiesce(next(iter(_entries.values()))[0])
             _entries.popitem(last=False)
         _entries[key] = (cache, tuple(t for t in tensors if t is not None))
         g.cull_cache = cache.data_ptr()
