@@ -494,6 +494,8 @@ def main():
         blend_ach = ab["blend_fwd"] / 1e9 / (blend_ms / 1e3) if blend_ms > 0 else 0.0
         # HBM bytes / VALU instructions per launch from the committed rocprofv3 --pmc passes of this workload
         tag = {"C3": "", "C2": "c2", "C5": "c5"}.get(args.config) if args.points is None else None
+        if args.static_scene:  # the cached K1 moves other bytes: its own counter passes, or none
+            tag = "static_scene" if tag == "" else None
         tdoc, tfile = traffic_doc(tag) if tag is not None else (None, None)
         tk = tdoc["kernels"].get(dom) if tdoc else None
         traffic = int((2 * tk["FETCH_SIZE_KB"] + tk["WRITE_SIZE_KB"]) * 1024) if tk else None  # gfx950: FETCH_SIZE

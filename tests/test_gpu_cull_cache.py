@@ -178,3 +178,32 @@ def test_c_abi_build_and_use(oracle_mod, cuda_device):
     assert (rec[:, 3].astype(np.float64) >= lam).all()
     assert L.gcr_build_cull_cache(C.byref(g), 1.5, out.data_ptr() + 16, None) == -1   # GCR_ERR_INVALID_ARGUMENT
     assert b"128-byte" in L.gcr_last_error()
+
+
+def test_inference_loop_of_a_static_scene(cuda_device):
+    """frames.InferenceLoop(static_scene=True): frames rotate over three streams and all of them read the one cache the
+    first frame built -- byte for byte the frames of the stateless loop, float route and uint8 route."""
+    from gaussiancity_amd import cull_cache, frames, synth
+    from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper
+    W, H = 160, 96
+    wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), device=cuda_device)
+    sc = scenes.blob_scene(30000, 91, 0, spread=120.0)
+    rot_xyzw = sc["rotations"][:, [1, 2, 3, 0]]
+    pts = torch.from_numpy(np.concatenate([sc["means3D"], sc["opacities"], sc["scales"], rot_xyzw,
+                                           sc["colors_precomp"]], axis=1).astype(np.float32)).to(cuda_device)
+    poses = synth.orbit_poses(9, 60.0, 50.0)
+    cull_cache.invalidate()
+    assert not cull_cache.enabled()
+    before = dict(cull_cache.stats)
+    with torch.no_grad():
+        want = frames.InferenceLoop(wr, device=cuda_device).run(pts, poses)
+        assert cull_cache.stats == before                       # off unless asked for
+        got = frames.InferenceLoop(wr, device=cuda_device, static_scene=True).run(pts, poses)
+        u8 = frames.InferenceLoop(wr, device=cuda_device, static_scene=True,
+                                  render_uint8_fn=lambda p, c, q: wr(p, c, q, as_uint8=True)).run(pts, poses)
+    assert cull_cache.stats["builds"] == before["builds"] + 1 and cull_cache.stats["hits"] >= before["hits"] + 2 * len(poses) - 1
+    assert not cull_cache.enabled()                             # the switch was the loop's, for the loop
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert all(np.array_equal(a, b) for a, b in zip(u8, want))
+    assert any(f.any() for f in got)
+    cull_cache.invalidate()

@@ -36,6 +36,15 @@ python $R/tools/rocpd_pmc.py /tmp/${TAG}_w/p_results.db $O/${TAG}_pmc_write.txt 
 python $R/tools/rocpd_pmc.py /tmp/${TAG}_sq/p_results.db $O/${TAG}_pmc_sq.txt > /dev/null
 python $R/tools/make_traffic.py /tmp/${TAG}_f/p_results.db /tmp/${TAG}_w/p_results.db $O/${TAG}_traffic.json /tmp/${TAG}_sq/p_results.db > /dev/null
 
+# ---- a static scene's second line (bench.py --static-scene: K1 reads the cull cache): one-stream trace + counters ----------
+B="python $R/bench.py --static-scene --no-cpu-baseline --no-secondary"
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_ss_kt1 -o k -- $B --streams 1 > /dev/null 2>&1 < /dev/null
+python $R/tools/rocpd_stats.py /tmp/${TAG}_ss_kt1/k_results.db $O/${TAG}_kernel_trace_stats_one_stream_static_scene.txt > /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/${TAG}_ss_f -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/${TAG}_ss_w -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1 < /dev/null
+python $R/tools/make_traffic.py /tmp/${TAG}_ss_f/p_results.db /tmp/${TAG}_ss_w/p_results.db $O/${TAG}_traffic_static_scene.json \
+  "" "C3 (5M S-city, 1920x1080, SH3, forward) with the static scene's cull cache" > /dev/null
+
 # ---- C2 forward + backward (BASELINE metric's second half): kernel trace + counters for K7 / K8 ---------------
 B="python $R/bench.py --config C2 --backward --no-cpu-baseline --no-secondary"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_c2_kt -o k -- $B --steps 200 > /dev/null 2>&1 < /dev/null
@@ -97,4 +106,8 @@ done > $O/${TAG}_bench_inference_loop.jsonl
 python $R/bench.py --config C2 --backward --no-secondary --steps 200 > $O/${TAG}_bench_c2_fwd_bwd.json 2>/dev/null
 python $R/bench.py --config C2 --backward --no-secondary --no-cpu-baseline --steps 200 --bwd-wave-units > $O/${TAG}_bench_c2_fwd_bwd_wave_units.json 2>/dev/null   # round 4's backward blend kernel (A/B)
 python $R/bench.py --steps 20 --no-cpu-baseline --no-secondary > $O/${TAG}_bench_c3_k20.json 2>/dev/null
+for c in C3 C5; do for m in "" "--native-int-api"; do   # the static scene's second line, stateless beside it on the same box
+  python $R/bench.py --config $c $m --no-cpu-baseline --no-secondary 2>/dev/null | tail -1
+  python $R/bench.py --config $c $m --static-scene --no-cpu-baseline --no-secondary 2>/dev/null | tail -1
+done; done > $O/${TAG}_bench_static_scene.jsonl
 echo collected $TAG; ls $O | grep "^${TAG}_"
