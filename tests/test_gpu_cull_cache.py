@@ -207,3 +207,39 @@ def test_inference_loop_of_a_static_scene(cuda_device):
     assert all(np.array_equal(a, b) for a, b in zip(u8, want))
     assert any(f.any() for f in got)
     cull_cache.invalidate()
+
+
+def test_cached_kernel_with_many_groups_and_passes_per_block(cuda_device):
+    """The cached K1's mid-chunk machinery: with the grid forced down to 12 blocks (GCR_K1_BLOCKS, read once per process ->
+    a subprocess) every block streams ~3400 Gaussians = three groups of five iterations, most of them candidates: passes
+    run at group ends, leftovers move to the front of the queue, a partial pass ends the chunk.  Full state against the
+    oracle for a mostly visible and a half-culled scene."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import gpu_util as G, scenes
+from gaussiancity_amd import cull_cache
+from oracle import oracle as O
+from test_gpu_parity import _frame, _check_forward
+cull_cache.enable(True)
+dev = torch.device("cuda:0")
+for spread, smax, floor in ((25.0, 3.0, 30000), (70.0, 3.0, 4000)):
+    P, W, H = 40000, 256, 160
+    rs = scenes.camera(W, H, pose_index=4)._replace(sh_degree=1)
+    sc = scenes.blob_scene(P, 57, 1, spread=spread, smax=smax)
+    fr = _frame(O, rs, sc)
+    assert floor < (fr.radii > 0).sum() < P, (fr.radii > 0).sum()
+    b = cull_cache.stats["builds"]
+    args, out = G.run_forward(rs, sc, dev, for_backward=False)
+    assert cull_cache.stats["builds"] == b + 1
+    _check_forward(fr, G.decode(P, W, H, out), P, True)
+print("CACHED_MANY_PASSES_OK")
+""" % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, GCR_K1_BLOCKS="12")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CACHED_MANY_PASSES_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -210,6 +210,10 @@ def main():
     ap.add_argument("--max-seconds", type=float, default=240.0)
     ap.add_argument("--wrapper-cases", type=int, default=150)
     ap.add_argument("--forward-only", action="store_true", help="skip the gradient comparison (same cases, same order)")
+    ap.add_argument("--static-scene", action="store_true",
+                    help="every case as an inference frame through the fused K1 with a static scene's cull cache "
+                         "(gaussiancity_amd/cull_cache.py), built per case; forward only.  GCR_K1_BLOCKS=12 in the "
+                         "environment makes every block stream several groups and run mid-chunk passes")
     a = ap.parse_args()
     import gpu_util as G
     import scenes
@@ -217,6 +221,10 @@ def main():
     from oracle import oracle as O
     O.build()
     dev = torch.device("cuda:0")
+    from gaussiancity_amd import cull_cache
+    if a.static_scene:
+        cull_cache.enable(True)
+        a.wrapper_cases = 0
     rng = np.random.default_rng(a.seed)
     t0, bad, done, by_regime = time.time(), 0, 0, {}
     for i in range(a.cases):
@@ -225,6 +233,9 @@ def main():
         c = draw_case(rng)
         if a.forward_only:
             c["backward"] = False
+        if a.static_scene:
+            c["backward"], c["train_frame"], c["split_preprocess"] = False, False, 0
+            cull_cache.invalidate()  # (a new scene per case: keep the cache from stepping aside)
         try:
             fails = run_case(c, O, G, scenes, N, dev)
         except Exception as e:  # a crash is a failure of the case, not of the sweep
@@ -234,8 +245,10 @@ def main():
         if fails:
             bad += 1
             print(json.dumps({"case": i, "fails": fails, "desc": c}), flush=True)
-    print(json.dumps({"cases": done, "failed": bad, "seconds": round(time.time() - t0, 1), "seed": a.seed,
-                      "by_regime": by_regime}), flush=True)
+    summary = {"cases": done, "failed": bad, "seconds": round(time.time() - t0, 1), "seed": a.seed, "by_regime": by_regime}
+    if a.static_scene:
+        summary.update(static_scene=True, cull_cache=dict(cull_cache.stats), k1_blocks_env=os.environ.get("GCR_K1_BLOCKS"))
+    print(json.dumps(summary), flush=True)
     # second sweep: the wrapper's own node (strides, flips, windows, camera modes) against the reference's route
     t1, wbad, wdone = time.time(), 0, 0
     for i in range(a.wrapper_cases):
