@@ -5,7 +5,8 @@
  * extensions/diff_gaussian_rasterization ("dgr/", CUDA sources under "cr/").  Plain pointers
  * and sizes only -- no torch types.  Every pointer is a DEVICE pointer (gfx950 HBM) unless
  * the name ends in _host.  All memory is owned by the caller (the reference lets torch own
- * it: dgr/rasterize_points.cu:57-68,118-126); nothing is retained across calls.
+ * it: dgr/rasterize_points.cu:57-68,118-126); nothing is retained across calls (the optional cull
+ * cache is the caller's buffer, too).
  *
  * Entry point                      replaces (reference interface)
  * -------------------------------  ---------------------------------------------------------
@@ -26,6 +27,9 @@
  * gcr_geometry_bytes/_image_bytes/ required<GeometryState|ImageState|BinningState>(n)
  *   _binning_bytes                 cr/rasterizer_impl.h:65-69
  * gcr_last_error                   the std::runtime_error text (cr/auxiliary.h:158-167)
+ * gcr_build_cull_cache +           (no counterpart: optional) what a caller whose scene does not change between frames
+ *   gcr_gaussians.cull_cache       (scripts/inference.py:640-667) may keep so that the per-Gaussian pass of the forward
+ *                                  (cr/forward.cu:147-233) streams 16 instead of 40 bytes per Gaussian; same outputs
  *
  * Conventions shared with the reference: matrices are 16 floats in the row-vector layout the
  * kernels index as m[0],m[4],m[8],m[12] (cr/auxiliary.h:48-56); quaternions are (r,x,y,z) and
