@@ -53,3 +53,26 @@ def test_bench_cli_surface():
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--help"]).decode()
     for flag in ("--gpus", "--steps", "--warmup", "--config", "--path", "--train-step"):
         assert flag in out
+
+
+def test_round5_lines_and_the_static_scene_second_line():
+    """The round's headline line is the stateless one; every line of the static scene's file says which of the two it is,
+    and the pairs were taken on one box (same workload, the cached line faster, never the file the driver's command writes)."""
+    def lines(name):
+        return [json.loads(l) for l in open(os.path.join(ROOT, "profiles", name)) if l.startswith("{")]
+    c3 = lines("r05_bench_c3.json")[-1]
+    _check(c3, True)
+    assert c3["config"]["cull"].startswith("stateless") and c3["cpu_baseline"]["gpu_image_bit_exact_vs_cpu"] is True
+    assert c3["secondary"]["cpu_baseline"]["worst_gradient_error_over_max"] <= 1e-4
+    both = lines("r05_bench_static_scene.jsonl")
+    assert len(both) == 8
+    for stateless, static in zip(both[0::2], both[1::2]):
+        _check(stateless, False)
+        _check(static, False)
+        assert stateless["config"]["cull"].startswith("stateless") and static["config"]["cull"].startswith("STATIC SCENE")
+        assert "second line" in static["config"]["cull"]
+        assert stateless["config"]["workload"] == static["config"]["workload"] and stateless["metric"] == static["metric"]
+        assert static["value"] > stateless["value"]
+        assert static["stages_ms"]["preprocess"]["ms_single_stream"] < stateless["stages_ms"]["preprocess"]["ms_single_stream"]
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--help"]).decode()
+    assert "--static-scene" in out and "--fast-exp" not in out
