@@ -55,25 +55,32 @@ def enable(on=True):
     return prev
 
 
+_tls = threading.local()  # .on: this host thread's override of the process-wide switch (scoped)
+
+
 def enabled():
-    return _enabled
+    """Does the calling thread's next inference frame use the cache?  (A scoped() block of this thread, else the
+    process-wide switch.)"""
+    return getattr(_tls, "on", _enabled)
 
 
 class scoped:
-    """`with cull_cache.scoped(True): ...` -- the switch for a block of frames; entries stay cached afterwards (a later
-    block on the same scene hits them)."""
+    """`with cull_cache.scoped(True): ...` -- the switch for a block of frames of THIS host thread (other threads keep
+    rendering with the process-wide setting); entries stay cached afterwards, a later block on the same scene hits them."""
 
     def __init__(self, on=True):
         self.on = bool(on)
 
     def __enter__(self):
-        global _enabled
-        self.prev, _enabled = _enabled, self.on
+        self.prev = getattr(_tls, "on", None)
+        _tls.on = self.on
         return self
 
     def __exit__(self, *exc):
-        global _enabled
-        _enabled = self.prev
+        if self.prev is None:
+            del _tls.on
+        else:
+            _tls.on = self.prev
         return False
 
 

@@ -500,7 +500,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                               tan_fovy, H, W, scale_modifier, degree, prefiltered, debug, _for_backward)
         g, keep_g = _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations,
                                cov3D_precomp)
-        if _cull._enabled and not _for_backward:  # a static scene's cull cache: same bits, fewer bytes (cull_cache.py)
+        if _cull.enabled() and not _for_backward:  # a static scene's cull cache: same bits, fewer bytes (cull_cache.py)
             keep_g.append(_cull.attach(g, scale_modifier, (means3D, scales, rotations, cov3D_precomp, opacity), device,
                                        _stream(device)))
         out = _forward(L, device, cam, g, P, H, W, _ticket)
@@ -562,7 +562,7 @@ def rasterize_points14(points, background, scale_modifier, viewmatrix, projmatri
         cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W,
                               scale_modifier, 0, False, False, for_backward, flip_x, flip_y, window, out_uint8)
         keep_cc = None
-        if _cull._enabled and not for_backward:  # (see rasterize_gaussians)
+        if _cull.enabled() and not for_backward:  # (see rasterize_gaussians)
             keep_cc = _cull.attach(g, scale_modifier, (points,), device, _stream(device))
         out = _forward(L, device, cam, g, P, H, W, ticket)
         del keep_c, pts, keep_cc

@@ -91,11 +91,18 @@ def test_inference_tensors_are_never_cached(builds):
     assert c is None and not g.cull_cache and builds == []
 
 
-def test_scoped_switch():
+def test_scoped_switch_is_the_calling_threads():
+    import threading
     prev = cc.enable(False)
     try:
+        seen = []
         with cc.scoped(True):
             assert cc.enabled()
-        assert not cc.enabled()
+            th = threading.Thread(target=lambda: seen.append(cc.enabled()))
+            th.start(); th.join()
+            with cc.scoped(False):
+                assert not cc.enabled()
+            assert cc.enabled()
+        assert not cc.enabled() and seen == [False]
     finally:
         cc.enable(prev)
