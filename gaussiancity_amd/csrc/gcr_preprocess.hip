@@ -449,8 +449,11 @@ __global__ __launch_bounds__(256) void k_preprocess_cull(const GcrPreprocessArgs
   uint32_t* __restrict__ my_cand = a.cand_list + chunk_begin;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-  // two iterations of inputs in flight per wave: when the kernel shares the GPU with another frame's blend it
-  // gets a fraction of the wave slots, and bytes in flight per wave are what keeps the stream at HBM speed
+  // inputs are requested two iterations ahead (when the kernel shares the GPU with another frame's blend it gets a
+  // fraction of the wave slots, and bytes in flight per wave are what keeps the stream at HBM speed).  What the hardware
+  // sees is less: the rotation cur <- nxt <- nx2 at the end of an iteration copies the loads' destination registers, so
+  // the loop waits for all but the newest loads -- see k_preprocess_fused_cached for the copy-free form and why this
+  // 40-byte stream does not gain from it
   PhaseAIn cur, nxt, nx2;
   bool viol = false;  // gcr_camera.prefiltered and a Gaussian behind the near plane
   long long idx64 = chunk_begin + tid;
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
   uint32_t waiting = 0;
   uint32_t parity = 0;
 
-  PhaseAIn cur, nxt, nx2;
+  PhaseAIn cur, nxt, nx2;  // (requested two iterations ahead; what the rotation below leaves of that: see k_preprocess_cull)
   bool viol = false;  // gcr_camera.prefiltered and a Gaussian behind the near plane
   long long idx64 = chunk_begin + tid;
   // The prefetch never leaves the block's own chunk: lanes that would read past it re-read the chunk's last Gaussian (an
