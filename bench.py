@@ -79,8 +79,9 @@ def main():
     ap.add_argument("--sort-in-blend", action="store_true",
                     help="the forward blend sorts its own tiles (lower frame latency, lower throughput; A/B)")
     ap.add_argument("--static-scene", action="store_true",
-                    help="second line, never the headline: the scene does not change between frames, so the rasterizer "
-                         "keeps its cull cache (gaussiancity_amd/cull_cache.py: same frames, K1 streams 16 B per Gaussian)")
+                    help="second line, never the headline: ONE mostly off-screen set of Gaussians rendered from many poses "
+                         "(C3 / C5), so the rasterizer keeps its cull cache (gaussiancity_amd/cull_cache.py: same frames, K1 "
+                         "streams 16 B per Gaussian); a mostly visible set (--inference-loop) is slower with it")
     ap.add_argument("--split-preprocess", action="store_true",
                     help="K1 as two kernels (streaming cull, then exact pass) instead of the fused one (A/B only)")
     ap.add_argument("--backward", action="store_true",

@@ -1,12 +1,18 @@
 """A static scene's cull cache (gcr_gaussians.cull_cache, include/gcr.h ABI v8) kept current for the Python API.
 
-GaussianCity's inference loop flies a camera through ONE generated city (scripts/inference.py:640-667: the point tensor
-is made once, the poses change): every frame's streaming cull reads the mean, the scales and the rotation of all of its
-Gaussians to reject the 95 % that are off screen.  With a cache -- (mean, rho) as one 16-byte record per Gaussian, rho =
-the camera-independent factor of the cull's screen bound, plus (scales, opacity, rotation) as one 32-byte record -- the
-cull streams 16 bytes per Gaussian instead of 40 (56 when the rows are [N,14]) and the few per cent that survive it fetch
-one 32-byte record instead of a 128-byte line of each of three arrays.  Every output is the same bits
-(tests/test_gpu_cull_cache.py); what changes is K1's time.
+When ONE set of Gaussians is rendered from many poses and most of it is off screen in each of them (BASELINE's C3 / C5
+workloads: 5 M / 20 M Gaussians of a city, 95 % culled per frame), every frame's streaming cull reads the mean, the
+scales and the rotation of all of them to reject that 95 %.  With a cache -- (mean, rho) as one 16-byte record per
+Gaussian, rho = the camera-independent factor of the cull's screen bound, plus (scales, opacity, rotation) as one 32-byte
+record -- the cull streams 16 bytes per Gaussian instead of 40 (56 when the rows are [N,14]) and the few per cent that
+survive it fetch one 32-byte record instead of a 128-byte line of each of three arrays.  Every output is the same bits
+(tests/test_gpu_cull_cache.py); what changes is K1's time (C3 73-79 -> 51-53 us).
+
+Where it does NOT pay.  GaussianCity's own inference loop (scripts/inference.py:208-263, 655-667) makes a NEW point tensor for
+every pose out of the points its visibility step found for that pose: nothing is static (the cache would be rebuilt per
+frame and steps aside), and everything is on screen.  Forced onto such a mostly-visible [N,14] set the cache costs bytes
+instead of saving them -- the stateless kernel reads each 56-byte row once, the cached one reads 16 + 32 bytes of cache
+AND the row for the colour: 9 565 -> 8 380 frames/s in bench.py --inference-loop (profiles/r05_bench_static_scene_other.jsonl).
 
 OFF by default -- the reference's API has no notion of a static scene, and the headline numbers are the stateless
 path's.  On: `gaussiancity_amd.cull_cache.enable(True)` (or GCR_STATIC_SCENE=1 in the environment, or

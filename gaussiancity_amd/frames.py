@@ -234,9 +234,11 @@ class InferenceLoop:
         """`render_uint8_fn(points, cam_pos, cam_quat) -> uint8 [H,W,3]` (optional): a renderer that produces the video
         frame itself (GaussianRasterizerWrapper(..., as_uint8=True): the blend kernel stores the bytes to_uint8_hwc would
         compute); used instead of render_fn + to_uint8_hwc when given.  `static_scene`: the frames of a run() share one
-        point tensor that nobody edits meanwhile (the reference's loop: one city, many poses) -- the rasterizer may keep
-        its cull cache for it (gaussiancity_amd/cull_cache.py: the same frames, the cull streams 16 instead of 56 bytes
-        per Gaussian).  Frames must be rendered under no_grad for it to apply."""
+        point tensor that nobody edits meanwhile AND most of it is off screen in every frame (a whole city's Gaussians
+        flown through; not the reference's own loop, which feeds each pose its visible points only) -- the rasterizer
+        may keep its cull cache for it (gaussiancity_amd/cull_cache.py: the same frames, the cull streams 16 instead of
+        56 bytes per Gaussian; slower than the stateless path when most points are visible).  Frames must be rendered
+        under no_grad for it to apply."""
         self.static_scene = bool(static_scene)
         self.render_fn = render_fn
         self.render_uint8_fn = render_uint8_fn

@@ -27,8 +27,8 @@
  * gcr_geometry_bytes/_image_bytes/ required<GeometryState|ImageState|BinningState>(n)
  *   _binning_bytes                 cr/rasterizer_impl.h:65-69
  * gcr_last_error                   the std::runtime_error text (cr/auxiliary.h:158-167)
- * gcr_build_cull_cache +           (no counterpart: optional) what a caller whose scene does not change between frames
- *   gcr_gaussians.cull_cache       (scripts/inference.py:640-667) may keep so that the per-Gaussian pass of the forward
+ * gcr_build_cull_cache +           (no counterpart: optional) what a caller who renders ONE mostly off-screen set of
+ *   gcr_gaussians.cull_cache       Gaussians from many poses may keep so that the per-Gaussian pass of the forward
  *                                  (cr/forward.cu:147-233) streams 16 instead of 40 bytes per Gaussian; same outputs
  *
  * Conventions shared with the reference: matrices are 16 floats in the row-vector layout the
@@ -142,15 +142,16 @@ typedef struct gcr_gaussians {
   int32_t stride_means3D, stride_opacities, stride_colors, stride_scales, stride_rotations;
   /* ABI v8, optional (NULL = none; forward calls only, the backward never reads it): the buffer gcr_build_cull_cache
    * filled from THESE means3D / scales / rotations (or cov3D_precomp) / opacities at the camera's scale_modifier;
-   * gcr_cull_cache_bytes(P) bytes, 128-byte aligned.  A scene that does not change between frames (a city that is only
-   * flown through, scripts/inference.py:640-667) is then culled from one 16-byte record per Gaussian instead of 40
+   * gcr_cull_cache_bytes(P) bytes, 128-byte aligned.  A set of Gaussians that does not change between frames and is
+   * mostly off screen in each of them (a whole city flown through) is then culled from one 16-byte record per Gaussian instead of 40
    * bytes out of three arrays (56 when the rows are [N,14]), and the few per cent that survive the cull fetch their
    * scales, rotation and opacity as one 32-byte record instead of a 128-byte line of each array.  Every output is the
    * same bits as without it: the cull takes the same decisions from the same numbers, it only ever skips Gaussians
    * whose exact projection has radius 0 (cr/forward.cu:147-233 decides everything else), and the records are copies.
    * The library cannot see whether the arrays still hold what the cache was built from -- a stale cache renders the
    * OLD positions, sizes and opacities of the culled / surviving Gaussians; keeping it current is the caller's job (the
-   * Python layer keys it on the tensors' versions).  Ignored under option "split_preprocess". */
+   * Python layer keys it on the tensors' versions).  It pays when most of the set is culled; a set that is mostly on
+   * screen renders faster without it (the candidates' records are extra bytes then).  Ignored under option "split_preprocess". */
   const void *cull_cache;
 } gcr_gaussians;
 
