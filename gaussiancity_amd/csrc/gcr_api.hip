@@ -165,7 +165,7 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   const size_t nblk = (p + 255) / 256;
   size_t o = 0;
   L->geom_rec = o;            o = align_up(o + p * sizeof(float4) * GCR_REC_QUADS);
-  L->geom_cov3D = o;          o = align_up(o + p * 6 * sizeof(float));
+  L->geom_cov3D = o;          o = align_up(o + p * GCR_COV3D_FLOATS * sizeof(float));
   L->geom_clamped = o;        o = align_up(o + p);
   L->geom_tiles_touched = o;  o = align_up(o + p * sizeof(uint32_t));
   L->geom_block_sums = o;     o = align_up(o + (nblk + 1) * sizeof(uint32_t));
@@ -396,7 +396,6 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
   a.radii = radii;
   a.rec = (float4*)(gb + L.geom_rec);
   a.cov3D = (float*)(gb + L.geom_cov3D);
-  a.clamped = (uint8_t*)(gb + L.geom_clamped);
   a.tile_count = (uint32_t*)(ib + L.img_tile_cursor);
   a.vis_list = (uint32_t*)(gb + L.geom_vis_list);
   a.vis_count = (uint32_t*)(gb + L.geom_vis_count);
@@ -1272,9 +1271,9 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   a.scale_modifier = cam->scale_modifier;
   a.means3D = g->means3D; a.scales = g->scales; a.rotations = g->rotations; a.shs = g->shs;
   a.cov3D = g->cov3D_precomp ? g->cov3D_precomp : (const float*)(gb + L.geom_cov3D);  // cr/rasterizer_impl.cu:329-330
+  a.s_cov3d = g->cov3D_precomp ? 6 : GCR_COV3D_FLOATS;
   a.view = cam->view_matrix; a.proj = cam->proj_matrix; a.campos = cam->campos;
   a.radii = radii;
-  a.clamped = (const uint8_t*)(gb + L.geom_clamped);
   a.vis_list = (const uint32_t*)(gb + L.geom_vis_list);
   a.vis_count = (const uint32_t*)(gb + L.geom_vis_count);
   a.nblocks = nblocks_k1; a.chunk = chunk_k1;

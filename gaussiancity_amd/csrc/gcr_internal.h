@@ -5,11 +5,17 @@
 
 #include "../../include/gcr.h"
 
-// One Gaussian's projected state, written by K1 and gathered by K3/K6/K7.  48 bytes, three
-// 16-byte quads so a staging thread issues three dwordx4 loads from (at most) two cache lines.
+// One Gaussian's projected state, written by K1 and gathered by K3/K6/K7/K8.  ONE 64-byte block, four 16-byte quads:
 //   q0 = (x, y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)
 //   q2 = (b, depth, rect_x, rect_y) with rect_* = min | max << 16 (tile units, as uint bits)
-#define GCR_REC_QUADS 3
+//   q3 = (clamp mask as uint bits -- bit ch: colour channel ch was clamped at 0, cr/forward.cu:68-73 --, 0, 0, 0)
+// Until round 5 the record was 48 bytes at a 48-byte stride with the clamp mask in a byte array of its own: K1 is bound
+// by its bytes, and a survivor's 48-byte store covered one 32-byte sector and half of another, its mask one byte of a
+// third -- partial sectors are read, merged and written back.  64-byte records are whole sectors for the writer and one
+// 64-byte block instead of one and a half for every gather.
+#define GCR_REC_QUADS 4
+// ... and its world-space covariance (K8 reads it back): six floats in a 32-byte slot, written as one whole sector
+#define GCR_COV3D_FLOATS 8
 
 // Per-tile atomic counters are padded to one per 128-byte line: device-scope atomics to the
 // same line serialise (measured: C2's 1120 unpadded counters made K1 4.6x slower).
@@ -31,7 +37,6 @@ struct GcrPreprocessArgs {
   int32_t* radii;
   float4* rec;
   float* cov3D;
-  uint8_t* clamped;
   uint32_t* tile_count;  // [T * GCR_CURSOR_STRIDE] per-tile instance counts (zeroed before K1)
   uint32_t* vis_list;    // [P] block b's survivors at [b*chunk, b*chunk + vis_count[b])
   uint32_t* vis_count;   // [nblocks]
@@ -80,7 +85,7 @@ struct GcrPreprocessBwdArgs {
   const float *means3D, *scales, *rotations, *shs, *cov3D;  // cov3D: precomp or geometry state
   const float *view, *proj, *campos;
   const int32_t* radii;
-  const uint8_t* clamped;
+  int s_cov3d;  // floats between two Gaussians' covariances: 6 for the caller's cov3D_precomp, GCR_COV3D_FLOATS for the state
   const uint32_t *vis_list, *vis_count;  // K1's per-block survivor lists
   int nblocks, chunk;
   const float4* grad_rec;  // K7's per-Gaussian accumulation records (GCR_GRAD_REC_FLOATS each)

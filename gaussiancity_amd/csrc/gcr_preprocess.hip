@@ -290,9 +290,10 @@ GCR_DEV bool phase_a1_exact(const GcrPreprocessArgs& a, const float (&vm)[16], c
   out.px = px; out.py = py; out.conx = conx; out.cony = cony; out.conz = conz; out.depth = p_view.z;
   out.rect_x = (uint32_t)minx | ((uint32_t)maxx << 16);
   out.rect_y = (uint32_t)miny | ((uint32_t)maxy << 16);
-  if (!PRECOMP_COV) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov3D[i];
+  if (!PRECOMP_COV) {  // one whole 32-byte sector (GCR_COV3D_FLOATS)
+    float4* __restrict__ cvo = reinterpret_cast<float4*>(a.cov3D + GCR_COV3D_FLOATS * (size_t)idx);
+    cvo[0] = make_float4(cov3D[0], cov3D[1], cov3D[2], cov3D[3]);
+    cvo[1] = make_float4(cov3D[4], cov3D[5], 0.0f, 0.0f);
   }
   return true;
 }
@@ -348,6 +349,7 @@ GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 me
                                 uint32_t list_pos, uint32_t* __restrict__ vis_list, float cached_opacity = 0.0f) {
   const float opacity = HAVE_OPACITY ? cached_opacity : a.opacities[(size_t)idx * a.s_opac];
   float cr, cg, cb;
+  uint32_t clamp_mask = 0u;
   if (a.colors_precomp == nullptr) {
     const float ox = mean.x - GCR_CAM(a, campos, a.campos, 0), oy = mean.y - GCR_CAM(a, campos, a.campos, 1),
                 oz = mean.z - GCR_CAM(a, campos, a.campos, 2);
@@ -389,7 +391,7 @@ GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 me
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) res[ch] = res[ch] + 0.5f;
-    a.clamped[idx] = (uint8_t)((res[0] < 0 ? 1 : 0) | (res[1] < 0 ? 2 : 0) | (res[2] < 0 ? 4 : 0));
+    clamp_mask = (res[0] < 0 ? 1u : 0u) | (res[1] < 0 ? 2u : 0u) | (res[2] < 0 ? 4u : 0u);
     cr = gcr_max(res[0], 0.0f);
     cg = gcr_max(res[1], 0.0f);
     cb = gcr_max(res[2], 0.0f);
@@ -403,6 +405,7 @@ GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 me
   rec[0] = make_float4(pr.px, pr.py, pr.conx, pr.cony);
   rec[1] = make_float4(pr.conz, opacity, cr, cg);
   rec[2] = make_float4(cb, pr.depth, __uint_as_float(pr.rect_x), __uint_as_float(pr.rect_y));
+  rec[3] = make_float4(__uint_as_float(clamp_mask), 0.0f, 0.0f, 0.0f);
   vis_list[list_pos] = (uint32_t)idx;
   // per-tile instance counts, global-cursor variant only (gcr_binning.hip explains why the
   // default path counts in LDS instead)
@@ -1006,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
   const V3 mean = {mp[0], mp[1], mp[2]};
   float cv[6];
 #pragma unroll
-  for (int i = 0; i < 6; i++) cv[i] = a.cov3D[6 * (size_t)idx + i];
+  for (int i = 0; i < 6; i++) cv[i] = a.cov3D[(size_t)a.s_cov3d * idx + i];
   float shv[48];  // SH coefficients [i][channel] (zeros beyond M)
   uint8_t cl = 0;
   if (a.shs != nullptr) {
@@ -1022,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
 #pragma unroll
       for (int q = 0; q < 48; q++) shv[q] = q < 3 * a.M ? shp[q] : 0.0f;
     }
-    cl = a.clamped[idx];
+    cl = (uint8_t)__float_as_uint(a.rec[(size_t)idx * GCR_REC_QUADS + 3].x);  // the clamp mask K1 left in the record
   }
   float4 rot = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   float scl[3] = {0.0f, 0.0f, 0.0f};

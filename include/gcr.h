@@ -200,10 +200,11 @@ typedef struct gcr_grads {
  * that tests can compare intermediate state with the oracle; not needed by normal callers. */
 typedef struct gcr_layout {
   /* geometry buffer (per Gaussian) */
-  size_t geom_rec;           /* float[12] per Gaussian: x,y,conic.x,conic.y | conic.z,opacity,
-                                r,g | b,depth,rect_x(min|max<<16),rect_y(min|max<<16) */
-  size_t geom_cov3D;         /* float[6] per Gaussian */
-  size_t geom_clamped;       /* uint8 bitmask per Gaussian (bit ch set = channel clamped) */
+  size_t geom_rec;           /* float[16] per Gaussian, one 64-byte block (ABI v8; 12 floats at a 48-byte stride before):
+                                x,y,conic.x,conic.y | conic.z,opacity,r,g | b,depth,rect_x(min|max<<16),rect_y(min|max<<16) |
+                                clamp mask as uint32 (bit ch set = colour channel ch clamped), 0, 0, 0 */
+  size_t geom_cov3D;         /* float[6] per Gaussian in a 32-byte slot (ABI v8: stride 8 floats, the last two are 0) */
+  size_t geom_clamped;       /* unused since ABI v8 (the mask lives in the record's fourth quad); P bytes are still carved */
   size_t geom_tiles_touched; /* uint32 per Gaussian   (radix fallback path only) */
   size_t geom_block_sums;    /* uint32 per 256-Gaussian block (radix fallback path only) */
   size_t geom_vis_list;      /* uint32 per Gaussian: K1 block b's survivors, packed at b*chunk */

@@ -49,15 +49,15 @@ def decode(P, W, H, out):
     R, color, radii, geom, binning, img = out
     L = N.get_layout(P, W, H, R)
     gb, bb, ib = geom.cpu().numpy(), binning.cpu().numpy(), img.cpu().numpy()
-    rec = gb[L.geom_rec:L.geom_rec + P * 48].view(np.float32).reshape(P, 12)
+    rec = gb[L.geom_rec:L.geom_rec + P * 64].view(np.float32).reshape(P, 16)   # 64-byte records (ABI v8)
     T = ((W + 15) // 16) * ((H + 15) // 16)
     d = dict(
         R=R, out_color=color.cpu().numpy(), radii=radii.cpu().numpy(),
         means2D=rec[:, 0:2], conic_opacity=np.concatenate([rec[:, 2:5], rec[:, 5:6]], 1),
         rgb=rec[:, 6:9], depths=rec[:, 9],
         rect=rec[:, 10:12].copy().view(np.uint32),   # (min | max << 16) in x and y, tile units
-        cov3D=gb[L.geom_cov3D:L.geom_cov3D + P * 24].view(np.float32).reshape(P, 6),
-        clamped=gb[L.geom_clamped:L.geom_clamped + P],
+        cov3D=gb[L.geom_cov3D:L.geom_cov3D + P * 32].view(np.float32).reshape(P, 8)[:, :6],   # 32-byte slots
+        clamped=rec[:, 12].copy().view(np.uint32).astype(np.uint8),   # the record's fourth quad carries the clamp mask
         final_T=ib[L.img_final_T:L.img_final_T + 4 * W * H].view(np.float32),
         n_contrib=ib[L.img_n_contrib:L.img_n_contrib + 4 * W * H].view(np.uint32),
         ranges=ib[L.img_ranges:L.img_ranges + 8 * T].view(np.uint32).reshape(T, 2),

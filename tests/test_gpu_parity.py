@@ -622,7 +622,7 @@ def test_full_size_properties(cuda_device):
         tile_of = torch.repeat_interleave(order_t, lens_t[order_t])   # tile of every list position
         final = torch.arange(R, device=plist.device) - torch.from_numpy(ranges[:, 0]).to(plist.device)[tile_of] < ns[tile_of]
         plist = torch.where(final, plist, plist[0])
-    depth = geom[L.geom_rec:L.geom_rec + P * 48].view(torch.float32).view(P, 12)[:, 9]
+    depth = geom[L.geom_rec:L.geom_rec + P * 64].view(torch.float32).view(P, 16)[:, 9]
     dkey = depth[plist].view(torch.int32).long()  # positive floats: the bit pattern orders like the value
     key = (dkey << 32) | plist
     seg_start = torch.zeros(R, dtype=torch.bool, device=key.device)

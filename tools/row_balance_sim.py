@@ -90,7 +90,7 @@ for cname in sys.argv[1:] or ('C3', 'C2'):
     assert frame[3] != 0, 'forward left no state'
     masks = binning[mask_off:mask_off + 2 * R].view(torch.int16).cpu().numpy().view(np.uint16)
     ids = binning[0:4 * R].view(torch.int32).cpu().numpy()
-    rec = geom[L.geom_rec:L.geom_rec + 48 * P].view(torch.float32).view(P, 12).cpu().numpy()
+    rec = geom[L.geom_rec:L.geom_rec + 64 * P].view(torch.float32).view(P, 16).cpu().numpy()
     ranges = img[L.img_ranges:L.img_ranges + 8 * T].view(torch.int32).view(T, 2).cpu().numpy()
     nc = img[L.img_n_contrib:L.img_n_contrib + 4 * W * H].view(torch.int32).view(H, W).cpu().numpy()
     ncp = np.zeros((gy * 16, gx * 16), np.int64)
