@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
 //       culls and appends everything else to the block's candidate list.  39 us.
 //   K1b k_preprocess_project (one candidate per thread, dense): phase A1 -- the reference's exact
 //       arithmetic (gcr-fp32-v1) takes EVERY decision (det == 0, radius, tile rect, area == 0) --
-//       then phase B: SH -> RGB, the 48-byte record, clamp mask, and the compacted visible list
+//       then phase B: SH -> RGB, the 64-byte record (clamp mask in its fourth quad), and the compacted visible list
 //       that the binning kernels and the backward preprocess iterate.
 // A0 only ever skips Gaussians whose exact result is radius 0 / no tiles, so outputs are unchanged.
 struct PhaseAIn {
