@@ -40,7 +40,7 @@ def test_scratch_sizes_and_layout():
     lib = N.lib()
     assert lib.gcr_geometry_bytes(0) >= 0
     g1, g2 = lib.gcr_geometry_bytes(1000), lib.gcr_geometry_bytes(2000)
-    assert 1000 * (48 + 24 + 1 + 4) <= g1 < g2
+    assert 1000 * (64 + 32 + 4) <= g1 < g2   # 64-byte records, 32-byte covariance slots, survivor list (ABI v8)
     assert lib.gcr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 8
     b0, b1 = lib.gcr_binning_bytes(0, 640, 448), lib.gcr_binning_bytes(1_000_000, 640, 448)
     assert b1 >= 1_000_000 * 24 and b0 < b1
@@ -48,6 +48,7 @@ def test_scratch_sizes_and_layout():
     offs = [L.geom_rec, L.geom_cov3D, L.geom_clamped, L.geom_tiles_touched, L.geom_block_sums,
             L.geom_num_rendered, L.geom_total]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    assert L.geom_cov3D - L.geom_rec >= 5000 * 64 and L.geom_clamped - L.geom_cov3D >= 5000 * 32   # whole sectors per Gaussian
     assert L.geom_total == lib.gcr_geometry_bytes(5000)
     assert L.img_total == lib.gcr_image_bytes(640, 448) and L.img_ranges < L.img_tile_cursor < L.img_total
     assert L.bin_total == lib.gcr_binning_bytes(123456, 640, 448)
