@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--float-frames", action="store_true",
                     help="--inference-loop: render float images and convert them to uint8 frames with torch kernels, as "
                          "scripts/inference.py does (default: the blend kernel stores the uint8 frame, same bytes)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B only: a library option by name (gcr_set_option), e.g. --opt pipeline=0 --opt blend_lds_pad=4096; "
+                         "the line's config.options lists what was set")
     ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the frame loop alternates over (frames are independent; 1 = serial); "
                          "default 3 (measured optimum for both paths: C3 forward 4 520 / 4 700 / 4 690 frames/s "
@@ -218,6 +221,10 @@ def main():
     N.set_option("split_preprocess", 1 if args.split_preprocess else 0)
     N.set_option("sort_in_blend", 1 if args.sort_in_blend else 0)
     N.set_option("lazy_sort", 0 if args.sort_whole else 1)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        if N.set_option(name, int(val)) == -1 and N.get_option(name) != int(val):
+            raise SystemExit("unknown library option %r" % name)
     if args.static_scene:
         from gaussiancity_amd import cull_cache
         cull_cache.enable(True)
@@ -584,7 +591,8 @@ def main():
                                     "lists beyond 1024 entries sorted lazily, as far as the blend walks (default)",
                        "cull": ("STATIC SCENE (--static-scene): a second line, not the headline -- the cull streams a cached "
                                 "16-byte (mean, bound) record per Gaussian built once for the scene; same frames bit for bit")
-                               if args.static_scene else "stateless: every frame reads means, scales, rotations (default)"},
+                               if args.static_scene else "stateless: every frame reads means, scales, rotations (default)",
+                       "options_set_on_the_command_line": list(args.opt)},
             "frame_stats": {"num_rendered": R_mean, "consumed_entries_Rp": Rp_mean, "visible": Pv_mean,
                             "tiles": T_tiles, "entries_per_tile": round(R_mean / T_tiles, 1),
                             "ns_per_instance": round(1e9 * elapsed / args.steps / max(R_mean, 1.0), 4)},
