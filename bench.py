@@ -116,6 +116,10 @@ def main():
     ap.add_argument("--float-frames", action="store_true",
                     help="--inference-loop: render float images and convert them to uint8 frames with torch kernels, as "
                          "scripts/inference.py does (default: the blend kernel stores the uint8 frame, same bytes)")
+    ap.add_argument("--d-step", action="store_true",
+                    help="--train-step: the step WITH the discriminator's half (core/train.py:227-257): a forward-only render "
+                         "under no_grad, an 18 262 793-parameter discriminator stand-in under DDP (73.1 MB all-reduce), then "
+                         "the G-step with the GAN term -- the reference's step when DISCRIMINATOR.ENABLED")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B only: a library option by name (gcr_set_option), e.g. --opt pipeline=0 --opt blend_lds_pad=4096; "
                          "the line's config.options lists what was set")
@@ -1106,6 +1110,7 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
     node on the [N,14] tensor), render 960x540, crop 640x448, L1 loss, backward (core/train.py:263-295).  One frame per
     rank per step; the DDP all-reduce is the path's only collective.  No optimizer step (not part of SURVEY's C4)."""
     from gaussiancity_amd import helpers
+    from gaussiancity_amd import frames as frames_mod
     from gaussiancity_amd.frames import DDPTrainStep, StandInGenerator, allreduce_gradients
     cfg, sc = synth.make_scene("C4", args.points)
     W, H = cfg["W"], cfg["H"]
@@ -1119,7 +1124,9 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
     crop = ((W - cw) // 2, (H - ch) // 2, cw, ch)
     gen = StandInGenerator(device=dev)
     n_param = sum(p.numel() for p in gen.parameters())
-    h = DDPTrainStep(wr, gen, crop=crop)
+    dis = frames_mod.StandInDiscriminator(device=dev) if args.d_step else None
+    n_param_d = sum(p.numel() for p in dis.parameters()) if dis is not None else 0
+    h = DDPTrainStep(wr, gen, crop=crop, discriminator=dis)
     poses = synth.orbit_poses()
 
     def step(i):
@@ -1210,20 +1217,23 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
     raster_ms = sum(st.values())
 
     # ---- the collective alone, same bytes, the in-place bucketed exchange of frames.allreduce_gradients
-    ar_ms, n_msg, flat = None, None, None
+    ar_ms, n_msg, flat, ar_d_ms = None, None, None, None
     if world > 1:
-        flat = torch.zeros(n_param, dtype=torch.float32, device=dev)
-        for _ in range(2):
-            allreduce_gradients([flat])
-        barrier()
-        t2 = time.perf_counter()
-        for _ in range(5):
-            n_msg = allreduce_gradients([flat])
-        barrier()
-        ar_ms = 1e3 * (time.perf_counter() - t2) / 5
-        tt = torch.tensor([elapsed, ar_ms, leg_s], dtype=torch.float64, device=dev)
+        def time_allreduce(n):
+            buf = torch.zeros(n, dtype=torch.float32, device=dev)
+            for _ in range(2):
+                allreduce_gradients([buf])
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(5):
+                msgs = allreduce_gradients([buf])
+            barrier()
+            return 1e3 * (time.perf_counter() - t2) / 5, msgs
+        ar_ms, n_msg = time_allreduce(n_param)
+        ar_d_ms = time_allreduce(n_param_d)[0] if n_param_d else 0.0  # the discriminator's message set (--d-step)
+        tt = torch.tensor([elapsed, ar_ms, leg_s, ar_d_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, ar_ms, leg_s = float(tt[0].item()), float(tt[1].item()), float(tt[2].item())
+        elapsed, ar_ms, leg_s, ar_d_ms = (float(tt[k].item()) for k in range(4))
     ranks_info = args.collect_ranks()
     if rank == 0:
         nbytes = n_param * 4
@@ -1258,6 +1268,13 @@ def train_step_bench(args, torch, dist, N, synth, Wrapper, dev, world, rank, bar
                                                "default on a GPU: bit-equal to the golden camera)"}[args.host_camera]},
             "allreduce_ms": round(ar_ms, 4) if ar_ms else None, "allreduce_bytes": nbytes,
             "allreduce_messages": n_msg, "allreduce_bus_GBps": round(bus, 1) if bus else None,
+            "d_step": ({"what": "the step includes the discriminator's half (core/train.py:227-257): a forward-only render of "
+                                "the frame under no_grad, the discriminator stand-in on fake and real image under DDP, its "
+                                "backward and all-reduce; the G-step carries the GAN term",
+                        "discriminator_parameters": n_param_d, "allreduce_bytes": 4 * n_param_d,
+                        "allreduce_ms": round(ar_d_ms, 4) if ar_d_ms else None,
+                        "allreduce_bus_GBps": (round((2.0 * (world - 1) / world) * 4 * n_param_d / 1e9 / (ar_d_ms / 1e3), 1)
+                                               if ar_d_ms else None)} if args.d_step else None),
             "rccl": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_DEBUG") if os.environ.get(k)} or None,
             "expected_allreduce": {"bytes": nbytes, "ring_ms_estimate": 3.2, "direct_all_links_ms_estimate": 0.46,
                                    "note": "SURVEY.md section 5: 279 MB fp32 over xGMI, 7 links x ~153 GB/s per GPU; a ring "

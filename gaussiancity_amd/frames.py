@@ -181,40 +181,105 @@ class StandInGenerator(torch.nn.Module):
         return x
 
 
+class StandInDiscriminator(torch.nn.Module):
+    """A parameter set with the discriminator's size (18,262,793 fp32 values = 73.1 MB) behind
+    the rasterizer: one scalar "label" per image from the image mean and the first two parameters; every other parameter
+    gets a dense zero gradient (p.sum() * 0), so DistributedDataParallel all-reduces the real message size.  As with
+    StandInGenerator: the message sizes and the place of the module in the step, none of its arithmetic (the
+    discriminator is a plain torch module that runs unchanged on ROCm)."""
+
+    def __init__(self, n_param=18_262_793, device=None):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(max(2, int(n_param)), dtype=torch.float32, device=device))
+
+    def forward(self, img):
+        return img.mean() * (1.0 + self.p[0]) + self.p[1] + self.p.sum() * 0.0
+
+
 class DDPTrainStep:
-    """The reference's G-step (core/train.py:263-295) with its real data-parallel wiring (core/train.py:78-87): the
+    """The reference's training step (core/train.py:227-295) with its real data-parallel wiring (core/train.py:78-87): the
     generator stand-in is wrapped in torch's DistributedDataParallel(find_unused_parameters=True), so the gradient
     buckets are all-reduced over RCCL/xGMI WHILE the backward is still running (autograd hooks), exactly as the
     reference's DDP does -- not in a separate pass after loss.backward() as TrainStepHarness does.  One frame per
     rank per step through helpers.get_gaussian_rasterization (wrapper -> one autograd node on the [N,14] tensor).
-    Buckets of `bucket_cap_mb` (default 64): few large messages, a ring all-reduce over xGMI is per-link bound."""
+    Buckets of `bucket_cap_mb` (default 64): few large messages, a ring all-reduce over xGMI is per-link bound.
 
-    def __init__(self, rasterizer_wrapper, generator, crop=None, lr=None, group=None, bucket_cap_mb=64):
+    `discriminator` (optional, round 6): the D-step in front of the G-step as the reference runs it when
+    cfg.TRAIN.GAUSSIAN.DISCRIMINATOR.ENABLED (core/train.py:227-257) -- a forward-only render of the same frame under
+    no_grad (the rasterizer then writes no backward state), the discriminator on the fake and on the real image, its
+    backward with the 73.1 MB all-reduce of ITS gradients, its optimizer step; the G-step then adds the GAN term to its
+    loss with the discriminator frozen (:260-283).  Without it the step is the G-step alone (round 1-5 behaviour)."""
+
+    discriminator = dnet = opt_d = last_d_loss = None  # (the G-step-only object of rounds 1-5)
+
+    def __init__(self, rasterizer_wrapper, generator, crop=None, lr=None, group=None, bucket_cap_mb=64, discriminator=None):
         self.rw = rasterizer_wrapper
         self.crop = crop
         self.generator = generator
         self.net = generator
+        self.discriminator = discriminator
+        self.dnet = discriminator
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             first = next(generator.parameters())
             self.net = torch.nn.parallel.DistributedDataParallel(
                 generator, device_ids=[first.device.index] if first.is_cuda else None, process_group=group,
                 find_unused_parameters=True, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+            if discriminator is not None:
+                dfirst = next(discriminator.parameters())
+                self.dnet = torch.nn.parallel.DistributedDataParallel(
+                    discriminator, device_ids=[dfirst.device.index] if dfirst.is_cuda else None, process_group=group,
+                    find_unused_parameters=True, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
         # cfg.TRAIN.GAUSSIAN optimizer (core/train.py:293-295); None = the step ends with the reduced gradients
         self.opt = (torch.optim.Adam(generator.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-7)
                     if lr is not None else None)
+        self.opt_d = (torch.optim.Adam(discriminator.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-7)
+                      if (lr is not None and discriminator is not None) else None)
+        self.last_d_loss = None
 
-    def step(self, base_points, cam_pos, cam_quat, target=None):
-        """base_points: [N,14] (no gradient needed).  Returns (loss, image)."""
+    def _render(self, pts, cam_pos, cam_quat):
         from . import helpers
-        for p in self.generator.parameters():
-            p.grad = None
-        pts = self.net(base_points)
         box = None
         if self.crop is not None:
             x, y, w, h = self.crop
             box = [{"x": x, "y": y, "w": w, "h": h}]
-        img = helpers.get_gaussian_rasterization(pts[None], self.rw, [cam_pos], [cam_quat], crop_bboxes=box)[0]
+        return helpers.get_gaussian_rasterization(pts[None], self.rw, [cam_pos], [cam_quat], crop_bboxes=box)[0]
+
+    @staticmethod
+    def _requires_grad(module, flag):  # utils/helpers.requires_grad
+        for p in module.parameters():
+            p.requires_grad_(flag)
+
+    def d_step(self, base_points, cam_pos, cam_quat, target=None):
+        """core/train.py:227-257.  Returns the discriminator loss (detached)."""
+        self._requires_grad(self.generator, False)
+        self._requires_grad(self.discriminator, True)
+        with torch.no_grad():  # the forward-only render: an inference frame for the rasterizer
+            fake = self._render(self.net(base_points), cam_pos, cam_quat).detach()
+        real = target if target is not None else torch.zeros_like(fake)
+        fake_label, real_label = self.dnet(fake), self.dnet(real)
+        # hinge stand-ins for gan_loss(fake, False, dis_update=True) + gan_loss(real, True, dis_update=True)
+        loss_d = torch.relu(1.0 + fake_label) + torch.relu(1.0 - real_label)
+        for p in self.discriminator.parameters():
+            p.grad = None
+        loss_d.backward()  # DDP: the discriminator's 73.1 MB of gradients are all-reduced here
+        if self.opt_d is not None:
+            self.opt_d.step()
+        self._requires_grad(self.discriminator, False)
+        self._requires_grad(self.generator, True)
+        self.last_d_loss = loss_d.detach()
+        return self.last_d_loss
+
+    def step(self, base_points, cam_pos, cam_quat, target=None):
+        """base_points: [N,14] (no gradient needed).  Returns (loss, image)."""
+        if self.discriminator is not None:
+            self.d_step(base_points, cam_pos, cam_quat, target)
+        for p in self.generator.parameters():
+            p.grad = None
+        pts = self.net(base_points)
+        img = self._render(pts, cam_pos, cam_quat)
         loss = (img - target).abs().mean() if target is not None else img.abs().mean()
+        if self.discriminator is not None:  # the GAN term, discriminator frozen (core/train.py:274-283)
+            loss = loss + 0.5 * torch.relu(1.0 - self.discriminator(img))
         loss.backward()
         if self.opt is not None:
             self.opt.step()

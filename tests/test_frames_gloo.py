@@ -175,6 +175,63 @@ def test_ddp_train_step_world2_gloo():
         assert ok and dense and is_ddp and tuple(shape) == (3, 3, 4), (rank, ok, dense, is_ddp, shape)
 
 
+def _ddp_d_step_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        gen = frames.StandInGenerator(n_param=2 * 3000, n_layers=2)
+        dis = frames.StandInDiscriminator(n_param=7001)
+        with torch.no_grad():
+            dis.p[0], dis.p[1] = 0.25, -0.1
+        calls = []
+
+        class _Spy(_FakeWrapper):  # records whether a render ran under no_grad (the D-step's forward-only frame)
+            def __call__(self, points, cam_pos, cam_quat):
+                calls.append(torch.is_grad_enabled())
+                return super().__call__(points, cam_pos, cam_quat)
+
+        step = frames.DDPTrainStep(_Spy(), gen, crop=(0, 0, 4, 3), bucket_cap_mb=0.01, discriminator=dis)
+        base = torch.linspace(-1, 1, 50 * 14).view(50, 14) * (rank + 1)
+        pose, quat, target = np.array([1.0 + rank, 2.0, 3.0]), np.array([0, 0, 0, 1.0]), torch.full((3, 3, 4), 0.3)
+        loss, img = step.step(base, pose, quat, target)
+        d_grad = dis.p.grad.clone()
+        # the same D-step without DDP on both ranks' data: the rank-averaged gradient
+        want = torch.zeros_like(dis.p)
+        for r in range(world):
+            d2 = frames.StandInDiscriminator(n_param=7001)
+            d2.load_state_dict(dis.state_dict())
+            g2 = frames.StandInGenerator(n_param=2 * 3000, n_layers=2)
+            s2 = frames.DDPTrainStep(_FakeWrapper(), g2, crop=(0, 0, 4, 3), discriminator=d2)
+            s2.net, s2.dnet = g2, d2  # (no DDP wrapper: a single-process reference of rank r's frame)
+            s2.d_step(torch.linspace(-1, 1, 50 * 14).view(50, 14) * (r + 1), np.array([1.0 + r, 2.0, 3.0]), quat, target)
+            want += d2.p.grad / world
+        q.put((rank, bool(torch.allclose(d_grad, want, rtol=1e-5, atol=1e-7)), float(d_grad[:2].abs().max()) > 0,
+               tuple(d_grad.shape) == (7001,), calls, isinstance(step.dnet, torch.nn.parallel.DistributedDataParallel),
+               all(p.grad is not None for p in gen.parameters()), float(step.last_d_loss)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_train_step_with_discriminator_world2_gloo():
+    """The C4 step as the reference runs it with the discriminator enabled (core/train.py:227-295): D-step = a forward-only
+    render under no_grad + the discriminator's backward with its own DDP all-reduce (73.1 MB at full size), then the G-step
+    with the GAN term.  World 2 over gloo: the discriminator's gradients come out rank-averaged and dense, the first render
+    of the step ran without autograd, the second with it, and the generator still gets its gradients."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_d_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, nonzero, dense, calls, is_ddp, gen_grads, d_loss in res:
+        assert ok and nonzero and dense and is_ddp and gen_grads and d_loss > 0, (rank, ok, nonzero, dense, is_ddp, gen_grads, d_loss)
+        assert calls == [False, True], calls
+
+
 def test_rank_affinity_from_sysfs(tmp_path, monkeypatch):
     """gaussiancity_amd.affinity (counterpart of utils/distributed.py:19-62): cpulist parsing, the sysfs lookup on a fake
     tree, the binding restricted to the process's own mask, and the no-GPU fallbacks."""

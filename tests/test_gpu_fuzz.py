@@ -65,44 +65,40 @@ def test_deterministic_records_hold_a_large_footprint(oracle_mod, cuda_device):
 
 def test_recorded_exceedances_are_rounding_noise(oracle_mod, cuda_device):
     """tests/golden/fuzz_exceedances.json: the cases of the randomised sweep whose gradients ever went beyond their tier
-    (three in rounds 3-4; four in round 5's own sweep).  Each is held here to the bar the file states:
-    per gradient tensor the GPU -- both backward blend kernels -- is no farther from the binary32 oracle than max(its tier,
-    8 x the distance of that oracle from the SAME statements evaluated in binary64) (oracle.Frame64, recomputed here:
-    seconds per case; largest ratio observed 6.4).  The forward stays bit-exact."""
+    (three in rounds 3-4; four in round 5's own sweep).  Two bars per gradient tensor, both backward blend
+    kernels, forward bit-exact:
+
+    * attribution (round 5): the GPU is no farther from the binary32 oracle than max(its tier, 8 x the distance of that oracle
+      from the SAME statements evaluated in binary64) (oracle.Frame64, recomputed here; largest ratio observed 6.4);
+    * no regression against the NORTH-STAR bar (round 6): ratio = |GPU - oracle32| / (tier * max(1,
+      max|oracle32|)) may not exceed max(1, 1.1 x the worst ratio on record for that case, kernel and tensor) --
+      `ratio_to_tier` in the file, the worst of 64 backward passes each (tools/fuzz_exceedance_ratios.py; the float atomics'
+      order moves the difference from run to run, hence the worst of many).  A tensor inside its tier stays inside or within
+      10 % of its recorded worst; one that exceeds it may not get more than 10 % worse."""
     import json
 
+    import fuzz_exceedance_ratios as R
     import fuzz_parity as F
     import gpu_util as G
     import scenes
-    import torch
     from gaussiancity_amd import ext
-    here = os.path.dirname(os.path.abspath(__file__))
-    doc = json.load(open(os.path.join(here, "golden", "fuzz_exceedances.json")))
+    doc = json.load(open(R.GOLDEN))
     assert len(doc["cases"]) >= 7
+    seen_worst = 0.0
     for rec in doc["cases"]:
         c = rec["desc"]
-        rs = scenes.camera(c["W"], c["H"], pose_index=c["pose"], radius=c["radius"], altitude=c["altitude"])
-        rs = rs._replace(sh_degree=c["deg"], bg=torch.tensor(c["bg"], dtype=torch.float32), scale_modifier=c["scale_modifier"])
-        sc = scenes.blob_scene(c["P"], c["seed"], c["deg"], spread=c["spread"], smin=c["smin"], smax=c["smax"],
-                               omin=c["omin"], omax=c["omax"])
-        kw = scenes.settings_kwargs(rs)
-        extra = dict(shs=sc["shs"]) if c["use_sh"] else dict(colors_precomp=sc["colors_precomp"])
-        kw.update(means3D=sc["means3D"], opacities=sc["opacities"], scales=sc["scales"], rotations=sc["rotations"], **extra)
+        rs, sc, kw, dpix, names, tier = R.build_case(c, oracle_mod, scenes)
         f32, f64 = oracle_mod.Frame(**kw), oracle_mod.Frame64(**kw)
-        dpix = np.random.default_rng(c["seed"] + 5).normal(size=(3, c["H"], c["W"])).astype(np.float32)
         g32, g64 = f32.backward(dpix), f64.backward(dpix)
-        tier = F.gradient_tolerance(c)
         assert tier == rec["tier"]
-        names = [n for n in F.GRADS if not (n == "dL_dsh" and not c["use_sh"]) and not (n == "dL_dcolor" and c["use_sh"])]
-        for wave_units in (0, 1):
-            with ext.options(bwd_wave_units=wave_units, bwd_piece=min(c["piece"], 223), lazy_sort=c["lazy"],
-                             split_preprocess=c["split_preprocess"]):
-                args, out = G.run_forward(rs, sc, cuda_device, use_sh=c["use_sh"], for_backward=True)
-                assert np.array_equal(out[1].cpu().numpy().view(np.uint32), f32.out_color.view(np.uint32)), rec["case"]
-                gg = G.run_backward(args, out, dpix, cuda_device)
-            for n in names:
-                got = gg[n].reshape(g32[n].shape)
-                err = float(np.abs(got - g32[n]).max())
-                noise = float(np.abs(g32[n] - g64[n]).max())
-                bar = max(tier * max(1.0, float(np.abs(g32[n]).max())), 8.0 * noise)
-                assert err <= bar, (rec["case"], wave_units, n, err, bar)
+        for wave_units, key in ((0, "workgroup_per_item"), (1, "wave_per_item_quadrant")):
+            recorded = rec["ratio_to_tier"][key]
+            for _ in range(2):
+                ratio = R.ratios_of_one_run(c, rs, sc, dpix, names, tier, g32, f32, wave_units, G, ext, cuda_device)
+                for n in names:
+                    scale = tier * max(1.0, float(np.abs(g32[n]).max()))
+                    noise = float(np.abs(g32[n] - g64[n]).max())
+                    assert ratio[n] * scale <= max(scale, 8.0 * noise), (rec["case"], key, n, ratio[n], noise / scale)
+                    assert ratio[n] <= max(1.0, 1.1 * recorded[n]), (rec["case"], key, n, ratio[n], recorded[n])
+                    seen_worst = max(seen_worst, ratio[n])
+    assert seen_worst <= 1.1 * doc["worst_ratio_to_tier"]
