@@ -785,6 +785,8 @@ class RescueService {
   size_t scratch_bytes_[64] = {};
   std::atomic<long> rescued_{0};
   std::atomic<long> dropped_{0};  // calls for help that came too late (the gate had given up)
+  const unsigned long long* rescuing_ = nullptr;  // (mu_) words of the frame rescue() is working on: already off frames_,
+  std::condition_variable idle_cv_;               //   still written to -- forget() waits for it
 
   static void publish(unsigned long long* w, int idx, unsigned int seq) {
     std::atomic_thread_fence(std::memory_order_seq_cst);
@@ -884,9 +886,12 @@ class RescueService {
           if (!hold && (unsigned int)w[3] == it->seq) {  // the gate is holding the stream: every kernel of the frame is done
             AsyncFrame f = *it;
             frames_.erase(it);
+            rescuing_ = f.words;
             lk.unlock();
             rescue(f);
             lk.lock();
+            rescuing_ = nullptr;
+            idle_cv_.notify_all();
             break;  // iterators are gone: rescan on the next round
           }
         }
@@ -916,8 +921,11 @@ class RescueService {
     if (was_empty) cv_.notify_one();  // (with frames outstanding the thread is polling, not waiting)
   }
   void forget(const unsigned long long* base, size_t n) {  // gcr_host_words_free: these words are about to be unmapped
-    std::lock_guard<std::mutex> lk(mu_);
+    std::unique_lock<std::mutex> lk(mu_);
     for (auto it = frames_.begin(); it != frames_.end();) it = (it->words >= base && it->words < base + n) ? frames_.erase(it) : it + 1;
+    // a frame that was handed to rescue() before this call is off the list but its words are still being written
+    // (words 7 / 5 / 6 / 2): the caller may not unmap them under the rescue thread
+    idle_cv_.wait(lk, [&] { return !(rescuing_ != nullptr && rescuing_ >= base && rescuing_ < base + n); });
   }
   void remove(const unsigned long long* words, unsigned int seq) {  // a frame whose enqueue failed after add()
     std::lock_guard<std::mutex> lk(mu_);
@@ -932,6 +940,8 @@ class RescueService {
   void reset_after_fork() {
     new (&mu_) std::mutex();
     new (&cv_) std::condition_variable();
+    new (&idle_cv_) std::condition_variable();
+    rescuing_ = nullptr;
     new (&frames_) std::deque<AsyncFrame>();
     started_ = false;
     for (int i = 0; i < 64; i++) {

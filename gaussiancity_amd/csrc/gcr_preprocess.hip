@@ -1068,9 +1068,13 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
   const float con_x = pr0.z, con_y = pr0.w, con_z = pr1.x, opac = pr1.y;
   const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
   const float hop = -0.5f * opac;
-  const float dcx = hop * g1.z, dcy = hop * g1.w, dcz = hop * g2.x;
-  const float dm2x = -(opac * ddelx_dx) * (con_x * g1.x + con_y * g1.y);
-  const float dm2y = -(opac * ddely_dy) * (con_z * g1.y + con_y * g1.x);
+  // A Gaussian no pixel consumed has five exact zeros here, and upstream -- which adds per-pixel terms and has none to add --
+  // leaves its gradients 0 whatever its record holds: the factors are skipped, so that a non-finite opacity or conic of
+  // such a Gaussian does not turn 0 into NaN.  (A NaN moment compares unequal to 0: it goes through.)
+  const bool no_moment = g1.x == 0.0f && g1.y == 0.0f && g1.z == 0.0f && g1.w == 0.0f && g2.x == 0.0f;
+  const float dcx = no_moment ? 0.0f : hop * g1.z, dcy = no_moment ? 0.0f : hop * g1.w, dcz = no_moment ? 0.0f : hop * g2.x;
+  const float dm2x = no_moment ? 0.0f : -(opac * ddelx_dx) * (con_x * g1.x + con_y * g1.y);
+  const float dm2y = no_moment ? 0.0f : -(opac * ddely_dy) * (con_z * g1.y + con_y * g1.x);
   a.dL_dmean2D[3 * (size_t)idx] = dm2x;
   a.dL_dmean2D[3 * (size_t)idx + 1] = dm2y;
   a.dL_dcolor[(size_t)idx * a.g_col] = g0.x;

@@ -25,7 +25,12 @@ exists, and any in-place edit through torch (which bumps `_version`) misses the 
 counter does not see are not detected -- a raw kernel scribbling into the storage, an in-place operation on `tensor.data`
 (which carries a version counter of its own): call invalidate() after such a write.  Tensors without a version counter
 (inference-mode tensors) are never cached.  A scene whose tensors are new objects with new storage every frame is
-rebuilt every frame; after eight such frames in a row the cache steps aside until invalidate().
+rebuilt every frame; after eight such frames in a row FROM ONE HOST THREAD the cache steps aside for that thread until
+invalidate() (the counter is per thread: one caller whose scene is not static does not switch the cache off for the others).
+
+Lifetime across streams.  A cache buffer is read by frames on whatever stream the caller renders on; every use marks
+the buffer for that stream (`Tensor.record_stream`), so when an entry is dropped the allocator itself holds the block
+back until those streams have passed the frames that read it -- no device-wide wait, nothing is held under the lock.
 
 Memory: 48 bytes per Gaussian per cached scene (240 MB at 5 M, 960 MB at 20 M), at most two scenes, plus the scene's own
 tensors, which an entry keeps alive.
@@ -45,8 +50,8 @@ _entries = collections.OrderedDict()  # key -> (cache buffer, uint8 [gcr_cull_ca
 _CACHE_BYTES_HOOK = None  # tests without the library: fn(P) -> bytes
 _lock = threading.Lock()
 stats = {"hits": 0, "builds": 0, "uncacheable": 0, "thrashing": 0}
-_THRASH_LIMIT = 8  # that many builds in a row without a hit: the caller's scene is not static; stop until invalidate()
-_builds_in_a_row = 0
+_THRASH_LIMIT = 8  # that many builds in a row without a hit BY ONE THREAD: its scene is not static; it stops until invalidate()
+_epoch = 0  # bumped by invalidate(): a thread's thrash counter of an older epoch starts again
 
 # tests replace this to count / fake builds without a GPU: fn(g: N.Gaussians, scale_modifier, out_ptr, stream) -> None
 _build_hook = None
@@ -96,19 +101,25 @@ def invalidate():
         _drop_all()
 
 
-def _quiesce(cache):
-    """Frames on other streams may still be reading `cache` (which belongs to the stream it was built on): before it goes
-    back to the allocator, wait for its device."""
+def _mark_used(cache, device):
+    """The frame about to be enqueued on the current stream reads `cache`: the allocator may not hand the block out again
+    before that stream has passed it (replaces a device-wide synchronize on every eviction)."""
     if cache.is_cuda:
-        torch.cuda.synchronize(cache.device)
+        cache.record_stream(torch.cuda.current_stream(device))
 
 
 def _drop_all():
-    global _builds_in_a_row
-    _builds_in_a_row = 0
-    for cache, _ in _entries.values():
-        _quiesce(cache)
+    global _epoch
+    _epoch += 1
     _entries.clear()
+
+
+def _thrash_counter():
+    """[count] of this thread's builds in a row without a hit (reset by a hit, by invalidate())."""
+    c = getattr(_tls, "builds", None)
+    if c is None or c[1] != _epoch:
+        c = _tls.builds = [0, _epoch]
+    return c
 
 
 def _key_of(tensors, scale_modifier):
@@ -129,7 +140,6 @@ def attach(g, scale_modifier, tensors, device, stream):
     """Point g.cull_cache (N.Gaussians, already filled for this frame) at the current cache of `tensors` = the tensors g's
     means3D / scales / rotations / cov3D_precomp / opacities pointers came from, building it on `stream` if there is
     none.  Returns the cache buffer (keep it alive until the frame is enqueued) or None when the tensors cannot be keyed."""
-    global _builds_in_a_row
     key = _key_of(tensors, scale_modifier)
     if key is None:
         stats["uncacheable"] += 1
@@ -139,13 +149,15 @@ def attach(g, scale_modifier, tensors, device, stream):
         if hit is not None:
             _entries.move_to_end(key)
             stats["hits"] += 1
-            _builds_in_a_row = 0
+            _thrash_counter()[0] = 0
+            _mark_used(hit[0], device)
             g.cull_cache = hit[0].data_ptr()
             return hit[0]
-        if _builds_in_a_row >= _THRASH_LIMIT:  # every frame brings new tensors: a build per frame costs more than it saves
+        builds = _thrash_counter()
+        if builds[0] >= _THRASH_LIMIT:  # every frame of this thread brings new tensors: a build per frame costs more than it saves
             stats["thrashing"] += 1
             return None
-        _builds_in_a_row += 1
+        builds[0] += 1
         nbytes = _CACHE_BYTES_HOOK(int(g.P)) if _CACHE_BYTES_HOOK is not None else N.lib().gcr_cull_cache_bytes(int(g.P))
         cache = torch.empty((int(nbytes),), dtype=torch.uint8, device=device)  # (torch's blocks are 512-byte aligned)
         if _build_hook is not None:
@@ -157,8 +169,8 @@ def attach(g, scale_modifier, tensors, device, stream):
             torch.cuda.current_stream(device).synchronize()
         stats["builds"] += 1
         while len(_entries) >= _MAX_ENTRIES:
-            _quiesce(next(iter(_entries.values()))[0])
-            _entries.popitem(last=False)
+            _entries.popitem(last=False)  # (its block waits in the allocator for the streams that were marked on it)
+        _mark_used(cache, device)
         _entries[key] = (cache, tuple(t for t in tensors if t is not None))
         g.cull_cache = cache.data_ptr()
         return cache

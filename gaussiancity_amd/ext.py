@@ -67,9 +67,9 @@ def _hint_put(key, value):
             _capacity_hint.popitem(last=False)
 
 
-# ---- per-call options (gcr_options, ABI v6) ---------------------------------------------------------------------------
+# ---- per-call options (gcr_options; ABI v6, fields as of v7) ---------------------------------------------------------------------------
 class options:
-    """`with ext.options(fast_exp=1, bwd_piece=64): ...` -- the native calls of THIS thread inside the block carry these
+    """`with ext.options(bwd_wave_units=1, bwd_piece=64): ...` -- the native calls of THIS thread inside the block carry these
     gcr_options (include/gcr.h); other threads, and the process-wide defaults of gcr_set_option, are untouched.  The
     forward and the backward of a frame must run under the same options."""
 

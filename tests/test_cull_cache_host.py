@@ -84,6 +84,26 @@ def test_a_scene_that_changes_every_frame_stops_being_cached(builds):
     assert c is not None
 
 
+def test_a_thrashing_thread_does_not_switch_the_cache_off_for_the_others(builds):
+    """the builds-in-a-row counter is the calling thread's.  One thread whose scene is new every frame stops being
+    served; a thread with a static scene keeps its hits."""
+    import threading
+    done = []
+
+    def thrasher():
+        for i in range(cc._THRASH_LIMIT + 3):
+            g, c = _attach(*_scene())
+        done.append(c is None)
+
+    th = threading.Thread(target=thrasher)
+    th.start(); th.join()
+    assert done == [True] and cc.stats["thrashing"] >= 3
+    scene = _scene()
+    g, c1 = _attach(*scene)
+    g, c2 = _attach(*scene)
+    assert c1 is not None and c2 is c1  # this thread: a build, then a hit
+
+
 def test_inference_tensors_are_never_cached(builds):
     with torch.inference_mode():
         m, s, r, o = _scene()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6 A/B helper: every line of the file given as $1 is a set of bench.py arguments; prints value / period / latency / stages
+# A/B helper: every line of the file given as $1 is a set of bench.py arguments; prints value / period / latency / stages
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd $R

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: kernel timeline of a bench.py command line ($1 = tag, rest = bench args)
+# kernel timeline of a bench.py command line ($1 = tag, rest = bench args)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 TAG=$1; shift
