@@ -559,6 +559,26 @@ def main():
                 "unit": "GB/s", "frac": round(k1_alg / HBM_PEAK_GBS, 4), "traffic": k1_traffic,
                 "traffic_GBps": round(k1_traffic / 1e9 / (k1_ms / 1e3), 1) if k1_traffic else None,
                 "traffic_frac_of_copy_ceiling": round(k1_traffic / 1e9 / (k1_ms / 1e3) / ceiling, 4) if k1_traffic else None}
+        # The whole frame against its two floors (round 6): every kernel's VALU instructions and counted HBM bytes from the
+        # same committed counter passes, priced as if they could be packed perfectly -- instruction issue at the blend's
+        # measured mix (27 of its 40 step instructions at 2.5 cycles, 13 at 4.2: 3.05 cycles per wave64 instruction,
+        # profiles/r04_valu_probe.jsonl) and at the 2-cycle peak; bytes at the chip's achievable 6.3 TB/s (three K1 in flight
+        # reach it; MI355X_MICROARCH.md) -- beside the measured period.  No schedule of these kernels goes below the larger.
+        if tdoc and not args.backward:
+            kk = [v for k, v in tdoc["kernels"].items() if k in stage_names]
+            f_valu = sum(v.get("SQ_INSTS_VALU", 0) for v in kk)
+            f_bytes = sum((2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024 for v in kk)
+            period_us = 1e6 * elapsed / args.steps
+            floor_mix = f_valu * 3.05 / (1024 * 2.4e9) * 1e6
+            floor_hbm = f_bytes / 6.3e12 * 1e6
+            roofline["frame"] = {
+                "valu_instr_per_frame": int(f_valu), "hbm_bytes_per_frame": int(f_bytes),
+                "floor_us_valu_issue_at_measured_mix": round(floor_mix, 1),
+                "floor_us_valu_issue_at_2_cycle_peak": round(f_valu * 2.0 / (1024 * 2.4e9) * 1e6, 1),
+                "floor_us_hbm_at_6.3_TBps": round(floor_hbm, 1), "period_us": round(period_us, 1),
+                "floor_over_period": round(max(floor_mix, floor_hbm) / period_us, 4),
+                "sum_of_kernels_alone_us": round(1e3 * sum(stage_alone.get(k, 0.0) for k in stage_names), 1),
+                "source": "profiles/" + tfile}
         T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
         sort_passes = (32 + higher_msb(T_tiles) + 7) // 8
         if blend_like:

@@ -6,7 +6,7 @@
 # Afterwards copy gpurun_out/<tag>_* into profiles/ and commit.
 #   usage: gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out
