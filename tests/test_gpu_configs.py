@@ -158,6 +158,58 @@ def test_c4_training_step_through_helpers_wrapper_and_autograd(oracle_mod, cuda_
     assert np.abs(got_g["dL_dmean3D"]).max() > 0
 
 
+def test_c4_step_with_the_discriminators_half(cuda_device):
+    """frames.DDPTrainStep(discriminator=...) on the device, single process (round 6; core/train.py:227-295): the D-step's
+    render runs under no_grad -- an inference frame for the rasterizer, its image the same bits as the G-step's render of the
+    same points --, the discriminator stand-in gets dense gradients of its full size, the generator none from the D-step, and
+    the G-step that follows produces the gradients of a G-step-only object plus the GAN term's."""
+    from gaussiancity_amd import frames
+    from gaussiancity_amd.rasterizer import GaussianRasterizerWrapper
+    cfg, sc = synth.make_scene("C4")
+    N, W, H = cfg["P"], cfg["W"], cfg["H"]
+    cw, ch = cfg["crop"]
+    dev = cuda_device
+    wr = GaussianRasterizerWrapper(synth.intrinsics(W, H), (W, H), device=dev)
+    pos, quat = synth.orbit_poses()[5]
+    rot = sc["rotations"][:, [1, 2, 3, 0]]
+    base = torch.from_numpy(np.concatenate([sc["means3D"], sc["opacities"], sc["scales"], rot, sc["colors_precomp"]],
+                                           axis=1).astype(np.float32)).to(dev)
+    crop = ((W - cw) // 2, (H - ch) // 2, cw, ch)
+    target = torch.full((3, ch, cw), 0.25, device=dev)
+
+    def generator():
+        g = frames.StandInGenerator(n_param=2 * 4000, n_layers=2, device=dev)
+        with torch.no_grad():
+            for i, p in enumerate(g.layers):
+                p[:28] = 1e-3 * (i + 1)
+        return g
+
+    gen, dis = generator(), frames.StandInDiscriminator(n_param=5001, device=dev)
+    with torch.no_grad():
+        dis.p[0], dis.p[1] = 0.5, -0.2
+    step = frames.DDPTrainStep(wr, gen, crop=crop, discriminator=dis)
+    d_loss = step.d_step(base, pos, quat, target)
+    assert float(d_loss) > 0 and all(p.grad is None for p in gen.parameters())
+    assert dis.p.grad.shape == (5001,) and float(dis.p.grad[:2].abs().max()) > 0 and float(dis.p.grad[2:].abs().max()) == 0.0
+    with torch.no_grad():
+        fake = step._render(gen(base), pos, quat)
+    loss, img = step.step(base, pos, quat, target)
+    assert np.array_equal(fake.cpu().numpy().view(np.uint32), img.cpu().numpy().view(np.uint32))  # no_grad frame = training frame
+    # the G-step alone on a twin generator, plus the GAN term by hand
+    gen2 = generator()
+    step2 = frames.DDPTrainStep(wr, gen2, crop=crop)
+    pts = gen2(base)
+    img2 = step2._render(pts, pos, quat)
+    want = (img2 - target).abs().mean() + 0.5 * torch.relu(1.0 - dis(img2))
+    for p in gen2.parameters():
+        p.grad = None
+    want.backward()
+    assert abs(float(want) - float(loss)) <= 1e-5 * max(1.0, abs(float(want)))
+    for a, b in zip(gen.parameters(), gen2.parameters()):
+        tol = 2e-4 * max(1.0, float(b.grad.abs().max()))  # (float atomics in the backward blend: two runs differ in the last bits)
+        assert float((a.grad - b.grad).abs().max()) <= tol
+
+
 @pytest.mark.parametrize("flip_lr,flip_ud", [(True, False), (False, False), (True, True), (False, True)])
 def test_points14_node_equals_the_generic_route(oracle_mod, cuda_device, flip_lr, flip_ud):
     """GaussianRasterizerWrapper on this build's own rasterizer runs as ONE autograd node on the [N,14] tensor in place
