@@ -123,6 +123,10 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B only: a library option by name (gcr_set_option), e.g. --opt pipeline=0 --opt blend_lds_pad=4096; "
                          "the line's config.options lists what was set")
+    ap.add_argument("--scene-order", default="seeded", choices=["seeded", "morton"],
+                    help="A/B only, never the workload: `morton` renumbers the synthetic scene's Gaussians along a Morton "
+                         "curve of their (x, y) -- the index order real GaussianCity points have (a raster scan of the "
+                         "BEV maps) and the seeded S-city, drawn uniformly at random, has not")
     ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the frame loop alternates over (frames are independent; 1 = serial); "
                          "default 3 (measured optimum for both paths: C3 forward 4 520 / 4 700 / 4 690 frames/s "
@@ -263,6 +267,15 @@ def main():
 
     def load_scene(cfg_name, points=None, size=None):
         cfg, sc = synth.make_scene(cfg_name, points)
+        if args.scene_order == "morton":
+            def spread(v):
+                v = v.astype(np.uint64) & np.uint64(0xffff)
+                for sh, m in ((8, 0x00ff00ff), (4, 0x0f0f0f0f), (2, 0x33333333), (1, 0x55555555)):
+                    v = (v | (v << np.uint64(sh))) & np.uint64(m)
+                return v
+            xy = np.clip(sc["means3D"][:, :2] * 8.0, 0, 65535)
+            order = np.argsort(spread(xy[:, 0]) | (spread(xy[:, 1]) << np.uint64(1)), kind="stable")
+            sc = {k: (np.ascontiguousarray(v[order]) if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
         if size is not None:
             cfg["W"], cfg["H"] = size
         W, H = cfg["W"], cfg["H"]
@@ -604,7 +617,8 @@ def main():
                             "Python API GaussianRasterizer.forward -> (image, radii), dgr/__init__.py:223-273: num_rendered "
                             "is not part of it and is not waited for"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (gcity-synth-v1 %s, seed %d)" % (cfg["scene"], cfg["seed"]),
+            "data": "synthetic (gcity-synth-v1 %s, seed %d)" % (cfg["scene"], cfg["seed"])
+                    + ("; A/B: Gaussians RENUMBERED along a Morton curve -- not the workload" if args.scene_order != "seeded" else ""),
             "config": {"workload": "%s: %s %d Gaussians, %dx%d, SH degree %d, %s, 24-pose orbit"
                                    % (args.config, cfg["scene"], P, W, H, cfg["sh_degree"], mode),
                        "parallelism": "frames sharded round-robin, one frame per GPU, no data-path collective; "

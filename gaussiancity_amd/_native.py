@@ -92,6 +92,7 @@ class Layout(C.Structure):
         ("bin_keys", C.c_size_t * 2), ("bin_vals", C.c_size_t * 2), ("bin_hist", C.c_size_t),
         ("bin_sorted", C.c_size_t), ("bin_work", C.c_size_t), ("bin_mask", C.c_size_t), ("bin_ckpt", C.c_size_t),
         ("bin_total", C.c_size_t), ("bin_lean_total", C.c_size_t), ("bin_staged", C.c_size_t),
+        ("geom_vis_rec", C.c_size_t),  # ABI v9
     ]
 
 
@@ -99,7 +100,7 @@ class FrameInfo(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("max_tile_instances", C.c_int64)]
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 TICKET_WORDS = 8  # 64-bit pinned host words per asynchronous frame (include/gcr.h, gcr_forward_async)
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 

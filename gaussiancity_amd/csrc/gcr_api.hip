@@ -30,6 +30,9 @@ std::atomic<int> g_bwd_wave_units{0};  // 1: the backward blend as one wave per 
 std::atomic<int> g_rescue_hold{0};  // test hook ("rescue_hold"): 1 = the rescue thread answers no call for help
 std::atomic<int> g_gate_polls{400000};  // polls before a frame gate gives up waiting for a rescue to START: about two seconds
                                         // (~5 us per poll: a PCIe round trip + two s_sleep 127); tests shorten it
+// Frames whose instance-capacity guess is at least this many instances band-sort their survivors before the tile tables
+// (gcr_binning.hip "band sort": two launches more, a scatter that writes whole sectors).  0: every frame; -1: none.
+std::atomic<int> g_band_sort_min{GCR_BAND_SORT_MIN_DEFAULT};
 std::atomic<int> g_bwd_piece{160};  // entries per backward piece of frames rendered for a backward (gcr_camera.backward)
 #ifdef GCR_EXPERIMENTS  // make EXTRA=-DGCR_EXPERIMENTS: timing experiments, never in the shipping library
 std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results are wrong when set
@@ -41,6 +44,7 @@ std::atomic<unsigned long long*> g_clock_buf{nullptr};  // K7 per-wave phase clo
 // Resolved once at the top of every entry point and handed down by value -- nothing below reads the globals.
 struct Opts {
   int lazy_sort, sort_in_blend, bwd_piece, deterministic, split_preprocess, force_radix, force_global_cursor, bwd_wave_units;
+  int band_sort_min;  // process-wide only (no field in gcr_options: the record keeps its size)
 };
 Opts resolve_options(const gcr_options* o) {
   Opts r;
@@ -52,6 +56,7 @@ Opts resolve_options(const gcr_options* o) {
   r.force_radix = g_force_radix.load();
   r.force_global_cursor = g_force_global_cursor.load();
   r.bwd_wave_units = g_bwd_wave_units.load();
+  r.band_sort_min = g_band_sort_min.load();
   if (o != nullptr) {
     if (o->bwd_wave_units >= 0) r.bwd_wave_units = o->bwd_wave_units != 0;
     if (o->lazy_sort >= 0) r.lazy_sort = o->lazy_sort != 0;
@@ -173,6 +178,7 @@ void compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gcr_layout* L) {
   L->geom_vis_count = o;      o = align_up(o + (nblk + 1) * sizeof(uint32_t));
   L->geom_num_rendered = o;   o = align_up(o + 16 * sizeof(uint64_t));  // frame words (gcr_internal.h: GCR_FRAME_*, nine in use)
   L->geom_block_tiles = o;    o = align_up(o + GCR_K1_MAX_BLOCKS * sizeof(uint64_t));  // K1 blocks' shares of R
+  L->geom_vis_rec = o;        o = align_up(o + p * sizeof(uint4));  // the survivors' binning records (ABI v9)
   L->geom_total = o;
 
   const size_t npix = (size_t)(W > 0 ? W : 0) * (size_t)(H > 0 ? H : 0);
@@ -296,6 +302,7 @@ int gcr_set_option(const char* name, int value) {
   if (!strcmp(name, "rescue_hold")) return g_rescue_hold.exchange(value != 0);
   if (!strcmp(name, "gate_polls")) return g_gate_polls.exchange(value < 1 ? 1 : value);
   if (!strcmp(name, "timing")) return g_timing.exchange(value);
+  if (!strcmp(name, "band_sort_min")) return g_band_sort_min.exchange(value < 0 ? -1 : value);
   if (!strcmp(name, "force_radix")) return g_force_radix.exchange(value);
   if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.exchange(value);
 #ifdef GCR_EXPERIMENTS
@@ -319,6 +326,7 @@ int gcr_get_option(const char* name) {
   if (!strcmp(name, "rescue_hold")) return g_rescue_hold.load();
   if (!strcmp(name, "gate_polls")) return g_gate_polls.load();
   if (!strcmp(name, "timing")) return g_timing.load();
+  if (!strcmp(name, "band_sort_min")) return g_band_sort_min.load();
   if (!strcmp(name, "force_radix")) return g_force_radix.load();
   if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.load();
   if (!strcmp(name, "split_preprocess")) return g_split_preprocess.load();
@@ -360,6 +368,11 @@ static inline int stride_or(int32_t s, int dense) { return s > 0 ? (int)s : dens
 // Enqueues K1 + tile counting + tile scan; leaves {R, longest list, go flag} in the geometry
 // buffer (*frame_dev_out).  cap_* only influence the go flag used by speculative launches.
 // `host_R` (optional): pinned word that receives (seq << 32 | num_rendered) as soon as K1 is done.
+// May the band-sorted survivor numbering use gcr_layout.geom_tiles_touched on this frame?
+static inline bool band_sort_slot_free(const Opts& op, int T) {
+  return !op.split_preprocess && !op.force_radix && !op.force_global_cursor && gcr_band_sort_possible(T);
+}
+
 static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes,
                               void* img, size_t img_bytes, int32_t* radii, unsigned long long cap_instances,
                               unsigned long long cap_list, unsigned long long** frame_dev_out, hipStream_t s,
@@ -399,6 +412,7 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
   a.tile_count = (uint32_t*)(ib + L.img_tile_cursor);
   a.vis_list = (uint32_t*)(gb + L.geom_vis_list);
   a.vis_count = (uint32_t*)(gb + L.geom_vis_count);
+  a.vis_rec = (uint4*)(gb + L.geom_vis_rec);
   // candidate list / counts of K1a live in the arrays only the radix fallback needs later
   a.cand_list = (uint32_t*)(gb + L.geom_tiles_touched);
   a.cand_count = (uint32_t*)(gb + L.geom_block_sums);
@@ -419,10 +433,15 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
     }
     if (int rc = debug_sync(cam, s, "preprocess")) return rc;
     StageTimer t(s, ST_SCAN);
+    // Band sort for frames expected to hold many instances (the caller's capacity guess: ~0 = no guess, the staged entry
+    // point): the renumbered survivors go where only K1a's candidates (split mode) and the radix fallback keep anything
+    const bool band = band_sort_slot_free(op, T) && op.band_sort_min >= 0 &&
+                      (op.band_sort_min == 0 || (cap_instances != ~0ull && cap_instances >= (unsigned long long)op.band_sort_min));
     // tile_total | tile_local | blk_total share the (T x 128 B) cursor region, unused on this path
-    HIP_TRY(gcr_launch_tile_count(T, a.gx, NG, G, a.nblocks, a.chunk, a.vis_list, a.vis_count, a.rec,
+    HIP_TRY(gcr_launch_tile_count(T, a.gx, NG, G, a.nblocks, a.chunk, a.vis_rec, a.vis_count,
                                   (uint32_t*)(ib + L.img_tile_table), cursor, cursor + (size_t)T,
-                                  cursor + 2 * (size_t)T, frame, a.block_tiles, host_R, seq, s),
+                                  cursor + 2 * (size_t)T, frame, a.block_tiles, host_R, seq,
+                                  band ? (uint4*)(gb + L.geom_tiles_touched) : nullptr, g->P / 4, s),
             "tile count");
   } else {
     {
@@ -501,10 +520,12 @@ static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_g
     if (NG > 0) {
       // also rebuilds `ranges` from the block totals, so it runs even when nothing is rendered
       uint32_t* cursor = (uint32_t*)(ib + L.img_tile_cursor);
-      HIP_TRY(gcr_launch_tile_scatter(T, gx, NG, G, nblocks, chunk, vis_list, vis_count, rec,
+      HIP_TRY(gcr_launch_tile_scatter(T, gx, NG, G, nblocks, chunk, (const uint4*)(gb + L.geom_vis_rec), vis_count,
                                       (uint32_t*)(ib + L.img_tile_table), cursor, cursor + (size_t)T,
                                       cursor + 2 * (size_t)T, ranges, pairs, frame_dev, cap_instances, cap_list,
-                                      host_longest, s),
+                                      host_longest,
+                                      band_sort_slot_free(op, T) ? (const uint4*)(gb + L.geom_tiles_touched) : nullptr,
+                                      g->P / 4, s),
               "tile scatter");
     } else if (R_layout > 0) {
       HIP_TRY(gcr_launch_scatter_instances(nblocks, chunk, vis_list, vis_count, rec, gx,

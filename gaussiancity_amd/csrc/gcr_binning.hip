@@ -68,14 +68,67 @@ constexpr int RANK_MERGE_MAX = 1024;  // chunked rank sort + merge below, bitoni
 // groups (gcr_tile_table_groups: fewer, fatter groups = fewer table rows through HBM; rounds 1-2 ran 512 groups of 512
 // threads while two tables fit a CU's LDS).  At 4K a table (130 KiB) only leaves room for one workgroup per CU anyway;
 // the scatter there is bound by its 8-byte stores landing in 32-byte sectors, not by occupancy.
-constexpr int TT_MAX_GROUP = 64;  // K1 blocks per group (host guarantees G <= this)
-constexpr int TT_MAX_TBLOCKS = 640;  // 64-tile blocks: T <= 40960 > the LDS limit of 150 KiB / 4 B
+constexpr int TT_MAX_TBLOCKS = 640;  // 64-tile blocks: T <= 40960 > the LDS limit of 148 KiB / 4 B
+
+// The K1 blocks' survivor lists laid end to end: pre[k] = survivors of blocks < k, pre[nblocks] = all of them.
+// Thread t owns the PER consecutive blocks [t * PER, ...): `vc` are their counts (tt_load_counts, requested at the
+// top of the kernel so that the round trip hides behind the caller's set-up); one wave scan + one pass over the wave
+// totals.  `wtot`: THREADS / 64 words nobody else is using (the function starts and ends with a workgroup barrier).
+template <int THREADS>
+struct TtPrefix {
+  static constexpr int PER = (GCR_K1_MAX_BLOCKS + THREADS) / THREADS;  // (+ the slot of the total)
+  uint32_t vc[PER];
+  GCR_DEV void load(const uint32_t* __restrict__ vis_count, int nblocks, int tid) {
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int bi = tid * PER + u;
+      vc[u] = bi < nblocks ? vis_count[bi] : 0u;
+    }
+  }
+  GCR_DEV void scan(uint32_t* pre, uint32_t* wtot, int nblocks, int tid) const {
+    const int lane = tid & 63, w = tid >> 6;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) mine += vc[u];
+    const uint32_t incl = gcr_wave_incl_scan_u32(mine, lane);
+    __syncthreads();
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+#pragma unroll
+    for (int k = 0; k < THREADS / 64; k++)
+      if (k < w) run += wtot[k];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int bi = tid * PER + u;
+      if (bi <= nblocks) pre[bi] = run;  // (bi == nblocks: the total; counts beyond the last block are 0)
+      run += vc[u];
+    }
+    __syncthreads();
+  }
+};
+// Where position f of the lists laid end to end lies in vis_list / vis_rec (binary search in the LDS prefix:
+// pre[k] <= f < pre[k + 1]).
+GCR_DEV uint32_t tt_position(const uint32_t* pre, int nblocks, int chunk, uint32_t f) {
+  int lo = 0, hi = nblocks;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pre[mid] <= f)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return (uint32_t)lo * (uint32_t)chunk + (f - pre[lo]);
+}
+// Survivor record {index, depth bits, rect_x, rect_y} at position f of the lists laid end to end (binary search in the LDS prefix: pre[k] <= f < pre[k + 1]).
+GCR_DEV uint4 tt_survivor(const uint32_t* pre, int nblocks, const uint4* __restrict__ vis_rec, int chunk, uint32_t f) {
+  return vis_rec[tt_position(pre, nblocks, chunk, f)];
+}
 
 template <bool SCATTER, int TT_THREADS>
 __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G, int nblocks_k1, int chunk,
-                                                           const uint32_t* __restrict__ vis_list,
+                                                           const uint4* __restrict__ vis_rec,
                                                            const uint32_t* __restrict__ vis_count,
-                                                           const float4* __restrict__ rec,
                                                            uint32_t* __restrict__ table,
                                                            const uint32_t* __restrict__ tile_total,
                                                            const uint32_t* __restrict__ tile_local,
@@ -87,14 +140,17 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
                                                            unsigned long long cap_list,
                                                            unsigned long long* __restrict__ host_word,
                                                            unsigned int seq,
-                                                           const unsigned long long* __restrict__ block_tiles) {
+                                                           const unsigned long long* __restrict__ block_tiles,
+                                                           const uint4* __restrict__ banded, int banded_capacity) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gcr_smem[];
   uint32_t* cnt = reinterpret_cast<uint32_t*>(gcr_smem);  // [T]
-  __shared__ uint32_t pre[TT_MAX_GROUP + 1];              // prefix of the group's list lengths
+  __shared__ uint32_t pre[GCR_K1_MAX_BLOCKS + 1];         // prefix of ALL K1 blocks' list lengths
   __shared__ uint32_t blk_base[TT_MAX_TBLOCKS];           // first instance of every 64-tile block
   __shared__ uint32_t wtot[TT_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   uint32_t* __restrict__ row = table + (size_t)blockIdx.x * T;
+  TtPrefix<TT_THREADS> blocks;
+  blocks.load(vis_count, nblocks_k1, tid);
   if (!SCATTER) {
     // K1 is complete when this kernel starts, so its first workgroup sums the K1 blocks' shares of num_rendered
     // (what the reference gets from its inclusive scan, cr/rasterizer_impl.cu:228-238), starts the frame summary
@@ -122,6 +178,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
         frame[1] = 0ull;
         frame[2] = 0ull;
         frame[GCR_FRAME_PIECE] = 0ull;  // no backward state yet (set by a forward blend that writes it)
+        frame[GCR_FRAME_BANDED] = banded != nullptr ? 1ull : 0ull;  // which numbering the table rows were counted in
         if (host_word != nullptr)
           gcr_store_to_host(host_word, ((unsigned long long)seq << 32) | (total > 0xffffffffull ? 0xffffffffull : total));
       }
@@ -171,26 +228,30 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
       }
     }
   }
-  const int kb0 = blockIdx.x * G;
-  const int kbn = min(G, nblocks_k1 - kb0);
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (int k = 0; k < kbn; k++) {
-      pre[k] = run;
-      run += vis_count[kb0 + k];
-    }
-    pre[kbn] = run;
-  }
-  __syncthreads();
-  const uint32_t total = pre[kbn];
-  for (uint32_t f = tid; f < total; f += TT_THREADS) {
-    int k = 0;
-    while (k + 1 < kbn && pre[k + 1] <= f) k++;
-    const uint32_t idx = vis_list[(size_t)(kb0 + k) * chunk + (f - pre[k])];
-    const float4 q2 = rec[(size_t)idx * GCR_REC_QUADS + 2];
-    const uint32_t rx = __float_as_uint(q2.z), ry = __float_as_uint(q2.w);
+  // The workgroup's share of the frame's survivors: an EQUAL cut of the K1 blocks' lists laid end to end, not a run of
+  // whole K1 blocks (rounds 1-5) -- a scene whose index order is spatially coherent (real GaussianCity points are a raster
+  // scan of the BEV maps) leaves most K1 blocks without a survivor and a few with thousands, and whole blocks made the
+  // few groups that own them do the frame's counting and scattering alone (round 6 A/B, C5 renumbered along a Morton
+  // curve: count + scan 54 -> 352 us, scatter 195 -> 668 us alone).  Both instantiations cut the same way, from
+  // vis_count alone.  (G, the blocks per group of the old cut, is unused.)
+  (void)G;
+  blocks.scan(pre, wtot, nblocks_k1, tid);
+  const uint32_t survivors = pre[nblocks_k1];
+  const uint32_t f_lo = (uint32_t)(((uint64_t)survivors * blockIdx.x) / gridDim.x);
+  const uint32_t f_hi = (uint32_t)(((uint64_t)survivors * (blockIdx.x + 1u)) / gridDim.x);
+  // `banded` (k_band_permute ran on this frame): the same survivors, renumbered by the tile band their rectangle starts
+  // in -- the workgroup's share then lands in a few hundred neighbouring tiles instead of all over the image
+  // (`banded` holds records while they fit -- banded_capacity of them -- and 4-byte positions in vis_rec beyond that:
+  // k_band decides from the same count every kernel sees)
+  const bool use_band = banded != nullptr && (SCATTER ? frame[GCR_FRAME_BANDED] != 0ull : true);
+  const bool band_recs = survivors <= (uint32_t)banded_capacity;
+  const uint32_t* __restrict__ banded_pos = reinterpret_cast<const uint32_t*>(banded);
+  for (uint32_t f = f_lo + (uint32_t)tid; f < f_hi; f += TT_THREADS) {
+    const uint4 sv = !use_band ? tt_survivor(pre, nblocks_k1, vis_rec, chunk, f)
+                               : (band_recs ? banded[f] : vis_rec[banded_pos[f]]);
+    const uint32_t rx = sv.z, ry = sv.w;
     const uint32_t minx = rx & 0xffffu, maxx = rx >> 16, miny = ry & 0xffffu, maxy = ry >> 16;
-    const uint64_t key = ((uint64_t)__float_as_uint(q2.y) << 32) | idx;
+    const uint64_t key = ((uint64_t)sv.y << 32) | sv.x;
     for (uint32_t y = miny; y < maxy; y++)
       for (uint32_t x = minx; x < maxx; x++) {
         const uint32_t t = y * (uint32_t)gx + x;
@@ -205,6 +266,119 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
   if (!SCATTER) {
     __syncthreads();
     for (int t = tid; t < T; t += TT_THREADS) row[t] = cnt[t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------- band sort (round 6)
+// A scatter workgroup's instances go wherever its Gaussians happen to lie: with 256 groups a (group, tile) pair holds
+// 0.5 (C3) to 1.4 (C5) instances, so every 8-byte key is a 32-byte sector written alone -- 3.9x the bytes at C5, the
+// scatter's time (round 6 A/B: the same frame with its Gaussians renumbered along a Morton curve scatters in 82 us
+// instead of 195).  For frames with many instances the survivors are therefore renumbered first, by the BAND of
+// GCR_BANDS equal runs of tiles (row-major) that holds the first tile of their rectangle: two small kernels, a counting
+// sort over 256 equal cuts of the survivor lists.  The tile-table kernels then take equal cuts of THAT order: a group's
+// instances fall into a few hundred neighbouring tiles, tens of them per tile, next to each other in `pairs`.
+//   k_band_hist:    hist[g][b] = survivors of cut g whose rectangle starts in band b
+//   k_band_permute: every workgroup sums the 256 x GCR_BANDS table (256 KiB, out of L2) into band starts + its own
+//                   offsets, then drops its survivors' indices into banded[] with LDS cursors
+// The order inside a band is whatever the LDS atomics make it -- like the slot order inside a tile, it is not
+// observable: the tile sort orders every list by its unique (depth, index) keys.
+constexpr int GCR_BANDS = 256;
+constexpr int BAND_CUTS = 256;  // workgroups of the two kernels (= rows of the histogram)
+GCR_DEV uint32_t band_of(uint32_t rx, uint32_t ry, uint32_t gx, uint32_t band_mul) {
+  const uint32_t t0 = (ry & 0xffffu) * gx + (rx & 0xffffu);
+  const uint32_t b = (uint32_t)(((uint64_t)t0 * band_mul) >> 32);
+  return b < (uint32_t)GCR_BANDS ? b : (uint32_t)GCR_BANDS - 1u;
+}
+
+constexpr int BAND_THREADS = 1024;  // one workgroup per CU: the loop is two dependent gathers per survivor, so width is what hides them
+constexpr int BAND_ILP = 4;         // survivors per thread and trip, their gathers in flight together
+template <bool PERMUTE>
+__global__ __launch_bounds__(BAND_THREADS) void k_band(int gx, uint32_t band_mul, int nblocks_k1, int chunk,
+                                                       const uint4* __restrict__ vis_rec,
+                                                       const uint32_t* __restrict__ vis_count,
+                                                       uint32_t* __restrict__ hist, uint4* __restrict__ banded,
+                                                       int banded_capacity) {
+  __shared__ uint32_t pre[GCR_K1_MAX_BLOCKS + 1];
+  __shared__ uint32_t wtot[BAND_THREADS / 64];
+  __shared__ uint32_t cur[GCR_BANDS];
+  __shared__ uint32_t part[2][BAND_THREADS / GCR_BANDS][GCR_BANDS];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  TtPrefix<BAND_THREADS> blocks;
+  blocks.load(vis_count, nblocks_k1, tid);
+  if (PERMUTE) {
+    // band b = tid mod GCR_BANDS, a quarter of the cuts per thread: the band's total over all cuts and its share in
+    // front of this cut (rows are 1 KiB, read coalesced; the table comes out of L2)
+    constexpr int Q = BAND_THREADS / GCR_BANDS, ROWS = BAND_CUTS / Q;
+    const int b = tid & (GCR_BANDS - 1), q = tid / GCR_BANDS;
+    uint32_t total = 0, before = 0;
+#pragma unroll 16
+    for (int r = 0; r < ROWS; r++) {
+      const int g = q * ROWS + r;
+      const uint32_t v = hist[(size_t)g * GCR_BANDS + b];
+      total += v;
+      before += g < (int)blockIdx.x ? v : 0u;
+    }
+    part[0][q][b] = total;
+    part[1][q][b] = before;
+    __syncthreads();
+    if (tid < GCR_BANDS) {  // waves 0..3
+      total = 0;
+      before = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        total += part[0][k][tid];
+        before += part[1][k][tid];
+      }
+      const uint32_t incl = gcr_wave_incl_scan_u32(total, lane);
+      if (lane == 63) wtot[w] = incl;
+      part[0][0][tid] = incl - total + before;  // (own slot: read above by this thread only)
+    }
+    __syncthreads();
+    if (tid < GCR_BANDS) {
+      uint32_t start = part[0][0][tid];
+#pragma unroll
+      for (int k = 0; k < GCR_BANDS / 64; k++)
+        if (k < w) start += wtot[k];
+      cur[tid] = start;
+    }
+  } else {
+    if (tid < GCR_BANDS) cur[tid] = 0u;
+  }
+  blocks.scan(pre, wtot, nblocks_k1, tid);
+  const uint32_t survivors = pre[nblocks_k1];
+  const uint32_t f_lo = (uint32_t)(((uint64_t)survivors * blockIdx.x) / gridDim.x);
+  const uint32_t f_hi = (uint32_t)(((uint64_t)survivors * (blockIdx.x + 1u)) / gridDim.x);
+  const bool band_recs = survivors <= (uint32_t)banded_capacity;  // else: 4-byte positions (P of them always fit)
+  uint32_t* __restrict__ banded_pos = reinterpret_cast<uint32_t*>(banded);
+  for (uint32_t f0 = f_lo + (uint32_t)tid; f0 < f_hi; f0 += BAND_THREADS * BAND_ILP) {
+    uint32_t pos[BAND_ILP];
+    uint4 sv[BAND_ILP];
+#pragma unroll
+    for (int u = 0; u < BAND_ILP; u++) {
+      const uint32_t f = f0 + (uint32_t)u * BAND_THREADS;
+      pos[u] = f < f_hi ? tt_position(pre, nblocks_k1, chunk, f) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int u = 0; u < BAND_ILP; u++)
+      if (pos[u] != 0xffffffffu) sv[u] = vis_rec[pos[u]];
+#pragma unroll
+    for (int u = 0; u < BAND_ILP; u++)
+      if (pos[u] != 0xffffffffu) {
+        const uint32_t b = band_of(sv[u].z, sv[u].w, (uint32_t)gx, band_mul);
+        if (PERMUTE) {
+          const uint32_t slot = atomicAdd(&cur[b], 1u);
+          if (band_recs)
+            banded[slot] = sv[u];
+          else
+            banded_pos[slot] = pos[u];
+        } else {
+          atomicAdd(&cur[b], 1u);
+        }
+      }
+  }
+  if (!PERMUTE) {
+    __syncthreads();
+    if (tid < GCR_BANDS) hist[(size_t)blockIdx.x * GCR_BANDS + tid] = cur[tid];
   }
 }
 
@@ -591,9 +765,12 @@ hipError_t gcr_launch_emit(int P, const uint32_t* tiles_touched, const uint32_t*
 
 // Geometry of the tile-table path: NG groups of G consecutive K1 blocks; 0 if the table does
 // not fit in LDS.
+bool gcr_band_sort_possible(int T) { return T >= GCR_BANDS; }
+
 int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out) {
   const size_t lds = (size_t)T * sizeof(uint32_t);
-  if (lds > 150 * 1024 || (T + 63) / 64 > TT_MAX_TBLOCKS) return 0;
+  // (160 KiB of LDS per workgroup: the table + 11 KiB of static arrays, the K1 blocks' prefix among them)
+  if (lds > 148 * 1024 || (T + 63) / 64 > TT_MAX_TBLOCKS) return 0;
   // One 1024-thread workgroup per CU.  Round 3 A/B at C3 (same box, experiment build): 512 groups of 512 threads (two
   // tables per CU) 4 407-4 432 frames/s, 256 groups of 1024 threads 4 470-4 550 -- half the table rows to write, scan and
   // read back (count + column scan 22.3 -> 18.9 us, scatter 28.7 -> 25.7 us alone); 192 / 128 groups the same, 64 slower.
@@ -604,7 +781,6 @@ int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out) {
   if (ng > nblocks_k1) ng = nblocks_k1;
   if (ng < 1) ng = 1;
   int G = (nblocks_k1 + ng - 1) / ng;
-  if (G > TT_MAX_GROUP) return 0;
   *G_out = G;
   return (nblocks_k1 + G - 1) / G;
 }
@@ -614,7 +790,7 @@ static hipError_t tile_table_attr() {
     const void* fns[4] = {(const void*)k_tile_table<false, 512>, (const void*)k_tile_table<true, 512>,
                           (const void*)k_tile_table<false, 1024>, (const void*)k_tile_table<true, 1024>};
     for (const void* f : fns) {
-      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
       if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -623,41 +799,51 @@ static hipError_t tile_table_attr() {
 }
 static inline bool tile_table_wide(int) { return true; }  // (the 512-thread instantiations remain for A/B builds)
 
-hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
-                                 const uint32_t* vis_count, const float4* rec, uint32_t* table,
+hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint4* vis_rec,
+                                 const uint32_t* vis_count, uint32_t* table,
                                  uint32_t* tile_total, uint32_t* tile_local, uint32_t* blk_total,
                                  unsigned long long* frame, const unsigned long long* block_tiles,
-                                 unsigned long long* host_R, unsigned int seq, hipStream_t s) {
+                                 unsigned long long* host_R, unsigned int seq, uint4* banded, int banded_capacity,
+                                 hipStream_t s) {
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
+  if (banded != nullptr) {
+    // (the histogram borrows the head of the tile table, which the count kernel overwrites afterwards: T >= GCR_BANDS)
+    const uint32_t band_mul = (uint32_t)((((uint64_t)GCR_BANDS << 32) + (uint64_t)T - 1) / (uint64_t)T);
+    k_band<false><<<BAND_CUTS, BAND_THREADS, 0, s>>>(gx, band_mul, nblocks_k1, chunk, vis_rec, vis_count, table, nullptr,
+                                                      banded_capacity);
+    k_band<true><<<BAND_CUTS, BAND_THREADS, 0, s>>>(gx, band_mul, nblocks_k1, chunk, vis_rec, vis_count, table, banded,
+                                                     banded_capacity);
+  }
   if (tile_table_wide(T))
     k_tile_table<false, 1024><<<NG, 1024, (size_t)T * sizeof(uint32_t), s>>>(
-        T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, nullptr, nullptr, nullptr, nullptr, nullptr,
-        frame, 0ull, 0ull, host_R, seq, block_tiles);
+        T, gx, G, nblocks_k1, chunk, vis_rec, vis_count, table, nullptr, nullptr, nullptr, nullptr, nullptr,
+        frame, 0ull, 0ull, host_R, seq, block_tiles, banded, banded_capacity);
   else
     k_tile_table<false, 512><<<NG, 512, (size_t)T * sizeof(uint32_t), s>>>(
-        T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, nullptr, nullptr, nullptr, nullptr, nullptr,
-        frame, 0ull, 0ull, host_R, seq, block_tiles);
+        T, gx, G, nblocks_k1, chunk, vis_rec, vis_count, table, nullptr, nullptr, nullptr, nullptr, nullptr,
+        frame, 0ull, 0ull, host_R, seq, block_tiles, banded, banded_capacity);
   k_table_colscan<<<(T + 63) / 64, 1024, 0, s>>>(table, NG, T, tile_total, tile_local, blk_total, frame);
   return hipGetLastError();
 }
 
-hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
-                                   const uint32_t* vis_count, const float4* rec, uint32_t* table,
+hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint4* vis_rec,
+                                   const uint32_t* vis_count, uint32_t* table,
                                    const uint32_t* tile_total, const uint32_t* tile_local,
                                    const uint32_t* blk_total, uint32_t* ranges, uint64_t* pairs,
                                    unsigned long long* frame, unsigned long long cap_instances,
-                                   unsigned long long cap_list, unsigned long long* host_longest, hipStream_t s) {
+                                   unsigned long long cap_list, unsigned long long* host_longest,
+                                   const uint4* banded, int banded_capacity, hipStream_t s) {
   hipError_t e = tile_table_attr();
   if (e != hipSuccess) return e;
   if (tile_table_wide(T))
     k_tile_table<true, 1024><<<NG, 1024, (size_t)T * sizeof(uint32_t), s>>>(
-        T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, tile_total, tile_local, blk_total, ranges, pairs,
-        frame, cap_instances, cap_list, host_longest, 0u, nullptr);
+        T, gx, G, nblocks_k1, chunk, vis_rec, vis_count, table, tile_total, tile_local, blk_total, ranges, pairs,
+        frame, cap_instances, cap_list, host_longest, 0u, nullptr, banded, banded_capacity);
   else
     k_tile_table<true, 512><<<NG, 512, (size_t)T * sizeof(uint32_t), s>>>(
-        T, gx, G, nblocks_k1, chunk, vis_list, vis_count, rec, table, tile_total, tile_local, blk_total, ranges, pairs,
-        frame, cap_instances, cap_list, host_longest, 0u, nullptr);
+        T, gx, G, nblocks_k1, chunk, vis_rec, vis_count, table, tile_total, tile_local, blk_total, ranges, pairs,
+        frame, cap_instances, cap_list, host_longest, 0u, nullptr, banded, banded_capacity);
   return hipGetLastError();
 }
 

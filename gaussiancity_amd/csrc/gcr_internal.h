@@ -40,6 +40,7 @@ struct GcrPreprocessArgs {
   uint32_t* tile_count;  // [T * GCR_CURSOR_STRIDE] per-tile instance counts (zeroed before K1)
   uint32_t* vis_list;    // [P] block b's survivors at [b*chunk, b*chunk + vis_count[b])
   uint32_t* vis_count;   // [nblocks]
+  uint4* vis_rec;        // [P] {index, depth bits, rect_x, rect_y} of every survivor, at its position in vis_list
   uint32_t* cand_list;   // [P] K1a's candidates of block b at [b*chunk, b*chunk + cand_count[b])
   uint32_t* cand_count;  // [nblocks]
   unsigned long long* block_tiles;  // [nblocks] every K1 block's share of num_rendered
@@ -197,7 +198,11 @@ static inline __host__ __device__ unsigned long long gcr_piece_slots(unsigned lo
 #define GCR_FRAME_CARVE 6     // bytes of the binning buffer as the forward carved it (for ITS capacity): a backward
                               // that is handed a smaller buffer must not follow the offsets above
 #define GCR_FRAME_STAGED_OFF 8  // byte offset of the staged records (48 B per instance, sorted-list order; round 5): the
-                                // frame words' slot in the geometry buffer is 256 bytes, words 9..31 are free
+                                // frame words' slot in the geometry buffer is 128 bytes, words 10..15 are free
+// default of the process-wide option "band_sort_min" (instances of the caller's capacity guess; tuned in round 6)
+#define GCR_BAND_SORT_MIN_DEFAULT 6000000
+#define GCR_FRAME_BANDED 9      // != 0: the tile table of this frame was counted over the band-sorted survivors
+                                // (gcr_binning.hip "band sort"; set by the count kernel, read by the scatter kernel)
 // Has the forward left the backward's state in a buffer of `binning_bytes`?  (frame word 3 is zeroed by the count
 // kernel of every frame and set by a forward blend that writes the state.)
 static inline __host__ __device__ bool gcr_frame_has_state(const unsigned long long* frame, unsigned long long binning_bytes) {
@@ -274,17 +279,20 @@ hipError_t gcr_launch_scan_tiles(uint32_t* tile_cursor, int stride, uint32_t* ra
                                  unsigned long long cap_list, unsigned long long* host_R, unsigned int seq,
                                  const unsigned long long* block_tiles, int nblocks_k1, hipStream_t s);
 int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out);
-hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
-                                 const uint32_t* vis_count, const float4* rec, uint32_t* table,
+hipError_t gcr_launch_tile_count(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint4* vis_rec,
+                                 const uint32_t* vis_count, uint32_t* table,
                                  uint32_t* tile_total, uint32_t* tile_local, uint32_t* blk_total,
                                  unsigned long long* frame, const unsigned long long* block_tiles,
-                                 unsigned long long* host_R, unsigned int seq, hipStream_t s);
-hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint32_t* vis_list,
-                                   const uint32_t* vis_count, const float4* rec, uint32_t* table,
+                                 unsigned long long* host_R, unsigned int seq, uint4* banded, int banded_capacity,
+                                 hipStream_t s);
+bool gcr_band_sort_possible(int T);  // band sort (gcr_binning.hip): `banded` = 16 B per survivor, null = off
+hipError_t gcr_launch_tile_scatter(int T, int gx, int NG, int G, int nblocks_k1, int chunk, const uint4* vis_rec,
+                                   const uint32_t* vis_count, uint32_t* table,
                                    const uint32_t* tile_total, const uint32_t* tile_local,
                                    const uint32_t* blk_total, uint32_t* ranges, uint64_t* pairs,
                                    unsigned long long* frame, unsigned long long cap_instances,
-                                   unsigned long long cap_list, unsigned long long* host_longest, hipStream_t s);
+                                   unsigned long long cap_list, unsigned long long* host_longest,
+                                   const uint4* banded, int banded_capacity, hipStream_t s);
 hipError_t gcr_launch_scatter_instances(int nblocks, int chunk, const uint32_t* vis_list,
                                         const uint32_t* vis_count, const float4* rec, int gx,
                                         uint32_t* tile_cursor, uint64_t* pairs, const uint32_t* ranges, int T,

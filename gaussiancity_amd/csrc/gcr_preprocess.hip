@@ -407,6 +407,10 @@ GCR_DEV void preprocess_phase_b(const GcrPreprocessArgs& a, int idx, const V3 me
   rec[2] = make_float4(cb, pr.depth, __uint_as_float(pr.rect_x), __uint_as_float(pr.rect_y));
   rec[3] = make_float4(__uint_as_float(clamp_mask), 0.0f, 0.0f, 0.0f);
   vis_list[list_pos] = (uint32_t)idx;
+  // what the binning kernels need of a survivor, at the same position of the block's list (ABI v9): they read the lists
+  // front to back instead of gathering rec[2] of every survivor out of P x 64 bytes
+  a.vis_rec[(vis_list - a.vis_list) + list_pos] =
+      make_uint4((uint32_t)idx, __float_as_uint(pr.depth), pr.rect_x, pr.rect_y);
   // per-tile instance counts, global-cursor variant only (gcr_binning.hip explains why the
   // default path counts in LDS instead)
   if (a.tile_count != nullptr) {

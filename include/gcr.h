@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define GCR_ABI_VERSION 8
+#define GCR_ABI_VERSION 9
 #define GCR_BLOCK_X 16 /* cr/config.h:16 */
 #define GCR_BLOCK_Y 16 /* cr/config.h:17 */
 #define GCR_NUM_CHANNELS 3 /* cr/config.h:15 */
@@ -240,6 +240,9 @@ typedef struct gcr_layout {
   size_t bin_staged;    /* (ABI v7) 48 B per instance, sorted-list order: every entry as the forward blend staged it
                            (centre, pre-scaled conic, opacity, colour, skip bound) -- the backward blend reads a piece's
                            records as one coalesced block instead of gathering them by Gaussian index */
+  size_t geom_vis_rec;  /* (ABI v9) uint32[4] per Gaussian, K1 block b's survivors packed at b*chunk like geom_vis_list:
+                           {Gaussian index, depth bits, rect_x, rect_y} -- what the binning kernels need of a survivor, so
+                           that they read K1's lists front to back instead of gathering a 64-byte record per survivor */
 } gcr_layout;
 
 /* Host-side summary of K1+K2, produced by gcr_forward_preprocess and consumed by
