@@ -275,15 +275,15 @@ __global__ __launch_bounds__(TT_THREADS) void k_tile_table(int T, int gx, int G,
 // scatter's time (round 6 A/B: the same frame with its Gaussians renumbered along a Morton curve scatters in 82 us
 // instead of 195).  For frames with many instances the survivors are therefore renumbered first, by the BAND of
 // GCR_BANDS equal runs of tiles (row-major) that holds the first tile of their rectangle: two small kernels, a counting
-// sort over 256 equal cuts of the survivor lists.  The tile-table kernels then take equal cuts of THAT order: a group's
+// sort over BAND_CUTS equal cuts of the survivor lists.  The tile-table kernels then take equal cuts of THAT order: a group's
 // instances fall into a few hundred neighbouring tiles, tens of them per tile, next to each other in `pairs`.
 //   k_band_hist:    hist[g][b] = survivors of cut g whose rectangle starts in band b
-//   k_band_permute: every workgroup sums the 256 x GCR_BANDS table (256 KiB, out of L2) into band starts + its own
+//   k_band_permute: every workgroup sums the BAND_CUTS x GCR_BANDS table (128 KiB, out of L2) into band starts + its own
 //                   offsets, then drops its survivors' indices into banded[] with LDS cursors
 // The order inside a band is whatever the LDS atomics make it -- like the slot order inside a tile, it is not
 // observable: the tile sort orders every list by its unique (depth, index) keys.
 constexpr int GCR_BANDS = 256;
-constexpr int BAND_CUTS = 256;  // workgroups of the two kernels (= rows of the histogram)
+constexpr int BAND_CUTS = 128;  // workgroups of the two kernels (= rows of the histogram)
 GCR_DEV uint32_t band_of(uint32_t rx, uint32_t ry, uint32_t gx, uint32_t band_mul) {
   const uint32_t t0 = (ry & 0xffffu) * gx + (rx & 0xffffu);
   const uint32_t b = (uint32_t)(((uint64_t)t0 * band_mul) >> 32);
@@ -771,10 +771,14 @@ int gcr_tile_table_groups(int T, int nblocks_k1, int* G_out) {
   const size_t lds = (size_t)T * sizeof(uint32_t);
   // (160 KiB of LDS per workgroup: the table + 11 KiB of static arrays, the K1 blocks' prefix among them)
   if (lds > 148 * 1024 || (T + 63) / 64 > TT_MAX_TBLOCKS) return 0;
-  // One 1024-thread workgroup per CU.  Round 3 A/B at C3 (same box, experiment build): 512 groups of 512 threads (two
-  // tables per CU) 4 407-4 432 frames/s, 256 groups of 1024 threads 4 470-4 550 -- half the table rows to write, scan and
-  // read back (count + column scan 22.3 -> 18.9 us, scatter 28.7 -> 25.7 us alone); 192 / 128 groups the same, 64 slower.
-  int ng = 256;
+  // 1024-thread workgroups, one per CU -- on HALF of the CUs.  Round 3 A/B at C3 (same box, experiment build): 512 groups
+  // of 512 threads (two tables per CU) 4 407-4 432 frames/s, 256 groups of 1024 threads 4 470-4 550 -- half the table rows to
+  // write, scan and read back.  Round 6, with the survivor records and the equal cut (profiles/r06_tile_table_groups_ab.txt):
+  // alone the count and the scatter take the same time with 128 groups as with 256 (C3 17.9 + 25.9 against 17.7 + 25.3 us)
+  // -- they are set-up and table traffic, not survivors -- and with three frames in flight the CUs they leave alone are
+  // worth more to the other frames' kernels: C3 5 476-5 510 -> 5 689-5 701 frames/s (96 groups 5 726-5 747), C5 1 039 ->
+  // 1 072-1 099, the dense stress scene D1 1 232 -> 1 217 (96: 1 182, which is why it is not 96).
+  int ng = 128;
 #ifdef GCR_EXPERIMENTS
   if (const char* e = getenv("GCR_TT_GROUPS")) ng = atoi(e);
 #endif

@@ -26,7 +26,7 @@ def kernel_source_hashes():
 # bench.py stage -> substrings of the kernel names launched inside that stage timer (gcr_api.hip)
 STAGES = {
     "preprocess": ("k_preprocess_fused", "k_preprocess_cull", "k_preprocess_project"),
-    "scan": ("k_tile_table<false", "k_tile_table<0", "k_tile_tableILb0", "k_table_colscan"),   # (<false, 1024>: no ">")
+    "scan": ("k_tile_table<false", "k_tile_table<0", "k_tile_tableILb0", "k_table_colscan", "k_band<"),   # (<false, 1024>: no ">"; k_band: the band sort of big frames, round 6)
     "emit": ("k_tile_table<true", "k_tile_table<1", "k_tile_tableILb1"),
     "sort": ("k_tile_sort",),
     "blend_fwd": ("k_blend_fwd",),
