@@ -394,13 +394,19 @@ def main():
         with torch.cuda.stream(st):
             torch.zeros(1, device=dev)
     torch.cuda.synchronize()
+    default_stream = torch.cuda.current_stream(dev)
 
     def run_frames(lo, hi, step_fn=None):
         step_fn = step_fn or step_main
         if args.host_threads <= 1:
-            for i in range(lo, hi):
-                with torch.cuda.stream(streams[i % len(streams)]):
+            # torch.cuda.set_stream, not the `with torch.cuda.stream(...)` context: the context manager costs the calling
+            # thread 6 us per frame (tools/host_profile_api.py), a tenth of what it needs to enqueue a frame
+            try:
+                for i in range(lo, hi):
+                    torch.cuda.set_stream(streams[i % len(streams)])
                     step_fn(poses[i])
+            finally:
+                torch.cuda.set_stream(default_stream)
             return
         # One host thread per stream.  The reference API returns num_rendered as a Python int, so every
         # call blocks its caller until the frame's scan has run; with a single host thread that wait

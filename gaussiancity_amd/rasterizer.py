@@ -232,6 +232,16 @@ class GaussianRasterizer(torch.nn.Module):
             raise Exception(
                 "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         opt = [shs, colors_precomp, scales, rotations, cov3D_precomp]
+        rs = self.raster_settings
+        frame = getattr(_ext, "rasterize_gaussians_frame", None)
+        if frame is not None and not rs.debug and not (torch.is_grad_enabled() and any(
+                t is not None and t.requires_grad for t in (means3D, means2D, opacities, *opt))):
+            # Nothing here asks for a gradient: RasterizeGaussiansFunction.apply would build no graph and hand back the
+            # same two tensors -- this build's native module renders such a frame without the autograd node, the state
+            # buffers a backward would read, or the host wait (ext.rasterize_gaussians_frame: same kernels, same bits).
+            return frame(rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3D_precomp,
+                         rs.view_matrix, rs.proj_matrix, rs.tanfovx, rs.tanfovy, rs.img_h, rs.img_w, shs, rs.sh_degree,
+                         rs.campos, rs.prefiltered)
         shs, colors_precomp, scales, rotations, cov3D_precomp = [
             _absent() if t is None else t for t in opt]
         return RasterizeGaussiansFunction.apply(
