@@ -497,15 +497,19 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         e = _empty_frame(device, H, W)
         return ((FrameTicket(L, None, None, 0, 0, None, None, False, R=0),) + e[1:]) if _ticket else e
     with _on_device(device):
-        cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
-                              tan_fovy, H, W, scale_modifier, degree, prefiltered, debug, _for_backward)
-        g, keep_g = _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations,
-                               cov3D_precomp)
         if _cull.enabled() and not _for_backward:  # a static scene's cull cache: same bits, fewer bytes (cull_cache.py)
-            keep_g.append(_cull.attach(g, scale_modifier, (means3D, scales, rotations, cov3D_precomp, opacity), device,
-                                       _stream(device)))
+            cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx,
+                                  tan_fovy, H, W, scale_modifier, degree, prefiltered, debug, _for_backward)
+            g, keep_g = _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations,
+                                   cov3D_precomp)
+            keep = (keep_c, keep_g, _cull.attach(g, scale_modifier, (means3D, scales, rotations, cov3D_precomp, opacity),
+                                                 device, _stream(device)))
+        else:
+            cam, g, keep = _records(device, P, H, W, background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                                    cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, sh, degree, campos,
+                                    bool(prefiltered), bool(debug), bool(_for_backward), _current_options())
         out = _forward(L, device, cam, g, P, H, W, _ticket)
-        del keep_c, keep_g
+        del keep
     return out
 
 
@@ -548,6 +552,37 @@ def _a512(n):
     return (int(n) + 511) & ~511
 
 
+def _records(device, P, H, W, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+             viewmatrix, projmatrix, tan_fovx, tan_fovy, sh, degree, campos, prefiltered, debug, for_backward, opt):
+    """(gcr_camera, gcr_gaussians, what must stay alive during the call) of a frame -- from this thread's cache when every
+    tensor of the call is the same object at the same address as when the records were built."""
+    tensors = (background, means3D, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, sh, campos)
+    key = (tuple(0 if (t is None or t.numel() == 0) else id(t) for t in tensors), scale_modifier, tan_fovx, tan_fovy, H, W,
+           degree, prefiltered, debug, for_backward, id(opt))
+    cache = _prep_cache()
+    ent = cache.get(key)
+    if ent is not None and ent.P == P:
+        for r, p, t in zip(ent.refs, ent.ptrs, tensors):
+            if r is not None and (r() is not t or t.data_ptr() != p):
+                break
+        else:
+            return ent.cam, ent.g, None
+    cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W,
+                          scale_modifier, degree, prefiltered, debug, for_backward)
+    g, keep_g = _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations, cov3D_precomp)
+    kept = [t for t in keep_c + keep_g if isinstance(t, torch.Tensor)]
+    live = [t for t in tensors if t is not None and t.numel() != 0]
+    if len(kept) == len(live) and all(any(k is t for t in live) for k in kept):  # no .contiguous() copy was made
+        ent = _Prepared()
+        ent.refs = tuple(None if (t is None or t.numel() == 0) else weakref.ref(t) for t in tensors)
+        ent.ptrs = tuple(0 if (t is None or t.numel() == 0) else t.data_ptr() for t in tensors)
+        ent.cam, ent.g, ent.device, ent.P = cam, g, device, P
+        cache[key] = ent
+        while len(cache) > _PREP_MAX:
+            cache.popitem(last=False)
+    return cam, g, (keep_c, keep_g)
+
+
 def rasterize_gaussians_frame(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                               viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                               prefiltered):
@@ -563,39 +598,14 @@ def rasterize_gaussians_frame(background, means3D, colors, opacity, scales, rota
         return rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                                    viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered,
                                    False, _for_backward=False, _ticket=True)[1:3]
-    tensors = (background, means3D, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, sh, campos)
-    key = (tuple(0 if (t is None or t.numel() == 0) else id(t) for t in tensors), scale_modifier, tan_fovx, tan_fovy, H, W,
-           degree, prefiltered, id(opt))
-    cache = _prep_cache()
-    ent = cache.get(key)
-    if ent is not None:
-        for r, p, t in zip(ent.refs, ent.ptrs, tensors):
-            if r is not None and (r() is not t or t.data_ptr() != p):
-                ent = None
-                break
-        if ent is not None and ent.P != P:
-            ent = None
     L = N.lib()
     device = means3D.device
     with _on_device(device):
-        if ent is None:
-            cam, keep_c = _camera(device, background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W,
-                                  scale_modifier, degree, prefiltered, False, False)
-            g, keep_g = _gaussians(device, P, means3D, opacity, sh, colors, scales, rotations, cov3D_precomp)
-            kept = [t for t in keep_c + keep_g if isinstance(t, torch.Tensor)]
-            live = [t for t in tensors if t is not None and t.numel() != 0]
-            if len(kept) == len(live) and all(any(k is t for t in live) for k in kept):  # no .contiguous() copy was made
-                ent = _Prepared()
-                ent.refs = tuple(None if (t is None or t.numel() == 0) else weakref.ref(t) for t in tensors)
-                ent.ptrs = tuple(0 if (t is None or t.numel() == 0) else t.data_ptr() for t in tensors)
-                ent.cam, ent.g, ent.device, ent.P = cam, g, device, P
-                cache[key] = ent
-                while len(cache) > _PREP_MAX:
-                    cache.popitem(last=False)
-        else:
-            cam, g, keep_c, keep_g = ent.cam, ent.g, None, None
+        cam, g, keep = _records(device, P, H, W, background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                                cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, sh, degree, campos, prefiltered,
+                                False, False, opt)
         out = _forward_lean(L, device, cam, g, P, H, W, opt)
-        del keep_c, keep_g
+        del keep
     return out
 
 

@@ -101,7 +101,10 @@ def test_mostly_visible_scene_takes_the_position_copy(oracle_mod, cuda_device, b
     (the lazy tile sort runs behind the scatter), an inference frame and a training frame."""
     P, W, H = 9000, 320, 272
     rs = scenes.camera(W, H, pose_index=7)._replace(sh_degree=2, bg=torch.tensor((0.1, 0.2, 0.3)))
-    sc = scenes.blob_scene(P, 77, 2, smax=10.0)
+    # (scales up to 7: lists of up to 1 858 entries, and the gradients stay a factor three inside the 1e-4 bar in every
+    # run -- with scales up to 10 this scene is in the fuzz sweep's ill-conditioned tier, tools/fuzz_parity.py, and
+    # dL_dcov3D lands between 0.4 and 1.4 times the bar depending on the order of the float atomics)
+    sc = scenes.blob_scene(P, 77, 2, smax=7.0)
     fr = _frame(oracle_mod, rs, sc)
     assert int((fr.radii > 0).sum()) * 4 > P
     for train in (False, True):
