@@ -399,6 +399,12 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *                     kernel, and always the deterministic mode's -- instead of one workgroup per (tile, piece) work
  *                     item that gathers a piece's records once for the tile's four quadrant waves and leaves one
  *                     record update per (entry, piece) (A/B)
+ *   "band_sort_min" (ABI v9, process-wide only) frames whose capacity guess (binning_capacity) is at least this   default 6 000 000
+ *                     many instances renumber K1's survivors by the band of tiles their rectangle starts in before the
+ *                     tile-table kernels count and scatter them (two more small launches; a workgroup's instances then
+ *                     land next to each other: C5 941-957 -> 1 025-1 071 frames/s, dense stress scene 916 -> 1 229-1 243;
+ *                     C3's 1.2 M instances stay below it).  0: every frame; -1: none.  The tile lists are the same
+ *                     either way -- the order inside a tile segment before the tile sort is not observable.
  *   "timing"       1: record per-stage HIP events (see gcr_get_stage_ms)             default 0
  *   "gate_polls"   polls (about 5 us each) a frame gate waits for an overflow rescue to START before it       default 400000
  *                     gives up and the ticket resolves to GCR_ERR_DEVICE (gcr_forward_async)

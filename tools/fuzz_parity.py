@@ -76,6 +76,9 @@ def with_round5_options(c):
     """Options added after the generator's draw order was fixed (the case sequence of a seed must not move): derived from
     the case's own seed.  wave_units: the backward blend as one wave per (work item, quadrant) -- a quarter of the cases."""
     c.setdefault("wave_units", int(c["seed"] % 4 == 0))
+    # round 6: the survivors renumbered by tile band in front of the tile-table kernels (option band_sort_min = 0) -- a
+    # third of the cases; the others keep the default (frames of this size are not band-sorted)
+    c.setdefault("band_sort", int(c["seed"] % 3 == 0))
     return c
 
 
@@ -94,6 +97,8 @@ def run_case(c, O, G, scenes, N, dev):
     opts = dict(bwd_piece=c["piece"], lazy_sort=c["lazy"], sort_in_blend=c["sort_in_blend"],
                 split_preprocess=c["split_preprocess"], deterministic_backward=c["deterministic"],
                 bwd_wave_units=c["wave_units"])
+    if c["band_sort"]:
+        opts["band_sort_min"] = 0
     prev = {k: N.set_option(k, v) for k, v in opts.items()}
     try:
         args, out = G.run_forward(rs, sc, dev, use_sh=c["use_sh"], for_backward=c["train_frame"])
