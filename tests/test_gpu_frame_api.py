@@ -145,3 +145,41 @@ def test_frame_entry_point_overflow_is_rescued(oracle_mod, cuda_device, monkeypa
     np.testing.assert_array_equal(radii.cpu().numpy(), fr.radii)
     ext._ring(N.lib()).harvest()
     assert ext._hint_get(key)[0] == fr.R  # the ticket nobody holds still refreshes the hint
+
+
+def test_frame_entry_point_soak_with_short_guesses(oracle_mod, cuda_device, monkeypatch):
+    """240 inference frames of four poses back to back over three streams, nothing synchronised in between, every twelfth
+    one with its capacity guess cut to 36 instances (the rescue renders it into the scratch block the call has long given
+    back to the allocator -- in stream order, behind the frame's gate): every image compared ON THE DEVICE with the oracle's
+    as soon as it is enqueued (the comparison kernels queue behind the frame), the rescues counted."""
+    from gaussiancity_amd import _native as N, ext
+    P, W, H = 3500, 176, 128
+    sc = scenes.blob_scene(P, 71, 2)
+    cams = [scenes.camera(W, H, pose_index=i)._replace(sh_degree=2) for i in (1, 5, 9, 13)]
+    want = [torch.from_numpy(_frame(oracle_mod, rs, sc).out_color).to(cuda_device).view(torch.int32) for rs in cams]
+    argsets = [_frame_args(_args(rs, sc, cuda_device)) for rs in cams]
+    key = (cuda_device.index, P, W, H)
+    monkeypatch.setattr(ext, "_ASYNC_MARGIN", 16)
+    for a in argsets:  # learn the hints (synchronous first frame of the key)
+        ext.rasterize_gaussians_frame(*a)
+    torch.cuda.synchronize()
+    monkeypatch.setattr(ext, "_ASYNC_MARGIN", 65536)
+    rescued0 = N.lib().gcr_rescue_count()
+    streams = [torch.cuda.Stream(device=cuda_device) for _ in range(3)]
+    bad = torch.zeros(240, dtype=torch.int32, device=cuda_device)
+    cut = 0
+    for i in range(240):
+        with torch.cuda.stream(streams[i % 3]):
+            if i % 12 == 5:
+                ext._ring(N.lib()).harvest()
+                monkeypatch.setattr(ext, "_ASYNC_MARGIN", 16)
+                ext._capacity_hint[key] = (10, 64)
+                cut += 1
+            img, _ = ext.rasterize_gaussians_frame(*argsets[i % 4])
+            if i % 12 == 5:
+                monkeypatch.setattr(ext, "_ASYNC_MARGIN", 65536)
+            bad[i] = (img.view(torch.int32) != want[i % 4]).sum()
+            del img
+    torch.cuda.synchronize()
+    assert int(bad.sum()) == 0, bad.nonzero().flatten().tolist()[:10]
+    assert N.lib().gcr_rescue_count() - rescued0 == cut == 20
