@@ -682,6 +682,8 @@ def main():
                 n_cpu += 1
             _, o = fwd(n_cpu - 1)
             same = bool(np.array_equal(o[1].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32)))
+            if not args.backward:  # ... and the same frame through the timed entry point (the Python API's inference frame)
+                same = same and bool(np.array_equal(fwd.api(n_cpu - 1)[0].cpu().numpy().view(np.uint32), fr.out_color.view(np.uint32)))
             threads = O.num_threads()
             O.set_num_threads(1)
             tc = time.perf_counter()
