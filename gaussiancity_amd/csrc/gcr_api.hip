@@ -34,6 +34,20 @@ std::atomic<int> g_gate_polls{400000};  // polls before a frame gate gives up wa
 // (gcr_binning.hip "band sort": two launches more, a scatter that writes whole sectors).  0: every frame; -1: none.
 std::atomic<int> g_band_sort_min{GCR_BAND_SORT_MIN_DEFAULT};
 std::atomic<int> g_bwd_piece{160};  // entries per backward piece of frames rendered for a backward (gcr_camera.backward)
+// Cache policy of a frame's one-pass streams (option "stream_policy"; gcr_preprocess.hip "NT", gcr_blend.hip `nt_out`;
+// results are identical either way).  -1 = automatic: non-temporal for the frames of the SYNCHRONOUS entry points
+// (gcr_forward, gcr_forward_preprocess: the caller waits for num_rendered, so its next cull cannot start before this one
+// has ended) while no other such frame of the process is between its enqueue and that answer; the default policy for
+// asynchronous frames, whose culls run side by side and share their lines.  0 = never, 1 = always.
+std::atomic<int> g_stream_policy{-1};
+std::atomic<int> g_sync_culls{0};  // synchronous frames whose num_rendered has not reached the host yet
+struct SyncCullGuard {             // (counts one such frame for the lifetime of the object)
+  const int others;
+  SyncCullGuard() : others(g_sync_culls.fetch_add(1)) {}
+  ~SyncCullGuard() { g_sync_culls.fetch_sub(1); }
+  SyncCullGuard(const SyncCullGuard&) = delete;
+  SyncCullGuard& operator=(const SyncCullGuard&) = delete;
+};
 #ifdef GCR_EXPERIMENTS  // make EXTRA=-DGCR_EXPERIMENTS: timing experiments, never in the shipping library
 std::atomic<int> g_k7_skip_flush{0};  // K7 drops its global atomics: results are wrong when set
 std::atomic<int> g_k6_debug{0};  // forward blend knock-outs (gcr_blend.hip GCR_K6_*)
@@ -45,6 +59,7 @@ std::atomic<unsigned long long*> g_clock_buf{nullptr};  // K7 per-wave phase clo
 struct Opts {
   int lazy_sort, sort_in_blend, bwd_piece, deterministic, split_preprocess, force_radix, force_global_cursor, bwd_wave_units;
   int band_sort_min;  // process-wide only (no field in gcr_options: the record keeps its size)
+  int stream_policy;  // process-wide only
 };
 Opts resolve_options(const gcr_options* o) {
   Opts r;
@@ -57,6 +72,7 @@ Opts resolve_options(const gcr_options* o) {
   r.force_global_cursor = g_force_global_cursor.load();
   r.bwd_wave_units = g_bwd_wave_units.load();
   r.band_sort_min = g_band_sort_min.load();
+  r.stream_policy = g_stream_policy.load();
   if (o != nullptr) {
     if (o->bwd_wave_units >= 0) r.bwd_wave_units = o->bwd_wave_units != 0;
     if (o->lazy_sort >= 0) r.lazy_sort = o->lazy_sort != 0;
@@ -303,6 +319,7 @@ int gcr_set_option(const char* name, int value) {
   if (!strcmp(name, "gate_polls")) return g_gate_polls.exchange(value < 1 ? 1 : value);
   if (!strcmp(name, "timing")) return g_timing.exchange(value);
   if (!strcmp(name, "band_sort_min")) return g_band_sort_min.exchange(value < 0 ? -1 : value);
+  if (!strcmp(name, "stream_policy")) return g_stream_policy.exchange(value < 0 ? -1 : (value != 0));
   if (!strcmp(name, "force_radix")) return g_force_radix.exchange(value);
   if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.exchange(value);
 #ifdef GCR_EXPERIMENTS
@@ -327,6 +344,7 @@ int gcr_get_option(const char* name) {
   if (!strcmp(name, "gate_polls")) return g_gate_polls.load();
   if (!strcmp(name, "timing")) return g_timing.load();
   if (!strcmp(name, "band_sort_min")) return g_band_sort_min.load();
+  if (!strcmp(name, "stream_policy")) return g_stream_policy.load();
   if (!strcmp(name, "force_radix")) return g_force_radix.load();
   if (!strcmp(name, "force_global_cursor")) return g_force_global_cursor.load();
   if (!strcmp(name, "split_preprocess")) return g_split_preprocess.load();
@@ -376,7 +394,7 @@ static inline bool band_sort_slot_free(const Opts& op, int T) {
 static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_t geom_bytes,
                               void* img, size_t img_bytes, int32_t* radii, unsigned long long cap_instances,
                               unsigned long long cap_list, unsigned long long** frame_dev_out, hipStream_t s,
-                              unsigned long long* host_R = nullptr, unsigned int seq = 0) {
+                              unsigned long long* host_R = nullptr, unsigned int seq = 0, bool nt_stream = false) {
   if (!geom || !radii || !img) return fail(GCR_ERR_INVALID_ARGUMENT, "geom/img/radii must be non-null");
   gcr_layout L;
   compute_layout(g->P, cam->img_w, cam->img_h, 0, &L);
@@ -405,6 +423,7 @@ static int enqueue_preprocess(const Opts& op, const gcr_camera* cam, const gcr_g
   a.prefiltered = cam->prefiltered != 0;
   a.cull_cache = op.split_preprocess ? nullptr : reinterpret_cast<const float4*>(g->cull_cache);
   a.cull_shape = a.cull_cache ? reinterpret_cast<const float4*>((const char*)g->cull_cache + gcr_cull_cache_offset_b(g->P)) : nullptr;
+  a.nt_stream = nt_stream ? 1 : 0;
   fill_cam(a.cam, cam);
   a.radii = radii;
   a.rec = (float4*)(gb + L.geom_rec);
@@ -496,7 +515,7 @@ static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_g
                               int64_t R_layout, int64_t list_length_hint, bool speculative,
                               unsigned long long cap_instances, unsigned long long cap_list, float* out_color,
                               hipStream_t s, unsigned long long* host_longest = nullptr,
-                              unsigned long long* gate_words = nullptr, unsigned int gate_seq = 0) {
+                              unsigned long long* gate_words = nullptr, unsigned int gate_seq = 0, bool nt_out = false) {
   gcr_layout L;
   compute_layout(g->P, cam->img_w, cam->img_h, R_layout, &L);
   char *gb = (char*)geom, *bb = (char*)binning, *ib = (char*)img;
@@ -559,6 +578,7 @@ static int enqueue_render_lds(const Opts& op, const gcr_camera* cam, const gcr_g
   b.flip_x = cam->flip_x != 0; b.flip_y = cam->flip_y != 0;
   b.win_x = cam->win_x; b.win_y = cam->win_y; b.win_w = cam->win_w; b.win_h = cam->win_h;
   b.out_u8 = cam->out_u8 != 0 && cam->backward != 1;
+  b.nt_out = nt_out && cam->backward != 1;
   fill_cam(b.cam, cam);
   b.final_T = (float*)(ib + L.img_final_T);
   b.n_contrib = (uint32_t*)(ib + L.img_n_contrib);
@@ -674,7 +694,10 @@ int gcr_forward_preprocess(const gcr_camera* cam, const gcr_gaussians* g, void* 
   const Opts op = resolve_options(cam->options);
   hipStream_t s = (hipStream_t)hip_stream;
   unsigned long long* frame = nullptr;
-  if (int rc = enqueue_preprocess(op, cam, g, geom, geom_bytes, img, img_bytes, radii, ~0ull, ~0ull, &frame, s)) return rc;
+  const SyncCullGuard sync_cull;  // (until this call returns: the copy below is the frame's host wait)
+  const bool nt = op.stream_policy > 0 || (op.stream_policy < 0 && sync_cull.others == 0);
+  if (int rc = enqueue_preprocess(op, cam, g, geom, geom_bytes, img, img_bytes, radii, ~0ull, ~0ull, &frame, s, nullptr, 0, nt))
+    return rc;
   unsigned long long r[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(r, frame, sizeof(r), hipMemcpyDeviceToHost, s), "num_rendered copy");
   HIP_TRY(hipStreamSynchronize(s), "num_rendered sync");  // cr/rasterizer_impl.cu:236-238
@@ -715,15 +738,19 @@ int gcr_forward(const gcr_camera* cam, const gcr_gaussians* g, void* geom, size_
   FrameReadback& rb = g_readback;
   const unsigned int seq = ++rb.seq ? rb.seq : ++rb.seq;  // never 0: the word starts out as 0
   unsigned long long* frame = nullptr;
+  // "stream_policy": this caller's next cull cannot start before the wait below has seen this one end
+  const SyncCullGuard sync_cull;
+  const bool nt = op.stream_policy > 0 || (op.stream_policy < 0 && sync_cull.others == 0);
   if (int rc = enqueue_preprocess(op, cam, g, geom, geom_bytes, img, img_bytes, radii,
                                   speculate ? (unsigned long long)binning_capacity : 0ull, ~0ull, &frame, s,
-                                  rb.pinned, seq))
+                                  rb.pinned, seq, nt))
     return rc;
   if (speculate) {
     // Everything else of the frame is enqueued before the host knows R: the kernels read the
     // tile ranges from device memory and are vetoed by frame[2] if the capacity guess was short.
     if (int rc = enqueue_render_lds(op, cam, g, geom, binning, img, binning_capacity, list_hint, true,
-                                    (unsigned long long)binning_capacity, ~0ull, out_color, s, rb.pinned + 1))
+                                    (unsigned long long)binning_capacity, ~0ull, out_color, s, rb.pinned + 1,
+                                    nullptr, 0, nt))
       return rc;
   }
   // the one host wait of the frame: poll the pinned word until the kernel after K1 has tagged it with this frame
@@ -1008,8 +1035,9 @@ int gcr_forward_async(const gcr_camera* cam, const gcr_gaussians* g, void* geom,
   hipStream_t s = (hipStream_t)hip_stream;
   const int64_t list_hint = tile_list_capacity > 0 ? tile_list_capacity : (int64_t)gcr_tile_sort_capacity();
   unsigned long long* frame = nullptr;
+  // (asynchronous frames are what runs side by side: their streams keep the default cache policy unless "stream_policy" is 1)
   if (int rc = enqueue_preprocess(op, cam, g, geom, geom_bytes, img, img_bytes, radii, (unsigned long long)binning_capacity,
-                                  ~0ull, &frame, s, words_host, seq))
+                                  ~0ull, &frame, s, words_host, seq, op.stream_policy > 0))
     return rc;
   AsyncFrame f;
   memset((void*)&f, 0, sizeof(f));
@@ -1036,7 +1064,8 @@ int gcr_forward_async(const gcr_camera* cam, const gcr_gaussians* g, void* geom,
   f.born = std::chrono::steady_clock::now();
   rescue_service().add(f);  // (before the kernel that may call for it is enqueued)
   const int rc = enqueue_render_lds(op, cam, g, geom, binning, img, binning_capacity, list_hint, true,
-                                    (unsigned long long)binning_capacity, ~0ull, out_color, s, words_host + 1, words_host, seq);
+                                    (unsigned long long)binning_capacity, ~0ull, out_color, s, words_host + 1, words_host, seq,
+                                    op.stream_policy > 0);
   if (rc < 0) rescue_service().remove(words_host, seq);  // no gate was enqueued: nobody will ever call for this frame
   return rc;
 }
@@ -1111,7 +1140,8 @@ int gcr_forward_render(const gcr_camera* cam, const gcr_gaussians* g, void* geom
   // Tile lists beyond the LDS sort capacity are sorted by the same workgroup with runs + merge passes; every
   // other tile stays on the LDS path (no whole-frame fallback for a long list).
   if (R == 0 || !op.force_radix)
-    return enqueue_render_lds(op, cam, g, geom, binning, img, R, info->max_tile_instances, false, ~0ull, ~0ull, out_color, s);
+    return enqueue_render_lds(op, cam, g, geom, binning, img, R, info->max_tile_instances, false, ~0ull, ~0ull, out_color, s,
+                              nullptr, nullptr, 0, op.stream_policy > 0);
 
   // "force_radix" (A/B and test option): the reference's own scheme -- emit tile|depth keys in index
   // order, stable global radix sort, boundary scan.

@@ -548,8 +548,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   if (g.pxi < a.W && g.pyi < a.H && (!STATE || a.out_color != nullptr)) {  // (state-only pass: pixels already stored)
     const float Tout = __builtin_fabsf(Tw);
     const size_t pix_id = (size_t)a.W * g.pyi + g.pxi;
-    a.final_T[pix_id] = Tout;
-    a.n_contrib[pix_id] = last_contributor;
+    // a.nt_out (block-uniform; round 6): an inference frame's per-pixel outputs are not read again on the device -- stored
+    // with the non-temporal policy they do not push the next frame's inputs out of the caches.  Set for callers that wait
+    // for every frame's num_rendered (one frame alone 0.262 -> 0.253 ms with it); beside two other frames' kernels it
+    // buys nothing (profiles/r06_cache_policy_ab.jsonl), and a training frame's backward reads all of it.
+    const bool nt_out = !STATE && a.nt_out != 0;
+    if (nt_out) {
+      __builtin_nontemporal_store(Tout, a.final_T + pix_id);
+      __builtin_nontemporal_store(last_contributor, a.n_contrib + pix_id);
+    } else {
+      a.final_T[pix_id] = Tout;
+      a.n_contrib[pix_id] = last_contributor;
+    }
     // the image may be stored mirrored (the wrapper's flip_lr / flip_ud without a copy kernel) and / or as a window of
     // the frame (the helpers' crop without slice kernels); the per-pixel state is neither
     size_t oplane;
@@ -565,6 +575,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         o[0] = gcr_video_byte(c0);
         o[1] = gcr_video_byte(c1);
         o[2] = gcr_video_byte(c2);
+      } else if (nt_out) {
+        __builtin_nontemporal_store(c0, a.out_color + out_id);
+        __builtin_nontemporal_store(c1, a.out_color + oplane + out_id);
+        __builtin_nontemporal_store(c2, a.out_color + 2 * oplane + out_id);
       } else {
         a.out_color[out_id] = c0;
         a.out_color[oplane + out_id] = c1;

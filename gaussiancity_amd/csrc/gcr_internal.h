@@ -49,6 +49,7 @@ struct GcrPreprocessArgs {
   int prefiltered;  // gcr_camera.prefiltered: a Gaussian behind the near plane is an error of the caller (GCR_PREFILTER_*)
   const float4* cull_cache;  // gcr_gaussians.cull_cache, part A: [P] (mean, rho) records of gcr_build_cull_cache, or null (stateless)
   const float4* cull_shape;  // ... part B: [P] x 32 bytes (scales, opacity, rotation) or (covariance, opacity, 0)
+  int nt_stream;  // the stateless fused kernel streams its inputs with the non-temporal policy (gcr_preprocess.hip "NT"): results identical
   GcrCamVals cam;
 };
 
@@ -228,6 +229,7 @@ struct GcrBlendArgs {
   int win_x, win_y, win_w, win_h;  // output window in image coordinates AFTER mirroring (win_w == 0: whole image)
   int flip_x, flip_y;       // fwd: out_color stored mirrored; bwd: dL_dpix loaded mirrored (gcr_camera.flip_x / flip_y)
   int out_u8;               // fwd: out_color is uint8 [H,W,3] video frames (gcr_camera.out_u8)
+  int nt_out;               // fwd, frames without backward state: final_T / n_contrib / float image stored with the non-temporal policy
   GcrCamVals cam;           // bg by value when cam.by_value
   int debug_flags;  // experiment builds only (GCR_EXPERIMENTS, "k7_skip_flush"): bit 0 = K7 drops its global atomics
   // pieces / checkpoints (above)

@@ -135,27 +135,41 @@ struct PhaseAIn {
   float c0, c1, c2, c3, c4, c5, c6;  // scale.xyz + rot.rxyz, or cov3D[0..5] (scalars: stay in VGPRs)
 };
 
+// NT (round 6): the stream's loads carry the non-temporal policy -- the instruction stream is otherwise the same.
+// A streaming cull that has the memory system to itself is latency-bound (C3: 330 MB in 75 us = 4.4 TB/s) and its
+// lines are read once: with `nt` they land 9 % sooner (75 -> 68.6 us).  Three culls of three frames in flight read the
+// SAME arrays a few microseconds apart and live on each other's lines in L2 / Infinity Cache: there `nt` costs 8 %
+// (149 -> 161 us each, 5 740 -> 5 550 frames/s).  So the host picks: GcrPreprocessArgs.nt_stream, set by the entry
+// points whose caller waits for num_rendered in every frame -- no second cull of that caller can be running
+// (profiles/r06_cache_policy_ab.jsonl).
+template <bool NT, typename T>
+GCR_DEV T k1_stream_load(const T* p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
 // The load is unconditional (callers clamp idx into range): a predicated prefetch makes the
 // compiler's s_waitcnt placement lose count across the loop back-edge and wait for everything.
-template <bool PRECOMP_COV>
+template <bool PRECOMP_COV, bool NT = false>
 GCR_DEV void phase_a_load(const GcrPreprocessArgs& a, long long idx, PhaseAIn& in) {
   const float* __restrict__ mp = a.means3D + (size_t)idx * a.s_mean;  // row strides: 3 / 3 / 4 floats when dense,
-  in.p = {mp[0], mp[1], mp[2]};                                       // 14 for column slices of a [N,14] tensor
+  in.p = {k1_stream_load<NT>(mp), k1_stream_load<NT>(mp + 1), k1_stream_load<NT>(mp + 2)};  // 14 for column slices of a [N,14] tensor
   if (PRECOMP_COV) {
     const float* __restrict__ c = a.cov3D_precomp + 6 * (size_t)idx;
-    in.c0 = c[0]; in.c1 = c[1]; in.c2 = c[2]; in.c3 = c[3]; in.c4 = c[4]; in.c5 = c[5];
+    in.c0 = k1_stream_load<NT>(c); in.c1 = k1_stream_load<NT>(c + 1); in.c2 = k1_stream_load<NT>(c + 2);
+    in.c3 = k1_stream_load<NT>(c + 3); in.c4 = k1_stream_load<NT>(c + 4); in.c5 = k1_stream_load<NT>(c + 5);
     in.c6 = 0.0f;
   } else {
     const float* __restrict__ sp = a.scales + (size_t)idx * a.s_scale;
-    in.c0 = sp[0];
-    in.c1 = sp[1];
-    in.c2 = sp[2];
+    in.c0 = k1_stream_load<NT>(sp);
+    in.c1 = k1_stream_load<NT>(sp + 1);
+    in.c2 = k1_stream_load<NT>(sp + 2);
     const float* __restrict__ rp = a.rotations + (size_t)idx * a.s_rot;
     if (a.s_rot == 4) {  // dense: one 16-byte load (the array is 16-byte aligned: torch allocations are)
-      const float4 rot = *reinterpret_cast<const float4*>(rp);
+      typedef float gcr_f4 __attribute__((ext_vector_type(4)));
+      const gcr_f4 rot = k1_stream_load<NT>(reinterpret_cast<const gcr_f4*>(rp));
       in.c3 = rot.x; in.c4 = rot.y; in.c5 = rot.z; in.c6 = rot.w;
     } else {
-      in.c3 = rp[0]; in.c4 = rp[1]; in.c5 = rp[2]; in.c6 = rp[3];
+      in.c3 = k1_stream_load<NT>(rp); in.c4 = k1_stream_load<NT>(rp + 1); in.c5 = k1_stream_load<NT>(rp + 2); in.c6 = k1_stream_load<NT>(rp + 3);
     }
   }
 }
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(256) void k_preprocess_project(const GcrPreprocessA
 // are waiting (all lanes busy) and once more at the end of the chunk.
 constexpr int FUSED_CAP = 512;  // <= 255 left over + <= 256 new candidates per iteration
 
-template <bool PRECOMP_COV>
+template <bool PRECOMP_COV, bool NT>
 __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArgs a) {
   __shared__ uint32_t sIdx[FUSED_CAP];
   __shared__ float sIn[10][FUSED_CAP];
@@ -619,15 +633,18 @@ __global__ __launch_bounds__(256) void k_preprocess_fused(const GcrPreprocessArg
   // kernel fetched at C3.  K1 alone: C3 82.3 -> 83.2 us, C5 355 -> 347 us, C2 18.3 -> 17.1 us
   // (profiles/r05_k1_ab_stateless_clamp_touch.jsonl, one process, alternating).
   const long long last = chunk_end - 1;
-  phase_a_load<PRECOMP_COV>(a, idx64 < last ? idx64 : last, cur);
-  phase_a_load<PRECOMP_COV>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);
+  phase_a_load<PRECOMP_COV, NT>(a, idx64 < last ? idx64 : last, cur);
+  phase_a_load<PRECOMP_COV, NT>(a, idx64 + 256 < last ? idx64 + 256 : last, nxt);
   for (long long base = chunk_begin; base < chunk_end; base += 256, parity ^= 1u) {
     idx64 = base + tid;
-    phase_a_load<PRECOMP_COV>(a, idx64 + 512 < last ? idx64 + 512 : last, nx2);  // prefetch, two iterations ahead
+    phase_a_load<PRECOMP_COV, NT>(a, idx64 + 512 < last ? idx64 + 512 : last, nx2);  // prefetch, two iterations ahead
     bool candidate = false;
     if (idx64 < chunk_end) {
       candidate = !phase_a0_certainly_culled<PRECOMP_COV>(a, vm, pm, wf2, cur, cull_rho<PRECOMP_COV>(a.scale_modifier, cur));
-      if (!candidate) a.radii[idx64] = 0;
+      if (!candidate) {  // (nobody reads a culled Gaussian's zero again in this frame)
+        if (NT) __builtin_nontemporal_store(0, a.radii + idx64);
+        else a.radii[idx64] = 0;
+      }
       if (a.prefiltered) viol |= near_plane_violation(vm, cur);
     }
     const uint64_t m = __ballot(candidate);
@@ -1372,9 +1389,11 @@ hipError_t gcr_launch_preprocess(const GcrPreprocessArgs& a, bool split, hipStre
       else
         k_preprocess_fused_cached<false><<<a.nblocks, 256, 0, s>>>(a);
     } else if (a.cov3D_precomp != nullptr) {
-      k_preprocess_fused<true><<<a.nblocks, 256, 0, s>>>(a);
+      if (a.nt_stream) k_preprocess_fused<true, true><<<a.nblocks, 256, 0, s>>>(a);
+      else k_preprocess_fused<true, false><<<a.nblocks, 256, 0, s>>>(a);
     } else {
-      k_preprocess_fused<false><<<a.nblocks, 256, 0, s>>>(a);
+      if (a.nt_stream) k_preprocess_fused<false, true><<<a.nblocks, 256, 0, s>>>(a);
+      else k_preprocess_fused<false, false><<<a.nblocks, 256, 0, s>>>(a);
     }
     return hipGetLastError();
   }

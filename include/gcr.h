@@ -405,6 +405,14 @@ int64_t gcr_rasterize_forward(gcr_resize_fn geometry_buffer, void *geometry_user
  *                     land next to each other: C5 941-957 -> 1 025-1 071 frames/s, dense stress scene 916 -> 1 229-1 243;
  *                     C3's 1.2 M instances stay below it).  0: every frame; -1: none.  The tile lists are the same
  *                     either way -- the order inside a tile segment before the tile sort is not observable.
+ *   "stream_policy" (process-wide only) cache policy of a frame's one-pass streams -- the streaming cull's input loads,   default -1
+ *                     the zeros it stores for culled Gaussians, an inference frame's per-pixel outputs.  -1: non-temporal
+ *                     for frames of the entry points that wait for num_rendered (gcr_forward, gcr_forward_preprocess)
+ *                     while no other such frame of the process is waiting -- the caller's next cull cannot overlap this
+ *                     one: C3 through the int-returning binding 5 150 -> 5 330 frames/s, one frame alone 0.262 ->
+ *                     0.248 ms -- and the default policy for asynchronous frames, whose culls run side by side and
+ *                     live on each other's lines in L2 / Infinity Cache (non-temporal there: 5 740 -> 5 580).
+ *                     0: never; 1: always.  The results are the same bits either way.
  *   "timing"       1: record per-stage HIP events (see gcr_get_stage_ms)             default 0
  *   "gate_polls"   polls (about 5 us each) a frame gate waits for an overflow rescue to START before it       default 400000
  *                     gives up and the ticket resolves to GCR_ERR_DEVICE (gcr_forward_async)
