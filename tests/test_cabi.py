@@ -144,6 +144,9 @@ def test_abi_v5_argument_checks_without_a_gpu():
     assert lib.gcr_set_option(b"bwd_piece", 10) == default_piece and lib.gcr_set_option(b"bwd_piece", 128) == 64     # clamped to 64..223
     assert lib.gcr_set_option(b"bwd_piece", 4096) == 128 and lib.gcr_set_option(b"bwd_piece", default_piece) == 223  # (upper clamp)
     assert lib.gcr_get_option(b"bwd_piece") == default_piece
+    # "stream_policy" (round 6): -1 automatic / 0 never / 1 always, process-wide, no struct field
+    assert lib.gcr_get_option(b"stream_policy") == -1 and lib.gcr_set_option(b"stream_policy", 5) == -1
+    assert lib.gcr_set_option(b"stream_policy", -3) == 1 and lib.gcr_get_option(b"stream_policy") == -1
     assert lib.gcr_set_option(b"deterministic_backward", 1) == 0 and lib.gcr_grad_record_floats() == 32
     assert lib.gcr_set_option(b"deterministic_backward", 0) == 1 and lib.gcr_grad_record_floats() == 16
 
