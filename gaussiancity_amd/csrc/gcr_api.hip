@@ -1331,7 +1331,10 @@ int gcr_backward(const gcr_camera* cam, const gcr_gaussians* g, const int32_t* r
   a.focal_x = cam->img_w / (2.0f * cam->tanfovx);
   a.scale_modifier = cam->scale_modifier;
   a.means3D = g->means3D; a.scales = g->scales; a.rotations = g->rotations; a.shs = g->shs;
-  a.cov3D = g->cov3D_precomp ? g->cov3D_precomp : (const float*)(gb + L.geom_cov3D);  // cr/rasterizer_impl.cu:329-330
+  // cr/rasterizer_impl.cu:329-330 reads the forward's stored covariance when none was supplied; K8 derives it from scales and
+  // rotation again instead (gcr_preprocess.hip phase_a1_exact: the same function, the same bits) -- the pointer below is only
+  // read for a supplied covariance
+  a.cov3D = g->cov3D_precomp ? g->cov3D_precomp : (const float*)(gb + L.geom_cov3D);
   a.s_cov3d = g->cov3D_precomp ? 6 : GCR_COV3D_FLOATS;
   a.view = cam->view_matrix; a.proj = cam->proj_matrix; a.campos = cam->campos;
   a.radii = radii;

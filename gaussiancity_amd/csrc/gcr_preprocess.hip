@@ -304,11 +304,11 @@ GCR_DEV bool phase_a1_exact(const GcrPreprocessArgs& a, const float (&vm)[16], c
   out.px = px; out.py = py; out.conx = conx; out.cony = cony; out.conz = conz; out.depth = p_view.z;
   out.rect_x = (uint32_t)minx | ((uint32_t)maxx << 16);
   out.rect_y = (uint32_t)miny | ((uint32_t)maxy << 16);
-  if (!PRECOMP_COV) {  // one whole 32-byte sector (GCR_COV3D_FLOATS)
-    float4* __restrict__ cvo = reinterpret_cast<float4*>(a.cov3D + GCR_COV3D_FLOATS * (size_t)idx);
-    cvo[0] = make_float4(cov3D[0], cov3D[1], cov3D[2], cov3D[3]);
-    cvo[1] = make_float4(cov3D[4], cov3D[5], 0.0f, 0.0f);
-  }
+  // (The covariance is NOT kept in the geometry buffer any more -- round 6, late.  Upstream stores it for its backward
+  // (cr/forward.cu:185-188, cr/backward.cu:384-391); here the one kernel that needs it, K8, recomputes it from the same
+  // scales and rotation with the same compute_cov3d -- the same bits -- instead of every forward paying a 32-byte store
+  // into a fresh sector per survivor: at C3 the cull alone 76.8 -> 70 us, 153 -> 140 us each with three frames in flight,
+  // 5 720 -> 5 860 frames/s (profiles/r06_k1_cov3d_store_ab.jsonl).  gcr_layout.geom_cov3D is still carved, and unused.)
   return true;
 }
 
@@ -1028,9 +1028,11 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
   const int idx = (int)my_list[it];
   const float* __restrict__ mp = a.means3D + (size_t)idx * a.s_mean;
   const V3 mean = {mp[0], mp[1], mp[2]};
-  float cv[6];
+  float cv[6];  // the caller's precomputed covariance; else derived below, once scales and rotation are here
+  if (a.scales == nullptr) {
 #pragma unroll
-  for (int i = 0; i < 6; i++) cv[i] = a.cov3D[(size_t)a.s_cov3d * idx + i];
+    for (int i = 0; i < 6; i++) cv[i] = a.cov3D[(size_t)a.s_cov3d * idx + i];
+  }
   float shv[48];  // SH coefficients [i][channel] (zeros beyond M)
   uint8_t cl = 0;
   if (a.shs != nullptr) {
@@ -1055,6 +1057,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(const GcrPreprocessBwdAr
     rot = a.s_rot == 4 ? *reinterpret_cast<const float4*>(rp) : make_float4(rp[0], rp[1], rp[2], rp[3]);
 #pragma unroll
     for (int i = 0; i < 3; i++) scl[i] = a.scales[(size_t)idx * a.s_scale + i];
+    // what K1 computed for this Gaussian (cr/forward.cu:110-143), from the same inputs with the same function: the same bits
+    const V3 sc3 = {scl[0], scl[1], scl[2]};
+    compute_cov3d(sc3, a.scale_modifier, rot, cv);
   }
   // K7's accumulation record of this Gaussian (gcr_internal.h); the API's per-Gaussian outputs of the
   // blend gradient are written from it here

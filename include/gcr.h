@@ -203,7 +203,9 @@ typedef struct gcr_layout {
   size_t geom_rec;           /* float[16] per Gaussian, one 64-byte block (ABI v8; 12 floats at a 48-byte stride before):
                                 x,y,conic.x,conic.y | conic.z,opacity,r,g | b,depth,rect_x(min|max<<16),rect_y(min|max<<16) |
                                 clamp mask as uint32 (bit ch set = colour channel ch clamped), 0, 0, 0 */
-  size_t geom_cov3D;         /* float[6] per Gaussian in a 32-byte slot (ABI v8: stride 8 floats, the last two are 0) */
+  size_t geom_cov3D;         /* unused since round 6 (late): 32 bytes per Gaussian are still carved, nothing is written -- the backward
+                                derives a Gaussian's covariance from its scales and rotation again (same function, same bits) instead of
+                                every forward storing it (float[6] in a 32-byte slot in ABI v8 / v9 builds before that) */
   size_t geom_clamped;       /* unused since ABI v8 (the mask lives in the record's fourth quad); P bytes are still carved */
   size_t geom_tiles_touched; /* uint32 per Gaussian   (radix fallback path only) */
   size_t geom_block_sums;    /* uint32 per 256-Gaussian block (radix fallback path only) */

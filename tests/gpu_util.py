@@ -56,7 +56,6 @@ def decode(P, W, H, out):
         means2D=rec[:, 0:2], conic_opacity=np.concatenate([rec[:, 2:5], rec[:, 5:6]], 1),
         rgb=rec[:, 6:9], depths=rec[:, 9],
         rect=rec[:, 10:12].copy().view(np.uint32),   # (min | max << 16) in x and y, tile units
-        cov3D=gb[L.geom_cov3D:L.geom_cov3D + P * 32].view(np.float32).reshape(P, 8)[:, :6],   # 32-byte slots
         clamped=rec[:, 12].copy().view(np.uint32).astype(np.uint8),   # the record's fourth quad carries the clamp mask
         final_T=ib[L.img_final_T:L.img_final_T + 4 * W * H].view(np.float32),
         n_contrib=ib[L.img_n_contrib:L.img_n_contrib + 4 * W * H].view(np.uint32),

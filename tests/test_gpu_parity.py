@@ -43,8 +43,8 @@ def _check_forward(fr, d, P, use_sh, has_cov3d_state=True):
         cl = fr.clamped[:P]
         mask = (cl[:, 0] | (cl[:, 1] << 1) | (cl[:, 2] << 2)).astype(np.uint8)
         np.testing.assert_array_equal(d["clamped"][vis], mask[vis])
-    if has_cov3d_state:
-        assert np.array_equal(d["cov3D"][vis].view(np.uint32), fr.cov3D[:P][vis].view(np.uint32))
+    # (`has_cov3d_state`: until late in round 6 the geometry buffer held every survivor's covariance and it was compared
+    # here; the forward no longer stores it -- K8 derives it again, and the gradients that depend on it are what is checked)
     if fr.R > 0:
         G.assert_point_list(d, fr)
     np.testing.assert_array_equal(d["ranges"], fr.ranges)
