@@ -49,6 +49,9 @@
 extern "C" {
 #endif
 
+/* 9 since round 6.  The number moves when a struct changes size or an entry point its signature; two late changes of round 6 did
+ * neither and kept it: the process-wide option "stream_policy" (gcr_set_option), and gcr_layout.geom_cov3D, which is still carved
+ * and no longer written. */
 #define GCR_ABI_VERSION 9
 #define GCR_BLOCK_X 16 /* cr/config.h:16 */
 #define GCR_BLOCK_Y 16 /* cr/config.h:17 */
