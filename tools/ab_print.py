@@ -1,3 +1,5 @@
+"""One line per run of a tools/ab_variants.sh record of bench.py lines: variant, frames/s, frame latency, per-stage ms (in flight, alone).
+    python tools/ab_print.py gpurun_out/<tag>_ab.jsonl"""
 import json,sys
 v=None
 for l in open(sys.argv[1]):

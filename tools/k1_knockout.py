@@ -1,3 +1,6 @@
+"""K1 (the fused cull) alone at C3 through the stage timer, once per cache policy (option stream_policy 0 / 1), for the library
+GCR_LIB_PATH names -- the timing side of the knock-out builds recorded in profiles/r06_k1_knockouts.jsonl (tools/ab_variants.sh).
+    gpurun -- 'REPS=1 bash tools/ab_variants.sh tag "python tools/k1_knockout.py" ship <variant>'"""
 import json, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
